@@ -1,0 +1,211 @@
+/*
+ * re_hip.h -- C ABI of librender_engine_hip.so: the MI355X-native per-frame visible-set
+ * pipeline of render_engine (spatial-hash visibility query -> frustum/logic cull -> instance
+ * model-matrix pack, and the ECS kinematic / TRS->mat4 tick).
+ *
+ * Plain pointers and sizes only; no C++/torch types.  A Rust `extern "C"` block binds these 1:1
+ * (INTEGRATION.md shows the shim).  Citations are reference file:line under /root/reference/src.
+ *
+ * The reference has no FFI/plugin layer (one Rust crate, generics + fn pointers), so a per-AABB
+ * `TraversalDecider::aabb_in_view` callback (culling/trait.rs:4-7) is the wrong granularity for
+ * a GPU.  The library replaces three *call sites* of Pipeline::execute wholesale:
+ *
+ *   re_cull_pack  <->  flows/pipeline.rs:216-229   (RenderFrustumCuller/LogicFrustumCuller +
+ *                      VisibleWorldFlow::find_visible_world_ids_{entire_world,frustum_aabb} -> CullResult)
+ *                 +    flows/render_flow.rs:401-410 (extract_static_data, sort_world_section_active_entities,
+ *                      append_written_information, upload_instance_data_to_render_system -> InstanceRange table
+ *                      + the bytes MappedBuffer::write_data_serialized would receive, render_components/mapped_buffer.rs:166-189)
+ *   re_tick       <->  flows/logic_flow.rs:230 (update_positions/apply_kinematics :308-448)
+ *                 +    flows/logic_flow.rs:255 -> helper_things/entity_change_helpers.rs:32-189,217-262
+ *                      (apply_change / update_aabb_after_kinematic_change)
+ *   re_upload_entities <-> flows/pipeline.rs:186-208 register_model_instances with an AddInstanceFunction
+ *                      that runs EntityTransformationBuilder::apply_choices (exports/entity_transformer.rs:55-75)
+ *                      + BoundingBoxTree::add_entity/end_of_changes (world/bounding_box_tree_v2.rs:563-762,1055-1130)
+ *
+ * Threading: one ctx = one caller thread at a time (Pipeline::execute runs on the render thread,
+ * threads/render_thread.rs:475-481); different ctxs (one per GPU) may be driven concurrently.
+ * Errors: no exceptions/aborts cross the ABI.  Every call returns RE_OK (0) or a negative code;
+ * re_last_error(ctx) holds the message (the reference panics/unwraps -> lib.rs:45-61 panic hook).
+ */
+#ifndef RE_HIP_H
+#define RE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RE_OK            0
+#define RE_E_ARG        -1   /* bad argument (null pointer, dt == 0 with rotating entities, ...) */
+#define RE_E_HIP        -2   /* HIP runtime error; message carries hipGetErrorString */
+#define RE_E_CAPACITY   -3   /* a configured capacity was exceeded */
+#define RE_E_OOB        -4   /* entity AABB out of world bounds (add_entity -> Err(()), bounding_box_tree_v2.rs:569-572) */
+#define RE_E_STATE      -5   /* call sequence error (e.g. tick before any cull) */
+#define RE_E_UNSUPPORTED -6
+
+/* component-presence / behaviour bits of an entity (re_entities.flags).  They mirror which
+ * components EntityTransformationBuilder writes (exports/entity_transformer.rs:99-142). */
+#define RE_F_STATIC      0x001u  /* is_entity_static: goes to static_entities of its world section */
+#define RE_F_HAS_VEL     0x002u  /* Velocity */
+#define RE_F_HAS_ACC     0x004u  /* Acceleration */
+#define RE_F_HAS_ROT     0x008u  /* Rotation */
+#define RE_F_HAS_ROTVEL  0x010u  /* VelocityRotation */
+#define RE_F_HAS_ROTACC  0x020u  /* AccelerationRotation */
+#define RE_F_HAS_SCALE   0x040u  /* Scale */
+#define RE_F_ALWAYS_EXEC 0x080u  /* AlwaysExecuteLogic (logic_flow.rs:803-836) */
+#define RE_F_OOB_LOGIC   0x100u  /* entity type has OutOfBoundsLogic => add_if_out_bounds (entity_change_helpers.rs:264-274) */
+#define RE_F_HAS_MOVED   0x200u  /* HasMoved marker, maintained by re_tick */
+#define RE_F_HAS_ROTATED 0x400u  /* HasRotated marker, maintained by re_tick */
+
+typedef struct re_ctx re_ctx;
+
+typedef struct {
+    int32_t  device;            /* HIP device ordinal */
+    uint32_t outline_length;    /* BoundingBoxTree::new(outline, atomic): 16384 in render_thread.rs:127 */
+    uint32_t atomic_length;     /* world_section_length: 64 (load_models.rs:52) */
+    uint32_t max_instances;     /* capacity of the packed instance buffer, in instances (0 = number of entities) */
+    uint32_t flags;             /* RE_CFG_* */
+} re_config;
+
+#define RE_CFG_DEFAULT 0u
+
+/* Entities, struct-of-arrays, host pointers; copied during the call.  Optional arrays may be
+ * NULL when no entity carries the corresponding flag. */
+typedef struct {
+    uint32_t n;
+    const uint32_t *entity_id;       /* EntityId(u32), objects/entity_id.rs:6 */
+    const uint32_t *model_index;     /* ModelId.model_index, models/model_definitions.rs:10-14 */
+    const uint32_t *render_system;   /* ModelId.render_system_index (NULL = 0) */
+    const uint32_t *sortable;        /* sortable bucket 0..3, objects/sorted_entities.rs (NULL = 0) */
+    const uint32_t *flags;           /* RE_F_* */
+    const float *original_aabb;      /* n*6: xmin,xmax,ymin,ymax,zmin,zmax (OriginalAABB, model space) */
+    const float *position;           /* n*3 */
+    const float *rotation;           /* n*4 axis xyz + angle (radians); read when RE_F_HAS_ROT */
+    const float *scale;              /* n*3; read when RE_F_HAS_SCALE */
+    const float *velocity;           /* n*3; RE_F_HAS_VEL */
+    const float *acceleration;       /* n*3; RE_F_HAS_ACC */
+    const float *rotation_velocity;  /* n*4 axis + rate; RE_F_HAS_ROTVEL */
+    const float *rotation_acceleration; /* n*4; RE_F_HAS_ROTACC */
+} re_entities;
+
+/* Camera inputs Pipeline::execute reads (flows/pipeline.rs:216-229, render_flow.rs:389-399). */
+typedef struct {
+    float projection_view[16];  /* camera.get_projection_matrix() * get_view_matrix(), column-major */
+    float position[3];
+    float direction[3];
+    float far_draw;             /* get_far_draw_distance() */
+    uint32_t n_lod;             /* default LevelOfView bands (<= 8), prelude/default_render_system.rs:240-256 */
+    float lod_min[8];
+    float lod_max[8];
+} re_camera;
+
+/* re_cull_pack flags */
+#define RE_CULL_EMIT_DUPLICATES 0x1u  /* reproduce the reference's double emission for world sections present twice in
+                                         visible_sections_vec (CullResult::extend, visible_world_flow.rs:31-35, pipeline.rs:228);
+                                         default 0 = each visible instance once (the visible-ID *set*) */
+#define RE_CULL_ASYNC           0x2u  /* enqueue only; results are valid after re_wait() */
+
+/* One (ModelId, sortable) group of the packed buffer == ModelRenderingInformation.instance_location
+ * entry (render_flow.rs:964-983). */
+typedef struct {
+    uint32_t model_index;       /* LOD-adjusted: model_index | min(lod,7) << 25 (model_definitions.rs:31-59) */
+    uint32_t render_system;
+    uint32_t sortable;
+    uint32_t begin_instance;    /* InstanceRange.begin_instance */
+    uint32_t count;             /* InstanceRange.count */
+} re_instance_range;
+
+/* Result of re_cull_pack.  Pointers are library-owned and stay valid until the next
+ * re_cull_pack / re_destroy on the ctx. */
+typedef struct {
+    uint32_t n_visible_sections;      /* |CullResult.visible_sections_map| */
+    uint32_t n_visible_vec;           /* visible_sections_vec.len() (duplicates counted) */
+    uint32_t n_instances;             /* instances the reference would write (sum of group counts) */
+    uint32_t n_written;               /* instances actually stored (min(n_instances, capacity)); the rest is
+                                         truncated like MappedBuffer::write_data_serialized, mapped_buffer.rs:171-186 */
+    uint32_t n_groups;
+    const re_instance_range *groups;  /* host memory, n_groups entries */
+    const uint32_t *d_entity_ids;     /* DEVICE memory, n_written entity ids, group after group */
+    const float    *d_matrices;       /* DEVICE memory, n_written * 16 floats: TransformationMatrix, column-major,
+                                         64 B/instance, byte-identical to what specify_type_ids! appends
+                                         (prelude/layout_update_macros.rs:15-21) */
+} re_visible;
+
+/* re_tick flags */
+#define RE_TICK_ALL_DYNAMIC 0x1u  /* tick every dynamic entity regardless of visibility (default: reference semantics --
+                                     only entities in active visible world sections + AlwaysExecuteLogic entities) */
+#define RE_TICK_ASYNC       0x2u
+
+typedef struct {
+    uint32_t n_changed;        /* entities whose change requests were applied */
+    uint32_t n_rebucket;       /* of those, entities whose world section changed (re-bucketed) */
+    uint32_t n_out_of_bounds;  /* entities add_entity rejected (see re_get_out_of_bounds) */
+} re_tick_result;
+
+/* components for re_read_component (ECS::get_copy<T>, objects/ecs.rs:653-664) */
+#define RE_C_POSITION        0   /* 3 floats */
+#define RE_C_ROTATION        1   /* 4 floats axis+angle */
+#define RE_C_SCALE           2   /* 3 floats */
+#define RE_C_VELOCITY        3   /* 3 floats */
+#define RE_C_ACCELERATION    4   /* 3 floats */
+#define RE_C_ROTATION_VEL    5   /* 4 floats */
+#define RE_C_ROTATION_ACC    6   /* 4 floats */
+#define RE_C_TRANSFORMATION  7   /* 16 floats */
+#define RE_C_STATIC_AABB     8   /* 6 floats */
+#define RE_C_ORIGINAL_AABB   9   /* 6 floats */
+#define RE_C_FLAGS          10   /* 1 uint32: RE_F_* incl. HasMoved/HasRotated */
+
+/* ---- lifecycle ---- */
+int         re_create(const re_config *cfg, re_ctx **out);
+void        re_destroy(re_ctx *ctx);
+const char *re_last_error(const re_ctx *ctx);       /* ctx may be NULL: last error of re_create */
+uint32_t    re_abi_version(void);
+
+/* ---- world ---- */
+/* Replaces the world with these entities: per entity TRS -> TransformationMatrix + StaticAABB on the
+ * GPU, spatial-hash cell assignment, one end_of_changes.  n_rejected (optional) receives the number
+ * of entities whose AABB is out of bounds (they are not inserted; apply_choices prints an error). */
+int re_upload_entities(re_ctx *ctx, const re_entities *ents, uint32_t *n_rejected);
+
+/* ---- frame ---- */
+int re_cull_pack(re_ctx *ctx, const re_camera *cam, uint32_t flags, re_visible *out);
+int re_tick(re_ctx *ctx, float delta_time, uint32_t flags, re_tick_result *out);
+int re_wait(re_ctx *ctx, re_visible *out_visible /*nullable*/, re_tick_result *out_tick /*nullable*/);
+
+/* Copy the packed instance buffer to host memory (the persistent-mapped GL buffer of
+ * RenderSystem::get_instanced_mapped_buffers, render_system/render_system.rs:210-214).  At most
+ * capacity_instances are written; *n_written receives the count (truncate-and-report). */
+int re_copy_visible(re_ctx *ctx, uint32_t *entity_ids_host, float *matrices_host,
+                    uint32_t capacity_instances, uint32_t *n_written);
+/* Direct the packed output into caller-owned DEVICE buffers (e.g. the all-gather send slab);
+ * NULLs restore the internal buffers. */
+int re_set_output_buffers(re_ctx *ctx, uint32_t *d_entity_ids, float *d_matrices, uint32_t capacity_instances);
+
+/* ECS read-back for user logic (LogicFunction reads components through &ECS, exports/logic_components.rs:15-18) */
+int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst);
+/* entity ids rejected by the last re_tick (update_entity_in_tree, entity_change_helpers.rs:325-351) */
+int re_get_out_of_bounds(re_ctx *ctx, uint32_t *entity_ids, uint32_t capacity, uint32_t *n);
+
+/* ---- introspection (parity tests, profiling) ---- */
+typedef struct {
+    uint32_t n_entities, n_dynamic, n_sections, n_shared_sections, max_level;
+    uint64_t device_bytes;
+} re_stats;
+int re_get_stats(re_ctx *ctx, re_stats *out);
+/* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,
+ * bounding_box_tree_v2.rs:21-26); tight = UniqueWorldSectionEntities.aabb (6 floats each).  Any pointer may be NULL. */
+int re_debug_get_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, float *tight_aabb6,
+                          uint32_t *n_local, uint32_t *n_static, uint8_t *is_static_section, uint32_t *n);
+/* visible_sections_map of the last cull, ascending; multiplicity[i] = 2 when the section is in both
+ * the logic and the render result (appears twice in visible_sections_vec). */
+int re_debug_get_visible_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n);
+/* device time of the kernels of the last cull_pack / tick, microseconds (hipEvent on the ctx stream) */
+int re_get_timings(re_ctx *ctx, float *cull_us, float *pack_us, float *tick_us);
+/* the HIP stream of the ctx (hipStream_t as void*) so callers can order their own work after it */
+void *re_get_stream(re_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

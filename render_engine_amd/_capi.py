@@ -1,0 +1,99 @@
+"""ctypes binding of librender_engine_hip.so (include/re_hip.h).  No fallback: if the library is
+missing or cannot be loaded the import of the product path fails loudly."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+RE_OK = 0
+F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
+F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
+F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED = 0x100, 0x200, 0x400
+CULL_EMIT_DUPLICATES, CULL_ASYNC = 0x1, 0x2
+TICK_ALL_DYNAMIC, TICK_ASYNC = 0x1, 0x2
+(C_POSITION, C_ROTATION, C_SCALE, C_VELOCITY, C_ACCELERATION, C_ROTATION_VEL, C_ROTATION_ACC,
+ C_TRANSFORMATION, C_STATIC_AABB, C_ORIGINAL_AABB, C_FLAGS) = range(11)
+COMPONENT_FLOATS = {C_POSITION: 3, C_ROTATION: 4, C_SCALE: 3, C_VELOCITY: 3, C_ACCELERATION: 3, C_ROTATION_VEL: 4,
+                    C_ROTATION_ACC: 4, C_TRANSFORMATION: 16, C_STATIC_AABB: 6, C_ORIGINAL_AABB: 6}
+
+_u32p, _fp = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("outline_length", C.c_uint32), ("atomic_length", C.c_uint32),
+                ("max_instances", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Entities(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("entity_id", _u32p), ("model_index", _u32p), ("render_system", _u32p), ("sortable", _u32p),
+                ("flags", _u32p), ("original_aabb", _fp), ("position", _fp), ("rotation", _fp), ("scale", _fp), ("velocity", _fp),
+                ("acceleration", _fp), ("rotation_velocity", _fp), ("rotation_acceleration", _fp)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("projection_view", C.c_float * 16), ("position", C.c_float * 3), ("direction", C.c_float * 3),
+                ("far_draw", C.c_float), ("n_lod", C.c_uint32), ("lod_min", C.c_float * 8), ("lod_max", C.c_float * 8)]
+
+
+class InstanceRange(C.Structure):
+    _fields_ = [("model_index", C.c_uint32), ("render_system", C.c_uint32), ("sortable", C.c_uint32),
+                ("begin_instance", C.c_uint32), ("count", C.c_uint32)]
+
+
+class Visible(C.Structure):
+    _fields_ = [("n_visible_sections", C.c_uint32), ("n_visible_vec", C.c_uint32), ("n_instances", C.c_uint32),
+                ("n_written", C.c_uint32), ("n_groups", C.c_uint32), ("groups", C.POINTER(InstanceRange)),
+                ("d_entity_ids", C.c_void_p), ("d_matrices", C.c_void_p)]
+
+
+class TickResult(C.Structure):
+    _fields_ = [("n_changed", C.c_uint32), ("n_rebucket", C.c_uint32), ("n_out_of_bounds", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_entities", C.c_uint32), ("n_dynamic", C.c_uint32), ("n_sections", C.c_uint32),
+                ("n_shared_sections", C.c_uint32), ("max_level", C.c_uint32), ("device_bytes", C.c_uint64)]
+
+
+# every symbol include/re_hip.h declares
+EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
+           "re_wait", "re_copy_visible", "re_set_output_buffers", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
+           "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream"]
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Loads the HIP library; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(render_engine_amd has no CPU fallback)")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.re_create.restype = C.c_int; L.re_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.re_destroy.restype = None; L.re_destroy.argtypes = [vp]
+    L.re_last_error.restype = C.c_char_p; L.re_last_error.argtypes = [vp]
+    L.re_abi_version.restype = C.c_uint32; L.re_abi_version.argtypes = []
+    L.re_upload_entities.restype = C.c_int; L.re_upload_entities.argtypes = [vp, C.POINTER(Entities), _u32p]
+    L.re_cull_pack.restype = C.c_int; L.re_cull_pack.argtypes = [vp, C.POINTER(CameraC), C.c_uint32, C.POINTER(Visible)]
+    L.re_tick.restype = C.c_int; L.re_tick.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(TickResult)]
+    L.re_wait.restype = C.c_int; L.re_wait.argtypes = [vp, C.POINTER(Visible), C.POINTER(TickResult)]
+    L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]
+    L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]
+    L.re_read_component.restype = C.c_int; L.re_read_component.argtypes = [vp, C.c_uint32, C.c_int, vp]
+    L.re_get_out_of_bounds.restype = C.c_int; L.re_get_out_of_bounds.argtypes = [vp, vp, C.c_uint32, _u32p]
+    L.re_get_stats.restype = C.c_int; L.re_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.re_debug_get_sections.restype = C.c_int; L.re_debug_get_sections.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, _u32p]
+    L.re_debug_get_visible_sections.restype = C.c_int; L.re_debug_get_visible_sections.argtypes = [vp, C.c_uint32, vp, vp, _u32p]
+    L.re_get_timings.restype = C.c_int; L.re_get_timings.argtypes = [vp, _fp, _fp, _fp]
+    L.re_get_stream.restype = vp; L.re_get_stream.argtypes = [vp]
+    _lib = L
+    return L

@@ -1,0 +1,661 @@
+// re_api.hip -- host side of librender_engine_hip.so: the extern "C" entry points declared in
+// include/re_hip.h, device-memory ownership, world build and per-frame kernel orchestration on one
+// HIP stream per context.  No CPU fallback exists: every entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "re_hip.h"
+#include "re_kernels.h"
+#include "re_math.h"
+
+using namespace re;
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    hipError_t alloc(size_t count, uint64_t *acct) {
+        release(acct);
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e == hipSuccess) { n = count; if (acct) *acct += count * sizeof(T); } else p = nullptr;
+        return e;
+    }
+    void release(uint64_t *acct) { if (p) { (void)hipFree(p); if (acct) *acct -= n * sizeof(T); } p = nullptr; n = 0; }
+};
+
+struct GroupKey { uint32_t model, rs, sort; bool operator==(const GroupKey &o) const { return model == o.model && rs == o.rs && sort == o.sort; } };
+struct GroupKeyHash { size_t operator()(const GroupKey &k) const { return (size_t)k.model * 0x9E3779B97F4A7C15ull ^ ((size_t)k.rs << 32) ^ ((size_t)k.sort << 20); } };
+
+}  // namespace
+
+struct re_ctx {
+    re_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    std::string err;
+    uint64_t dev_bytes = 0;
+    uint32_t maxlevel = 0;
+
+    // rows
+    uint32_t n = 0, ndyn = 0;
+    DevBuf<uint32_t> d_id, d_gclass, d_flags, d_row_cell;
+    DevBuf<float> d_mat, d_pos, d_rot, d_scale;
+    DevBuf<Aabb> d_aabb, d_orig;
+    DevBuf<uint32_t> d_dyn_row; DevBuf<float> d_dyn_vel, d_dyn_acc, d_dyn_rotvel, d_dyn_rotacc;
+    DevBuf<uint64_t> d_row_key; DevBuf<uint8_t> d_row_nk; DevBuf<SharedRec> d_shrec; DevBuf<uint32_t> d_counter;
+    std::vector<uint32_t> h_id, h_flags, h_dyn_row;      // host mirrors of the immutable id column / upload flags / dynamic-row list
+    bool has_rotvel = false;
+    std::unordered_map<uint32_t, uint32_t> id_to_row;
+    // sections
+    uint32_t ncells = 0, nsh = 0, nrows_csr = 0;
+    DevBuf<uint64_t> d_cell_key; DevBuf<Aabb> d_cell_tight; DevBuf<uint32_t> d_cell_begin, d_cell_nlocal, d_cell_nstatic, d_cell_stamp, d_rows;
+    DevBuf<uint8_t> d_cell_flags;
+    DevBuf<int32_t> d_sh_cells, d_sh_owner; DevBuf<Aabb> d_sh_aabb; DevBuf<uint32_t> d_sh_begin, d_sh_nact, d_sh_nstat; DevBuf<uint8_t> d_sh_cached, d_sh_dirty;
+    std::vector<uint64_t> h_cell_key;
+    bool dirty_pending = false;
+    // groups
+    uint32_t ngclass = 0, nslots = 0;
+    DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
+    DevBuf<InstanceRange> d_ranges;
+    // frame
+    uint32_t frame = 0; bool have_cull = false;
+    FrameParams P{};
+    uint32_t entry_cap = 0, item_cap = 0, out_cap = 0, list_cap = 0;
+    DevBuf<uint4> d_entries; DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
+    uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0;
+    DevBuf<FrameHeader> d_hdr; DevBuf<TickHeader> d_th; DevBuf<uint32_t> d_movers, d_oob;
+    FrameHeader *h_hdr = nullptr; InstanceRange *h_ranges = nullptr; TickHeader *h_th = nullptr;   // pinned
+    std::vector<re_instance_range> groups_out;
+    bool cull_inflight = false, tick_inflight = false;
+    re_tick_result last_tick{};
+    float t_cull = 0, t_pack = 0, t_tick = 0;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf; return code;
+    }
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (ctx)->fail(RE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+extern "C" uint32_t re_abi_version(void) { return 1u; }
+
+extern "C" const char *re_last_error(const re_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int re_create(const re_config *cfg, re_ctx **out) {
+    if (!cfg || !out) { g_create_error = "re_create: null argument"; return RE_E_ARG; }
+    if (cfg->atomic_length == 0 || cfg->outline_length < cfg->atomic_length) { g_create_error = "re_create: outline_length must be >= atomic_length > 0"; return RE_E_ARG; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) { g_create_error = std::string("re_create: no HIP device available (") + hipGetErrorString(e) + "); this library has no CPU path"; return RE_E_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_error = "re_create: device ordinal out of range"; return RE_E_ARG; }
+    re_ctx *c = new re_ctx();
+    c->cfg = *cfg; c->device = cfg->device;
+    c->maxlevel = max_level(cfg->outline_length, cfg->atomic_length);
+    if (c->maxlevel > (uint32_t)MAX_LEVELS) { g_create_error = "re_create: outline/atomic gives more than 16 levels"; delete c; return RE_E_ARG; }
+    if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = std::string("re_create: ") + hipGetErrorString(e); delete c; return RE_E_HIP;
+    }
+    for (auto &ev : c->ev) (void)hipEventCreate(&ev);
+    *out = c;
+    return RE_OK;
+}
+
+static void free_world(re_ctx *c) {
+    uint64_t *a = &c->dev_bytes;
+    c->d_id.release(a); c->d_gclass.release(a); c->d_flags.release(a); c->d_row_cell.release(a); c->d_mat.release(a); c->d_pos.release(a); c->d_rot.release(a);
+    c->d_scale.release(a); c->d_aabb.release(a); c->d_orig.release(a); c->d_dyn_row.release(a); c->d_dyn_vel.release(a); c->d_dyn_acc.release(a);
+    c->d_dyn_rotvel.release(a); c->d_dyn_rotacc.release(a); c->d_row_key.release(a); c->d_row_nk.release(a); c->d_shrec.release(a); c->d_counter.release(a);
+    c->d_cell_key.release(a); c->d_cell_tight.release(a); c->d_cell_begin.release(a); c->d_cell_nlocal.release(a); c->d_cell_nstatic.release(a);
+    c->d_cell_stamp.release(a); c->d_rows.release(a); c->d_cell_flags.release(a); c->d_sh_cells.release(a); c->d_sh_owner.release(a); c->d_sh_aabb.release(a);
+    c->d_sh_begin.release(a); c->d_sh_nact.release(a); c->d_sh_nstat.release(a); c->d_sh_cached.release(a); c->d_sh_dirty.release(a);
+    c->d_gc_model.release(a); c->d_gc_rs.release(a); c->d_gc_sort.release(a); c->d_group_count.release(a); c->d_group_begin.release(a); c->d_group_fill.release(a);
+    c->d_ranges.release(a); c->d_entries.release(a); c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
+    c->d_hdr.release(a); c->d_th.release(a); c->d_movers.release(a); c->d_oob.release(a);
+    if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
+    if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
+    if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
+    c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false;
+}
+
+extern "C" void re_destroy(re_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_world(c);
+    for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static RowArrays row_arrays(re_ctx *c) {
+    RowArrays R; R.id = c->d_id.p; R.gclass = c->d_gclass.p; R.flags = c->d_flags.p; R.mat = c->d_mat.p; R.aabb = c->d_aabb.p; R.orig = c->d_orig.p;
+    R.pos = c->d_pos.p; R.rot = c->d_rot.p; R.scale = c->d_scale.p; return R;
+}
+
+// ------------------------------------------------------------------------------------------------
+// World-section structure from the per-row section keys (the spatial hash as key-sorted arrays).
+// Bulk semantics of one registration batch followed by BoundingBoxTree::end_of_changes.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct SortRec { uint64_t key; uint64_t sub; uint32_t row; };   // sub = static << 32 | entity id
+struct SharedId { uint32_t nk; uint64_t keys[8]; bool operator<(const SharedId &o) const { if (nk != o.nk) return nk < o.nk; return memcmp(keys, o.keys, sizeof keys) < 0; } };
+}
+
+static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const std::vector<uint8_t> &row_nk, std::vector<SharedRec> &shrec,
+                          const std::vector<uint32_t> &flags) {
+    const uint32_t n = c->n;
+    uint64_t *acct = &c->dev_bytes;
+    // --- unique rows sorted by (section key, static, entity id): CSR order == the oracle's iteration order
+    std::vector<SortRec> recs; recs.reserve(n);
+    for (uint32_t r = 0; r < n; r++) if (row_nk[r] == 1) recs.push_back({ row_key[r], ((uint64_t)((flags[r] & F_STATIC) ? 1 : 0) << 32) | c->h_id[r], r });
+    auto cmp = [](const SortRec &a, const SortRec &b) { return a.key != b.key ? a.key < b.key : a.sub < b.sub; };
+    if (!std::is_sorted(recs.begin(), recs.end(), cmp)) std::sort(recs.begin(), recs.end(), cmp);
+    // --- shared sections, indexed by first appearance in row order (== creation order of a fresh tree)
+    std::sort(shrec.begin(), shrec.end(), [](const SharedRec &a, const SharedRec &b) { return a.row < b.row; });
+    std::map<SharedId, uint32_t> shmap; std::vector<SharedId> shids; std::vector<std::vector<uint32_t>> sh_act, sh_sta;
+    for (const SharedRec &sr : shrec) {
+        SharedId id; id.nk = sr.nk; memcpy(id.keys, sr.keys, sizeof id.keys);
+        auto it = shmap.find(id); uint32_t s;
+        if (it == shmap.end()) { s = (uint32_t)shids.size(); shmap.emplace(id, s); shids.push_back(id); sh_act.emplace_back(); sh_sta.emplace_back(); } else s = it->second;
+        ((flags[sr.row] & F_STATIC) ? sh_sta[s] : sh_act[s]).push_back(sr.row);
+    }
+    const uint32_t nsh = (uint32_t)shids.size();
+    auto by_id = [&](uint32_t a, uint32_t b) { return c->h_id[a] < c->h_id[b]; };
+    for (uint32_t s = 0; s < nsh; s++) { std::sort(sh_act[s].begin(), sh_act[s].end(), by_id); std::sort(sh_sta[s].begin(), sh_sta[s].end(), by_id); }
+    // --- section keys = keys of unique rows U keys linked by shared sections
+    std::vector<uint64_t> keys; keys.reserve(recs.size());
+    for (size_t i = 0; i < recs.size(); i++) if (i == 0 || recs[i].key != recs[i - 1].key) keys.push_back(recs[i].key);
+    if (nsh) {
+        std::vector<uint64_t> lk;
+        for (const SharedId &id : shids) for (uint32_t k = 0; k < id.nk; k++) lk.push_back(id.keys[k]);
+        std::sort(lk.begin(), lk.end()); lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
+        std::vector<uint64_t> merged; merged.reserve(keys.size() + lk.size());
+        std::set_union(keys.begin(), keys.end(), lk.begin(), lk.end(), std::back_inserter(merged));
+        keys.swap(merged);
+    }
+    const uint32_t ncells = (uint32_t)keys.size();
+    std::vector<uint32_t> begin(ncells + 1, 0), nlocal(ncells, 0), nstatic(ncells, 0), rows; rows.reserve(n);
+    std::vector<uint32_t> row_cell(n, ROW_CELL_NONE);
+    {
+        size_t i = 0;
+        for (uint32_t ci = 0; ci < ncells; ci++) {
+            begin[ci] = (uint32_t)rows.size();
+            while (i < recs.size() && recs[i].key == keys[ci]) {
+                if (recs[i].sub >> 32) nstatic[ci]++; else nlocal[ci]++;
+                rows.push_back(recs[i].row); row_cell[recs[i].row] = ci; i++;
+            }
+        }
+        begin[ncells] = (uint32_t)rows.size();
+    }
+    std::vector<int32_t> sh_cells((size_t)nsh * 8 + 8, -1); std::vector<uint32_t> sh_begin(nsh + 1, 0), sh_nact(nsh + 1, 0), sh_nstat(nsh + 1, 0);
+    std::vector<std::vector<uint32_t>> cell_links;                         // only for sections that link shared sections
+    std::unordered_map<uint32_t, uint32_t> cell_link_idx;
+    for (uint32_t s = 0; s < nsh; s++) {
+        for (uint32_t k = 0; k < shids[s].nk; k++) {
+            uint32_t ci = (uint32_t)(std::lower_bound(keys.begin(), keys.end(), shids[s].keys[k]) - keys.begin());
+            sh_cells[(size_t)s * 8 + k] = (int32_t)ci;
+            auto it = cell_link_idx.find(ci);
+            if (it == cell_link_idx.end()) { cell_link_idx.emplace(ci, (uint32_t)cell_links.size()); cell_links.emplace_back(); it = cell_link_idx.find(ci); }
+            cell_links[it->second].push_back(s);
+        }
+        sh_begin[s] = (uint32_t)rows.size(); sh_nact[s] = (uint32_t)sh_act[s].size(); sh_nstat[s] = (uint32_t)sh_sta[s].size();
+        for (uint32_t r : sh_act[s]) { rows.push_back(r); row_cell[r] = ROW_CELL_SHARED | s; }
+        for (uint32_t r : sh_sta[s]) { rows.push_back(r); row_cell[r] = ROW_CELL_SHARED | s; }
+    }
+    // --- update_static_world_sections (bounding_box_tree_v2.rs:1133-1213), every section and shared section changed
+    std::vector<uint8_t> cflags(ncells + 1, 0);
+    for (uint32_t ci = 0; ci < ncells; ci++) {
+        bool st = false;
+        if (nlocal[ci] == 0) {
+            auto it = cell_link_idx.find(ci);
+            if (it == cell_link_idx.end()) st = true;
+            else for (uint32_t s : cell_links[it->second]) if (sh_nact[s] == 0) st = true;
+        }
+        cflags[ci] = (st ? CF_STATIC_SECTION : 0) | CF_STATIC_DIRTY;
+    }
+    for (uint32_t s = 0; s < nsh; s++)
+        for (uint32_t k = 0; k < shids[s].nk; k++) {
+            uint32_t ci = (uint32_t)sh_cells[(size_t)s * 8 + k];
+            if (sh_nact[s] == 0) { if (nlocal[ci] == 0) cflags[ci] |= CF_STATIC_SECTION; }
+            else cflags[ci] &= ~CF_STATIC_SECTION;
+        }
+    // --- upload
+    c->ncells = ncells; c->nsh = nsh; c->nrows_csr = (uint32_t)rows.size();
+    c->h_cell_key = keys;
+    std::vector<uint64_t> keys_padded(keys); keys_padded.resize((size_t)((ncells + 1) & ~1u) + 2, 0xFFFFFFFFFFFFFFFFull);
+    HIPCHK(c, c->d_cell_key.alloc(keys_padded.size(), acct));
+    HIPCHK(c, c->d_cell_tight.alloc(ncells, acct)); HIPCHK(c, c->d_cell_begin.alloc(ncells + 1, acct)); HIPCHK(c, c->d_cell_nlocal.alloc(ncells, acct));
+    HIPCHK(c, c->d_cell_nstatic.alloc(ncells, acct)); HIPCHK(c, c->d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, c->d_cell_flags.alloc(ncells, acct));
+    HIPCHK(c, c->d_rows.alloc(rows.size(), acct)); HIPCHK(c, c->d_row_cell.alloc(n, acct));
+    HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
+    HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));
+    HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_cell_key.p, keys_padded.data(), keys_padded.size() * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_cell_begin.p, begin.data(), (size_t)(ncells + 1) * 4, hipMemcpyHostToDevice, st));
+    if (ncells) {
+        HIPCHK(c, hipMemcpyAsync(c->d_cell_nlocal.p, nlocal.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_cell_nstatic.p, nstatic.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_cell_flags.p, cflags.data(), (size_t)ncells, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(c->d_cell_stamp.p, 0, (size_t)ncells * 4, st));
+    }
+    if (!rows.empty()) HIPCHK(c, hipMemcpyAsync(c->d_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->d_row_cell.p, row_cell.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (nsh) {
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_cells.p, sh_cells.data(), (size_t)nsh * 8 * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_begin.p, sh_begin.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_nact.p, sh_nact.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_nstat.p, sh_nstat.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(c->d_sh_owner.p, 0xFF, (size_t)nsh * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->d_sh_cached.p, 0, nsh, st));
+        HIPCHK(c, hipMemsetAsync(c->d_sh_dirty.p, 1, nsh, st));
+    }
+    // --- end_of_changes: tight AABBs.  total_world_aabb_combining of a fresh batch == number of unique adds (:710-744)
+    int too_many = recs.size() > 500;
+    if (ncells) hipLaunchKernelGGL(k_fold_tight, dim3((ncells + 255) / 256), dim3(256), 0, st, ncells, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p,
+                                   c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, too_many);
+    if (nsh) hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
+    HIPCHK(c, hipGetLastError());
+    // --- frame buffers sized for this world
+    c->entry_cap = ncells + 2 * nsh + 64;
+    HIPCHK(c, c->d_entries.alloc(c->entry_cap, acct));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->dirty_pending = true; c->have_cull = false;
+    return RE_OK;
+}
+
+extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_rejected) {
+    if (!c) return RE_E_ARG;
+    if (!E || (E->n && (!E->entity_id || !E->model_index || !E->flags || !E->original_aabb || !E->position))) return c->fail(RE_E_ARG, "re_upload_entities: missing required array");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_world(c);
+    const uint32_t n = E->n;
+    c->n = n;
+    uint64_t *acct = &c->dev_bytes;
+    // host staging: defaults for absent components, normalised axes (Rotation::new etc., exports/movement_components.rs:108-164)
+    std::vector<float> rot((size_t)n * 4), scl((size_t)n * 3);
+    std::vector<uint32_t> flags(n), gclass(n);
+    std::vector<uint32_t> dyn_row; std::vector<float> dvel, dacc, drv, dra;
+    std::unordered_map<GroupKey, uint32_t, GroupKeyHash> gmap; std::vector<GroupKey> gkeys;
+    c->h_id.assign(E->entity_id, E->entity_id + n);
+    c->id_to_row.clear(); c->id_to_row.reserve(n);
+    for (uint32_t r = 0; r < n; r++) {
+        uint32_t fl = E->flags[r] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
+        flags[r] = fl;
+        if ((fl & F_HAS_ROT) && !E->rotation) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROT but rotation == NULL", r);
+        if ((fl & F_HAS_SCALE) && !E->scale) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_SCALE but scale == NULL", r);
+        if ((fl & F_HAS_VEL) && !E->velocity) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_VEL but velocity == NULL", r);
+        if ((fl & F_HAS_ACC) && !E->acceleration) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ACC but acceleration == NULL", r);
+        if ((fl & F_HAS_ROTVEL) && !E->rotation_velocity) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROTVEL but rotation_velocity == NULL", r);
+        if ((fl & F_HAS_ROTACC) && !E->rotation_acceleration) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROTACC but rotation_acceleration == NULL", r);
+        if (fl & F_HAS_ROT) {
+            const float *a = E->rotation + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]);
+            rot[r * 4 + 0] = a[0] / nn; rot[r * 4 + 1] = a[1] / nn; rot[r * 4 + 2] = a[2] / nn; rot[r * 4 + 3] = a[3];
+        } else { rot[r * 4 + 0] = 1.f; rot[r * 4 + 1] = 0.f; rot[r * 4 + 2] = 0.f; rot[r * 4 + 3] = 0.f; }           // Rotation::default
+        if (fl & F_HAS_SCALE) { scl[r * 3 + 0] = E->scale[r * 3 + 0]; scl[r * 3 + 1] = E->scale[r * 3 + 1]; scl[r * 3 + 2] = E->scale[r * 3 + 2]; }
+        else { scl[r * 3 + 0] = scl[r * 3 + 1] = scl[r * 3 + 2] = 1.f; }                                          // Scale::default
+        GroupKey gk{ E->model_index[r], E->render_system ? E->render_system[r] : 0u, E->sortable ? E->sortable[r] : 0u };
+        auto it = gmap.find(gk);
+        if (it == gmap.end()) { it = gmap.emplace(gk, (uint32_t)gkeys.size()).first; gkeys.push_back(gk); }
+        gclass[r] = it->second;
+        if (fl & (F_HAS_VEL | F_HAS_ROTVEL)) {
+            dyn_row.push_back(r);
+            for (int k = 0; k < 3; k++) { dvel.push_back((fl & F_HAS_VEL) ? E->velocity[r * 3 + k] : 0.f); dacc.push_back((fl & F_HAS_ACC) ? E->acceleration[r * 3 + k] : 0.f); }
+            float rv[4] = { 1.f, 0.f, 0.f, 0.f }, ra[4] = { 1.f, 0.f, 0.f, 0.f };
+            if (fl & F_HAS_ROTVEL) { const float *a = E->rotation_velocity + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]); rv[0] = a[0] / nn; rv[1] = a[1] / nn; rv[2] = a[2] / nn; rv[3] = a[3]; }
+            if (fl & F_HAS_ROTACC) { const float *a = E->rotation_acceleration + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]); ra[0] = a[0] / nn; ra[1] = a[1] / nn; ra[2] = a[2] / nn; ra[3] = a[3]; }
+            for (int k = 0; k < 4; k++) { drv.push_back(rv[k]); dra.push_back(ra[k]); }
+        }
+        c->id_to_row[E->entity_id[r]] = r;
+    }
+    if (c->id_to_row.size() != n) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity ids");
+    c->h_flags = flags; c->h_dyn_row = dyn_row; c->has_rotvel = false;
+    for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
+    c->ndyn = (uint32_t)dyn_row.size();
+    c->ngclass = (uint32_t)gkeys.size(); c->nslots = c->ngclass * 8u;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->d_id.alloc(n, acct)); HIPCHK(c, c->d_gclass.alloc(n, acct)); HIPCHK(c, c->d_flags.alloc(n, acct)); HIPCHK(c, c->d_mat.alloc((size_t)n * 16, acct));
+    HIPCHK(c, c->d_pos.alloc((size_t)n * 3, acct)); HIPCHK(c, c->d_rot.alloc((size_t)n * 4, acct)); HIPCHK(c, c->d_scale.alloc((size_t)n * 3, acct));
+    HIPCHK(c, c->d_aabb.alloc(n, acct)); HIPCHK(c, c->d_orig.alloc(n, acct));
+    HIPCHK(c, c->d_row_key.alloc(n, acct)); HIPCHK(c, c->d_row_nk.alloc(n, acct)); HIPCHK(c, c->d_shrec.alloc(n, acct)); HIPCHK(c, c->d_counter.alloc(4, acct));
+    HIPCHK(c, c->d_dyn_row.alloc(c->ndyn, acct)); HIPCHK(c, c->d_dyn_vel.alloc((size_t)c->ndyn * 3, acct)); HIPCHK(c, c->d_dyn_acc.alloc((size_t)c->ndyn * 3, acct));
+    HIPCHK(c, c->d_dyn_rotvel.alloc((size_t)c->ndyn * 4, acct)); HIPCHK(c, c->d_dyn_rotacc.alloc((size_t)c->ndyn * 4, acct));
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_id.p, E->entity_id, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_gclass.p, gclass.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_flags.p, flags.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_pos.p, E->position, (size_t)n * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_rot.p, rot.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_scale.p, scl.data(), (size_t)n * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_orig.p, E->original_aabb, (size_t)n * 24, hipMemcpyHostToDevice, st));
+    }
+    if (c->ndyn) {
+        HIPCHK(c, hipMemcpyAsync(c->d_dyn_row.p, dyn_row.data(), (size_t)c->ndyn * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_dyn_vel.p, dvel.data(), (size_t)c->ndyn * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_dyn_acc.p, dacc.data(), (size_t)c->ndyn * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_dyn_rotvel.p, drv.data(), (size_t)c->ndyn * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_dyn_rotacc.p, dra.data(), (size_t)c->ndyn * 16, hipMemcpyHostToDevice, st));
+    }
+    // groups
+    {
+        std::vector<uint32_t> gm(c->ngclass + 1), gr(c->ngclass + 1), gs(c->ngclass + 1);
+        for (uint32_t g = 0; g < c->ngclass; g++) { gm[g] = gkeys[g].model; gr[g] = gkeys[g].rs; gs[g] = gkeys[g].sort; }
+        HIPCHK(c, c->d_gc_model.alloc(c->ngclass, acct)); HIPCHK(c, c->d_gc_rs.alloc(c->ngclass, acct)); HIPCHK(c, c->d_gc_sort.alloc(c->ngclass, acct));
+        HIPCHK(c, c->d_group_count.alloc(c->nslots, acct)); HIPCHK(c, c->d_group_begin.alloc(c->nslots, acct)); HIPCHK(c, c->d_group_fill.alloc(c->nslots, acct));
+        HIPCHK(c, c->d_ranges.alloc(c->nslots, acct));
+        if (c->ngclass) {
+            HIPCHK(c, hipMemcpyAsync(c->d_gc_model.p, gm.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->d_gc_rs.p, gr.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(c->d_gc_sort.p, gs.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(c, hipMemsetAsync(c->d_group_count.p, 0, (size_t)std::max(c->nslots, 1u) * 4, st));
+        HIPCHK(c, hipMemsetAsync(c->d_group_fill.p, 0, (size_t)std::max(c->nslots, 1u) * 4, st));
+    }
+    // TRS -> matrix, AABB, section keys on the GPU
+    HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 16, st));
+    if (n) hipLaunchKernelGGL(k_transform_assign, dim3((n + 255) / 256), dim3(256), 0, st, row_arrays(c), n, c->cfg.outline_length, c->cfg.atomic_length,
+                              c->d_row_key.p, c->d_row_nk.p, c->d_shrec.p, c->d_counter.p, n);
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint64_t> row_key(n); std::vector<uint8_t> row_nk(n); uint32_t nshrec = 0;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(row_key.data(), c->d_row_key.p, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(row_nk.data(), c->d_row_nk.p, (size_t)n, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipMemcpyAsync(&nshrec, c->d_counter.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::vector<SharedRec> shrec(nshrec);
+    if (nshrec) HIPCHK(c, hipMemcpy(shrec.data(), c->d_shrec.p, (size_t)nshrec * sizeof(SharedRec), hipMemcpyDeviceToHost));
+    uint32_t rejected = 0;
+    for (uint32_t r = 0; r < n; r++) if (row_nk[r] == 0) rejected++;
+    if (n_rejected) *n_rejected = rejected;
+    c->d_shrec.release(acct);
+    int rc = build_sections(c, row_key, row_nk, shrec, flags);
+    if (rc != RE_OK) return rc;
+    // frame buffers
+    c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
+    c->item_cap = std::max(2u * n, 64u);
+    c->list_cap = std::max(c->ndyn, 1u);
+    HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
+    HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
+    HIPCHK(c, c->d_hdr.alloc(1, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_hdr), sizeof(FrameHeader), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_th), sizeof(TickHeader), hipHostMallocDefault));
+    memset(c->h_hdr, 0, sizeof(FrameHeader)); memset(c->h_th, 0, sizeof(TickHeader));
+    c->frame = 0;
+    return RE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame parameters: RenderFrustumCuller::new(P*V), LogicFrustumCuller::new(wsl, pos) and the two
+// candidate boxes of flows/pipeline.rs:219-226 / flows/visible_world_flow.rs:47-57,117-145
+// ------------------------------------------------------------------------------------------------
+static void fill_level_boxes(LevelBox *out, uint32_t maxlevel, float wsl, float xmin, float xmax, float ymin, float ymax, float zmin, float zmax) {
+    for (uint32_t level = 0; level < (uint32_t)MAX_LEVELS; level++) {
+        LevelBox b{};
+        if (level < maxlevel) {
+            float ll = wsl * ldexpf(1.0f, (int)level);                              // world_section_length * 2.0_f32.powf(level)
+            b.nx = f2u32(ceilf((xmax - xmin) / ll)); b.ny = f2u32(ceilf((ymax - ymin) / ll)); b.nz = f2u32(ceilf((zmax - zmin) / ll));
+            b.bx = f2u32(xmin / ll); b.by = f2u32(ymin / ll); b.bz = f2u32(zmin / ll);
+            b.level_length = ll;
+        }
+        out[level] = b;
+    }
+}
+
+static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
+    FrameParams &P = c->P;
+    make_planes(cam->projection_view, P.planes);
+    for (int k = 0; k < 3; k++) P.cam[k] = cam->position[k];
+    P.far_draw = cam->far_draw;
+    float wsl = (float)c->cfg.atomic_length;
+    P.lookahead = wsl;
+    P.n_lod = cam->n_lod > 8 ? 8 : cam->n_lod;
+    for (int k = 0; k < 8; k++) { P.lod_min[k] = cam->lod_min[k]; P.lod_max[k] = cam->lod_max[k]; }
+    P.max_level = c->maxlevel; P.frame = c->frame; P.emit_duplicates = (flags & RE_CULL_EMIT_DUPLICATES) ? 1u : 0u;
+    float draw = wsl * 2.0f;                                                    // find_visible_world_ids_entire_world(.., wsl * 2.0, ..)
+    fill_level_boxes(P.box[0], c->maxlevel, wsl, rmax(cam->position[0] - draw, 0.0f), cam->position[0] + draw, rmax(cam->position[1] - draw, 0.0f), cam->position[1] + draw,
+                     rmax(cam->position[2] - draw, 0.0f), cam->position[2] + draw);
+    float half = cam->far_draw / 2.0f;                                          // find_visible_world_ids_frustum_aabb
+    float cx = cam->direction[0] * half + cam->position[0], cy = cam->direction[1] * half + cam->position[1], cz = cam->direction[2] * half + cam->position[2];
+    fill_level_boxes(P.box[1], c->maxlevel, wsl, rmax(cx - half, 0.0f), cx + half, rmax(cy - half, 0.0f), cy + half, rmax(cz - half, 0.0f), cz + half);
+}
+
+static void fill_visible(re_ctx *c, re_visible *out) {
+    const FrameHeader &h = *c->h_hdr;
+    uint32_t cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
+    c->groups_out.resize(h.n_groups);
+    for (uint32_t g = 0; g < h.n_groups && g < c->nslots; g++) {
+        const InstanceRange &r = c->h_ranges[g];
+        c->groups_out[g] = re_instance_range{ r.model_index, r.render_system, r.sortable, r.begin, r.count };
+    }
+    if (!out) return;
+    out->n_visible_sections = h.n_vis_map; out->n_visible_vec = h.n_vis_vec;
+    out->n_instances = h.total; out->n_written = std::min(h.total, cap);
+    out->n_groups = h.n_groups; out->groups = c->groups_out.data();
+    out->d_entity_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p;
+    out->d_matrices = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
+}
+
+static int finish_cull(re_ctx *c, re_visible *out) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cull_inflight = false;
+    (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
+    c->t_cull *= 1000.f; c->t_pack *= 1000.f;
+    if ((uint32_t)c->h_hdr->cursor > c->entry_cap) return c->fail(RE_E_CAPACITY, "visible-section entry capacity exceeded");
+    if ((uint32_t)(c->h_hdr->cursor >> 32) > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", (uint32_t)(c->h_hdr->cursor >> 32), c->item_cap);
+    fill_visible(c, out);
+    return RE_OK;
+}
+
+extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_visible *out) {
+    if (!c) return RE_E_ARG;
+    if (!cam) return c->fail(RE_E_ARG, "re_cull_pack: camera is NULL");
+    if (!c->h_hdr) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    c->frame += 1;
+    make_frame_params(c, cam, flags);
+    const FrameParams &P = c->P;
+    HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, sizeof(FrameHeader), st));
+    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    if (c->dirty_pending) {
+        if (c->ncells) hipLaunchKernelGGL(k_static_cache_cells, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_tight.p, c->d_cell_flags.p, P);
+        if (c->nsh) hipLaunchKernelGGL(k_static_cache_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_dirty.p, c->d_sh_owner.p, c->d_sh_cached.p, P);
+        c->dirty_pending = false;
+    }
+    if (c->ncells) hipLaunchKernelGGL(k_cull_sections, dim3((c->ncells + CULL_CHUNK - 1) / CULL_CHUNK), dim3(CULL_THREADS), 0, st, c->d_cell_key.p, c->ncells, c->d_cell_tight.p,
+                                      c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
+    if (c->nsh) hipLaunchKernelGGL(k_cull_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p,
+                                   c->d_sh_owner.p, c->d_sh_cached.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
+    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
+    uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
+    uint32_t grid = std::min(1024u, (c->item_cap + 255u) / 256u);
+    size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
+    hipLaunchKernelGGL(k_emit_count, dim3(grid), dim3(256), lds, st, c->d_entries.p, c->entry_cap, c->d_hdr.p, c->d_rows.p, c->d_gclass.p, c->d_item_row.p, c->d_item_slot.p,
+                       c->item_cap, c->d_group_count.p, c->nslots);
+    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
+                       c->d_ranges.p, c->nslots, c->d_hdr.p);
+    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, c->d_hdr.p, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
+                       c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[2], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr.p, sizeof(FrameHeader), hipMemcpyDeviceToHost, st));
+    if (c->nslots) HIPCHK(c, hipMemcpyAsync(c->h_ranges, c->d_ranges.p, sizeof(InstanceRange) * c->nslots, hipMemcpyDeviceToHost, st));
+    c->have_cull = true; c->cull_inflight = true;
+    if (flags & RE_CULL_ASYNC) return RE_OK;
+    return finish_cull(c, out);
+}
+
+static int finish_tick(re_ctx *c, re_tick_result *out) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tick_inflight = false;
+    (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f;
+    c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob;
+    if (out) *out = c->last_tick;
+    return RE_OK;
+}
+
+extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out) {
+    if (!c) return RE_E_ARG;
+    if (!c->h_hdr) return c->fail(RE_E_STATE, "re_tick: no world uploaded");
+    if (!(flags & RE_TICK_ALL_DYNAMIC) && !c->have_cull) return c->fail(RE_E_STATE, "re_tick: reference semantics tick entities of the last visibility query; call re_cull_pack first or pass RE_TICK_ALL_DYNAMIC");
+    if (dt == 0.0f) {
+        // VelocityRotation * 0.0 asserts in the reference (exports/movement_components.rs:287)
+        if (c->has_rotvel) return c->fail(RE_E_ARG, "re_tick: delta_time == 0 with rotating entities (the reference asserts)");
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));
+    HIPCHK(c, hipEventRecord(c->ev[3], st));
+    if (c->ndyn) hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
+                                    row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->P, dt,
+                                    (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[4], st));
+    HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, sizeof(TickHeader), hipMemcpyDeviceToHost, st));
+    c->tick_inflight = true;
+    if (flags & RE_TICK_ASYNC) return RE_OK;
+    return finish_tick(c, out);
+}
+
+extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_tick) {
+    if (!c) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = RE_OK;
+    if (c->cull_inflight) rc = finish_cull(c, out_visible); else { HIPCHK(c, hipStreamSynchronize(c->stream)); if (out_visible && c->h_hdr) fill_visible(c, out_visible); }
+    if (rc != RE_OK) return rc;
+    if (c->tick_inflight) rc = finish_tick(c, out_tick); else if (out_tick) *out_tick = c->last_tick;
+    return rc;
+}
+
+extern "C" int re_copy_visible(re_ctx *c, uint32_t *ids_host, float *mats_host, uint32_t capacity, uint32_t *n_written) {
+    if (!c || !c->h_hdr) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->cull_inflight) { int rc = finish_cull(c, nullptr); if (rc) return rc; }
+    uint32_t cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
+    uint32_t nw = std::min(std::min(c->h_hdr->total, cap), capacity);      // truncate and report (mapped_buffer.rs:171-186)
+    const uint32_t *src_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; const float *src_m = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
+    if (nw && ids_host) HIPCHK(c, hipMemcpyAsync(ids_host, src_ids, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
+    if (nw && mats_host) HIPCHK(c, hipMemcpyAsync(mats_host, src_m, (size_t)nw * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (n_written) *n_written = nw;
+    return RE_OK;
+}
+
+extern "C" int re_set_output_buffers(re_ctx *c, uint32_t *d_ids, float *d_mats, uint32_t capacity) {
+    if (!c) return RE_E_ARG;
+    if ((d_ids == nullptr) != (d_mats == nullptr)) return c->fail(RE_E_ARG, "re_set_output_buffers: both pointers or neither");
+    c->ext_out_ids = d_ids; c->ext_out_mats = d_mats; c->ext_out_cap = d_ids ? capacity : 0;
+    return RE_OK;
+}
+
+extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, void *dst) {
+    if (!c || !dst) return RE_E_ARG;
+    auto it = c->id_to_row.find(entity_id);
+    if (it == c->id_to_row.end()) return c->fail(RE_E_ARG, "re_read_component: unknown entity %u", entity_id);
+    uint32_t r = it->second;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    auto dynidx = [&](uint32_t &j) -> bool {                      // dynamic rows are kept in ascending row order
+        auto p = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), r);
+        if (p == c->h_dyn_row.end() || *p != r) return false;
+        j = (uint32_t)(p - c->h_dyn_row.begin()); return true;
+    };
+    uint32_t j = 0;
+    switch (component) {
+        case RE_C_POSITION: HIPCHK(c, hipMemcpy(dst, c->d_pos.p + (size_t)r * 3, 12, hipMemcpyDeviceToHost)); break;
+        case RE_C_ROTATION: HIPCHK(c, hipMemcpy(dst, c->d_rot.p + (size_t)r * 4, 16, hipMemcpyDeviceToHost)); break;
+        case RE_C_SCALE: HIPCHK(c, hipMemcpy(dst, c->d_scale.p + (size_t)r * 3, 12, hipMemcpyDeviceToHost)); break;
+        case RE_C_TRANSFORMATION: HIPCHK(c, hipMemcpy(dst, c->d_mat.p + (size_t)r * 16, 64, hipMemcpyDeviceToHost)); break;
+        case RE_C_STATIC_AABB: HIPCHK(c, hipMemcpy(dst, c->d_aabb.p + r, 24, hipMemcpyDeviceToHost)); break;
+        case RE_C_ORIGINAL_AABB: HIPCHK(c, hipMemcpy(dst, c->d_orig.p + r, 24, hipMemcpyDeviceToHost)); break;
+        case RE_C_FLAGS: HIPCHK(c, hipMemcpy(dst, c->d_flags.p + r, 4, hipMemcpyDeviceToHost)); break;
+        case RE_C_VELOCITY: if (!dynidx(j)) return c->fail(RE_E_ARG, "entity %u has no Velocity", entity_id); HIPCHK(c, hipMemcpy(dst, c->d_dyn_vel.p + (size_t)j * 3, 12, hipMemcpyDeviceToHost)); break;
+        case RE_C_ACCELERATION: if (!dynidx(j)) return c->fail(RE_E_ARG, "entity %u has no Acceleration", entity_id); HIPCHK(c, hipMemcpy(dst, c->d_dyn_acc.p + (size_t)j * 3, 12, hipMemcpyDeviceToHost)); break;
+        case RE_C_ROTATION_VEL: if (!dynidx(j)) return c->fail(RE_E_ARG, "entity %u has no VelocityRotation", entity_id); HIPCHK(c, hipMemcpy(dst, c->d_dyn_rotvel.p + (size_t)j * 4, 16, hipMemcpyDeviceToHost)); break;
+        case RE_C_ROTATION_ACC: if (!dynidx(j)) return c->fail(RE_E_ARG, "entity %u has no AccelerationRotation", entity_id); HIPCHK(c, hipMemcpy(dst, c->d_dyn_rotacc.p + (size_t)j * 4, 16, hipMemcpyDeviceToHost)); break;
+        default: return c->fail(RE_E_ARG, "re_read_component: unknown component %d", component);
+    }
+    return RE_OK;
+}
+
+extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity, uint32_t *n) {
+    if (!c || !c->h_th) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc) return rc; }
+    uint32_t cnt = std::min(c->h_th->n_oob, c->list_cap);
+    std::vector<uint32_t> rows(cnt);
+    if (cnt) HIPCHK(c, hipMemcpy(rows.data(), c->d_oob.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < cnt && i < capacity; i++) if (ids) ids[i] = c->h_id[rows[i]];
+    if (n) *n = cnt;
+    return RE_OK;
+}
+
+extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
+    if (!c || !out) return RE_E_ARG;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->ncells; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes;
+    return RE_OK;
+}
+
+extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, float *tight, uint32_t *n_local, uint32_t *n_static, uint8_t *is_static_section, uint32_t *n) {
+    if (!c) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t m = std::min(capacity, c->ncells);
+    if (n) *n = c->ncells;
+    if (!m) return RE_OK;
+    if (keys) memcpy(keys, c->h_cell_key.data(), (size_t)m * 8);
+    if (tight) HIPCHK(c, hipMemcpy(tight, c->d_cell_tight.p, (size_t)m * 24, hipMemcpyDeviceToHost));
+    if (n_local) HIPCHK(c, hipMemcpy(n_local, c->d_cell_nlocal.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    if (n_static) HIPCHK(c, hipMemcpy(n_static, c->d_cell_nstatic.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    if (is_static_section) {
+        std::vector<uint8_t> f(m); HIPCHK(c, hipMemcpy(f.data(), c->d_cell_flags.p, m, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < m; i++) is_static_section[i] = f[i] & CF_STATIC_SECTION;
+    }
+    return RE_OK;
+}
+
+extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n) {
+    if (!c || !c->have_cull) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->cull_inflight) { int rc = finish_cull(c, nullptr); if (rc) return rc; }
+    uint32_t cap = std::max(c->ncells, 1u);
+    uint32_t *d_idx = nullptr, *d_cnt = nullptr; uint8_t *d_mult = nullptr;
+    HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_idx), (size_t)cap * 4)); HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_mult), cap)); HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d_cnt), 4));
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, 4, c->stream));
+    if (c->ncells) hipLaunchKernelGGL(k_collect_visible, dim3((c->ncells + 255) / 256), dim3(256), 0, c->stream, c->ncells, c->d_cell_stamp.p, c->frame, d_idx, d_mult, cap, d_cnt);
+    uint32_t cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> idx(cnt); std::vector<uint8_t> mult(cnt);
+    if (cnt) { HIPCHK(c, hipMemcpy(idx.data(), d_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(mult.data(), d_mult, cnt, hipMemcpyDeviceToHost)); }
+    (void)hipFree(d_idx); (void)hipFree(d_mult); (void)hipFree(d_cnt);
+    std::vector<uint32_t> order(cnt); for (uint32_t i = 0; i < cnt; i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return idx[a] < idx[b]; });
+    for (uint32_t i = 0; i < cnt && i < capacity; i++) { if (keys) keys[i] = c->h_cell_key[idx[order[i]]]; if (multiplicity) multiplicity[i] = mult[order[i]]; }
+    if (n) *n = cnt;
+    return RE_OK;
+}
+
+extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *tick_us) {
+    if (!c) return RE_E_ARG;
+    if (cull_us) *cull_us = c->t_cull; if (pack_us) *pack_us = c->t_pack; if (tick_us) *tick_us = c->t_tick;
+    return RE_OK;
+}
+
+extern "C" void *re_get_stream(re_ctx *c) { return c ? (void *)c->stream : nullptr; }

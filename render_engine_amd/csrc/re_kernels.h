@@ -1,0 +1,74 @@
+// re_kernels.h -- device-side data layout shared by the kernels (re_kernels.hip) and the C-ABI
+// host code (re_api.hip).  All arrays are struct-of-arrays in HBM; see DESIGN.md "HBM layout".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "re_math.h"
+
+namespace re {
+
+// entity flag bits (== RE_F_* of include/re_hip.h) + internal
+constexpr uint32_t F_STATIC = 0x001, F_HAS_VEL = 0x002, F_HAS_ACC = 0x004, F_HAS_ROT = 0x008, F_HAS_ROTVEL = 0x010,
+                   F_HAS_ROTACC = 0x020, F_HAS_SCALE = 0x040, F_ALWAYS_EXEC = 0x080, F_OOB_LOGIC = 0x100,
+                   F_HAS_MOVED = 0x200, F_HAS_ROTATED = 0x400, F_DEAD = 0x80000000u;
+// world-section flag bits
+constexpr uint8_t CF_STATIC_SECTION = 1;   // member of static_world_sections (bounding_box_tree_v2.rs:1133-1213)
+constexpr uint8_t CF_STATIC_CACHED = 2;    // its static entities are in the render cache (render_flow.rs:549-594)
+constexpr uint8_t CF_STATIC_DIRTY = 4;     // member of changed_static_unique_sections
+
+constexpr uint32_t ROW_CELL_NONE = 0xFFFFFFFFu, ROW_CELL_SHARED = 0x80000000u;
+constexpr int MAX_LEVELS = 16;
+constexpr int CULL_THREADS = 256;
+constexpr int CULL_CHUNK = 4096;           // sections per workgroup of k_cull_sections (LDS queue of 16 KiB)
+constexpr uint32_t LDS_HIST_SLOTS = 4096;  // group slots (gclass*8+lod) that fit the LDS histograms
+
+struct RowArrays {                          // one row per entity, in upload order
+    uint32_t *id, *gclass, *flags;
+    float *mat;                             // 16 floats, column-major, 64 B per row
+    Aabb *aabb, *orig;                      // StaticAABB, OriginalAABB
+    float *pos, *rot, *scale;               // 3, 4 (axis+angle), 3 floats
+};
+struct SharedRec { uint32_t row, nk; uint64_t keys[8]; };
+
+struct LevelBox { uint32_t bx, by, bz, nx, ny, nz; float level_length; uint32_t pad; };
+
+struct FrameParams {
+    float planes[24];
+    float cam[3]; float far_draw;
+    float lookahead;
+    uint32_t n_lod; float lod_min[8], lod_max[8];
+    uint32_t max_level, frame, emit_duplicates, pad;
+    LevelBox box[2][MAX_LEVELS];            // [0] logic box, [1] render box, per level
+};
+struct FrameHeader {
+    unsigned long long cursor;              // low 32: entries, high 32: instances
+    uint32_t n_vis_map, n_vis_vec, n_groups, total;
+};
+struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, pad; };
+struct InstanceRange { uint32_t model_index, render_system, sortable, begin, count; };
+
+__global__ void k_transform_assign(RowArrays R, uint32_t n, uint32_t outline, uint32_t atomic, uint64_t *row_key, uint8_t *row_nk,
+                                   SharedRec *shrec, uint32_t *shrec_count, uint32_t shrec_cap);
+__global__ void k_fold_tight(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
+                             const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many);
+__global__ void k_fold_shared(uint32_t nsh, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat, const uint32_t *rows, const Aabb *ent_aabb, Aabb *sh_aabb);
+__global__ void k_static_cache_cells(uint32_t ncells, const Aabb *cell_tight, uint8_t *cell_flags, FrameParams P);
+__global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty, int32_t *sh_owner, uint8_t *sh_cached, FrameParams P);
+__global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const Aabb *cell_tight, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
+                                const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, uint4 *entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P);
+__global__ void k_cull_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat,
+                              const int32_t *sh_owner, const uint8_t *sh_cached, const uint32_t *cell_stamp, const uint8_t *cell_flags, const Aabb *cell_tight,
+                              uint4 *entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P);
+__global__ void k_emit_count(const uint4 *entries, uint32_t entry_cap, const FrameHeader *hdr, const uint32_t *rows, const uint32_t *row_gclass,
+                             uint32_t *item_row, uint32_t *item_slot, uint32_t item_cap, uint32_t *group_count, uint32_t nslots);
+__global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
+                             const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr);
+__global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
+                               uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
+__global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
+                       const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
+                       const Aabb *sh_aabb, FrameParams P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap);
+__global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
+
+}  // namespace re

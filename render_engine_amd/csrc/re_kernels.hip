@@ -1,0 +1,582 @@
+// re_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the visible-set pipeline.
+//
+// Written for 64-wide wavefronts: ballots are 64-bit, in-wave prefix sums use mbcnt, one atomic
+// per wave reserves output space.  No MFMA: the work is branchy per-section / per-entity integer
+// and f32 math, bound by HBM (the section-key scan) -- see DESIGN.md for the roofline of each kernel.
+// Built with -ffp-contract=off: every f32 result that feeds a visibility decision must round
+// exactly like the reference's Rust code (see re_math.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "re_kernels.h"
+#include "re_math.h"
+
+namespace re {
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+// inclusive scan of v over the 64 lanes of the wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d, 64); if (l >= (uint32_t)d) v += o; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_transform: per entity row, TRS -> TransformationMatrix + StaticAABB, then the spatial-hash
+// section decision of BoundingBoxTree::add_entity (world/bounding_box_tree_v2.rs:563-579).
+// mode 0 = registration (EntityTransformationBuilder::write_components: only supplied factors)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transform_assign(RowArrays R, uint32_t n, uint32_t outline, uint32_t atomic,
+                                                           uint64_t *row_key, uint8_t *row_nk, SharedRec *shrec, uint32_t *shrec_count, uint32_t shrec_cap) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t fl = R.flags[r];
+    float pos[3] = { R.pos[r * 3 + 0], R.pos[r * 3 + 1], R.pos[r * 3 + 2] };
+    float axis[3] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2] }; float angle = R.rot[r * 4 + 3];
+    float scl[3] = { R.scale[r * 3 + 0], R.scale[r * 3 + 1], R.scale[r * 3 + 2] };
+    float m[16];
+    trs_matrix(pos, (fl & F_HAS_ROT) != 0, axis, angle, (fl & F_HAS_SCALE) != 0, scl, m);
+    float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
+    mo[0] = make_float4(m[0], m[1], m[2], m[3]); mo[1] = make_float4(m[4], m[5], m[6], m[7]);
+    mo[2] = make_float4(m[8], m[9], m[10], m[11]); mo[3] = make_float4(m[12], m[13], m[14], m[15]);
+    Aabb orig = R.orig[r];
+    Aabb a = apply_transformation(orig, m);
+    R.aabb[r] = a;
+    Aabb bv = a;
+    bool oob = normalize_aabb(&bv, (float)outline);
+    uint64_t keys[8];
+    int nk = oob ? 0 : assign_sections(bv, atomic, keys);      // apply_choices adds with add_if_out_bounds = false
+    if (nk < 0) nk = 0;
+    row_nk[r] = (uint8_t)nk;
+    row_key[r] = nk >= 1 ? keys[0] : 0ull;
+    if (nk > 1) {
+        uint32_t slot = atomicAdd(shrec_count, 1u);
+        if (slot < shrec_cap) {
+            SharedRec rec; rec.row = r; rec.nk = (uint32_t)nk;
+            for (int k = 0; k < 8; k++) rec.keys[k] = k < nk ? keys[k] : 0ull;
+            shrec[slot] = rec;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K_fold: BoundingBoxTree::end_of_changes (:1055-1130).  One lane per world section folds the
+// epsilon-biased combine over local_entities.chain(static_entities) in CSR order (ascending id),
+// or takes back_up_aabb when too many sections changed and the section is crowded.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_tight(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
+                                                    const uint32_t *cell_nstatic, const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight,
+                                                    uint32_t atomic, int too_many) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    uint64_t key = cell_key[c];
+    uint32_t n = cell_nlocal[c] + cell_nstatic[c];
+    uint32_t adj = 20u + key_level(key) * 5u; if (adj > 50u) adj = 50u;
+    Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };                    // StaticAABB::point_aabb()
+    if (too_many && n > adj) u = key_to_aabb(key, atomic);        // back_up_aabb
+    else {
+        uint32_t b = cell_begin[c];
+        for (uint32_t i = 0; i < n; i++) {
+            Aabb e = ent_aabb[rows[b + i]];
+            u = (i == 0) ? e : combine_aabb(u, e);
+        }
+    }
+    cell_tight[c] = u;
+}
+// shared-section branch of end_of_changes (:1104-1125): first_entity is never cleared, so the AABB
+// is that of the last entity iterated (entities, then static_entities)
+__global__ __launch_bounds__(256) void k_fold_shared(uint32_t nsh, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat,
+                                                     const uint32_t *rows, const Aabb *ent_aabb, Aabb *sh_aabb) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsh) return;
+    uint32_t n = sh_nact[s] + sh_nstat[s];
+    Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (n) u = ent_aabb[rows[sh_begin[s] + n - 1]];
+    sh_aabb[s] = u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: static render cache (flows/render_flow.rs:549-594).  A unique section whose static set
+// changed is re-cached with the camera of this frame: its static entities are cached only if
+// distance_to_aabb(section.aabb) < far at that moment (sort_unique_world_sections :749-754).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_static_cache_cells(uint32_t ncells, const Aabb *cell_tight, uint8_t *cell_flags, FrameParams P) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    uint8_t f = cell_flags[c];
+    if (!(f & CF_STATIC_DIRTY)) return;
+    float d = distance_to_aabb(cell_tight[c], P.cam[0], P.cam[1], P.cam[2]);
+    f &= ~(CF_STATIC_DIRTY | CF_STATIC_CACHED);
+    if (d < P.far_draw) f |= CF_STATIC_CACHED;
+    cell_flags[c] = f;
+}
+// shared sections reached from a re-cached unique section (sort_shared_world_sections(is_static) :808-866):
+// the first unique section (ascending key == ascending index) that reaches it caches its static entities
+__global__ __launch_bounds__(256) void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty,
+                                                             int32_t *sh_owner, uint8_t *sh_cached, FrameParams P) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsh) return;
+    if (!sh_dirty[s]) return;
+    int32_t owner = -1;
+    for (int k = 0; k < 8; k++) { int32_t c = sh_cells[s * 8 + k]; if (c >= 0 && (owner < 0 || c < owner)) owner = c; }
+    float d2 = distance_to_aabb(sh_aabb[s], P.cam[0], P.cam[1], P.cam[2]);
+    sh_owner[s] = owner; sh_cached[s] = (uint8_t)(d2 < P.far_draw); sh_dirty[s] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: visibility query over the spatial hash == VisibleWorldFlow::find_visible_world_ids for both
+// cullers (flows/visible_world_flow.rs:40-146, flows/pipeline.rs:216-229) fused with the
+// per-section part of RenderFlow (distance test, LOD; render_flow.rs:475-492, 749-754).
+//
+// The reference enumerates every candidate id of a camera-centred box per level and probes a hash
+// map.  Here the occupied sections are one key-sorted array: a section is a candidate iff its own
+// index lies inside the box of its level, so the query is ONE streaming pass over the 8-byte keys
+// (the only per-section bytes read for non-candidates).  Phase 1: each workgroup scans a
+// contiguous chunk of keys (2 keys = 16 B per lane per load) and compacts candidates into an LDS
+// queue with wave ballots.  Phase 2: dense lanes run the predicates on the queued candidates and
+// append {row range, count, running instance offset, LOD} entries with one 64-bit atomic per wave.
+// Per-level box tables live in LDS (levels are not wave-uniform at level boundaries).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *__restrict__ cell_key, uint32_t ncells,
+                                                                const Aabb *__restrict__ cell_tight, const uint32_t *__restrict__ cell_begin,
+                                                                const uint32_t *__restrict__ cell_nlocal, const uint32_t *__restrict__ cell_nstatic,
+                                                                const uint8_t *__restrict__ cell_flags, uint32_t *__restrict__ cell_stamp,
+                                                                uint4 *__restrict__ entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P) {
+    __shared__ LevelBox s_box[2][MAX_LEVELS];
+    __shared__ uint32_t s_queue[CULL_CHUNK];
+    __shared__ uint32_t s_qn;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < 2 * MAX_LEVELS; i += CULL_THREADS) s_box[i / MAX_LEVELS][i % MAX_LEVELS] = P.box[i / MAX_LEVELS][i % MAX_LEVELS];
+    if (tid == 0) s_qn = 0;
+    __syncthreads();
+
+    // ---- phase 1: stream the keys of this chunk, queue candidates ----
+    const uint32_t chunk_begin = blockIdx.x * CULL_CHUNK;
+    const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);      // key array is padded to an even count
+#pragma unroll
+    for (uint32_t it = 0; it < CULL_CHUNK / (2 * CULL_THREADS); it++) {
+        uint32_t c0 = chunk_begin + (it * CULL_THREADS + tid) * 2;
+        bool cand0 = false, cand1 = false;
+        if (c0 < ncells) {
+            ulonglong2 kk = kp[c0 >> 1];
+            {
+                uint32_t lv = key_level(kk.x);
+                if (lv < P.max_level) {
+                    LevelBox a = s_box[0][lv], b = s_box[1][lv];
+                    uint32_t x = key_x(kk.x), y = key_y(kk.x), z = key_z(kk.x);
+                    bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
+                    bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
+                    cand0 = inl | inr;
+                }
+            }
+            if (c0 + 1 < ncells) {
+                uint32_t lv = key_level(kk.y);
+                if (lv < P.max_level) {
+                    LevelBox a = s_box[0][lv], b = s_box[1][lv];
+                    uint32_t x = key_x(kk.y), y = key_y(kk.y), z = key_z(kk.y);
+                    bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
+                    bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
+                    cand1 = inl | inr;
+                }
+            }
+        }
+        uint64_t m0 = __ballot(cand0), m1 = __ballot(cand1);
+        uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
+        if (n0 + n1) {                                                       // wave-uniform
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(&s_qn, n0 + n1);
+            base = __shfl(base, 0, 64);
+            if (cand0) s_queue[base + mbcnt(m0)] = c0;
+            if (cand1) s_queue[base + n0 + mbcnt(m1)] = c0 + 1;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: predicates on the candidates, dense lanes ----
+    const uint32_t qn = s_qn;
+    uint32_t vis_map_acc = 0, vis_vec_acc = 0;
+    for (uint32_t i0 = 0; i0 < qn; i0 += CULL_THREADS) {                     // uniform trip count per workgroup
+        uint32_t i = i0 + tid;
+        bool has = false; uint32_t rb = 0, cnt = 0, lod = 0, mult = 0, nemit = 0;
+        if (i < qn) {
+            uint32_t c = s_queue[i];
+            uint64_t key = cell_key[c];
+            uint32_t lv = key_level(key), x = key_x(key), y = key_y(key), z = key_z(key);
+            LevelBox a = s_box[0][lv], b = s_box[1][lv];
+            bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
+            bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
+            // candidate AABB as visible_world_flow.rs:73-82: base = (base_unique + i) as f32 * level_length
+            float ll = a.level_length;
+            bool visl = false, visr = false;
+            if (inl) {
+                float fx = (float)(a.bx + ((x - a.bx) & 0xFFFFu)) * ll, fy = (float)(a.by + ((y - a.by) & 0xFFFFu)) * ll, fz = (float)(a.bz + ((z - a.bz) & 0xFFFFu)) * ll;
+                Aabb g = { fx, fx + ll, fy, fy + ll, fz, fz + ll };
+                visl = logic_aabb_in_view(P.lookahead, P.cam[0], P.cam[1], P.cam[2], g);
+            }
+            if (inr) {
+                float fx = (float)(b.bx + ((x - b.bx) & 0xFFFFu)) * ll, fy = (float)(b.by + ((y - b.by) & 0xFFFFu)) * ll, fz = (float)(b.bz + ((z - b.bz) & 0xFFFFu)) * ll;
+                Aabb g = { fx, fx + ll, fy, fy + ll, fz, fz + ll };
+                visr = frustum_aabb_visible(P.planes, g);
+            }
+            if (visl | visr) {
+                mult = (visl && visr) ? 2u : 1u;
+                cell_stamp[c] = (P.frame << 2) | mult;
+                vis_map_acc += 1; vis_vec_acc += mult;
+                Aabb t = cell_tight[c];
+                float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
+                uint8_t f = cell_flags[c];
+                bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
+                bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
+                uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c];
+                rb = cell_begin[c] + (act ? 0u : nl);
+                cnt = (act ? nl : 0u) + (sta ? ns : 0u);
+                lod = lod_index(d, P.n_lod, P.lod_min, P.lod_max);
+                uint32_t m = P.emit_duplicates ? mult : 1u;
+                nemit = cnt * m;
+                has = cnt > 0;
+                lod |= m << 8;
+            }
+        }
+        uint64_t mask = __ballot(has);
+        if (mask) {
+            uint32_t incl = wave_incl_scan(nemit);
+            uint32_t tot = __shfl(incl, 63, 64);
+            uint32_t ne = __popcll(mask);
+            unsigned long long base = 0;
+            if (lane_id() == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->cursor), (unsigned long long)ne | ((unsigned long long)tot << 32));
+            base = __shfl(base, 0, 64);
+            if (has) {
+                uint32_t slot = (uint32_t)base + mbcnt(mask);
+                if (slot < entry_cap) entries[slot] = make_uint4(rb, cnt, (uint32_t)(base >> 32) + (incl - nemit), lod);
+            }
+        }
+    }
+    // visible-section counters: one atomic per wave
+    for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); }
+    if (lane_id() == 0 && vis_map_acc) { atomicAdd(&hdr->n_vis_map, vis_map_acc); atomicAdd(&hdr->n_vis_vec, vis_vec_acc); }
+}
+
+// K1b: shared world sections (render_flow.rs:808-866): emitted once per frame when some linking
+// unique section is visible and active; static members through the unique section that cached them.
+__global__ __launch_bounds__(256) void k_cull_shared(uint32_t nsh, const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
+                                                     const uint32_t *__restrict__ sh_begin, const uint32_t *__restrict__ sh_nact, const uint32_t *__restrict__ sh_nstat,
+                                                     const int32_t *__restrict__ sh_owner, const uint8_t *__restrict__ sh_cached,
+                                                     const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags, const Aabb *__restrict__ cell_tight,
+                                                     uint4 *__restrict__ entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t rbA = 0, cntA = 0, lodA = 0, rbS = 0, cntS = 0, lodS = 0;
+    if (s < nsh) {
+        bool act = false;
+        for (int k = 0; k < 8; k++) {
+            int32_t c = sh_cells[s * 8 + k];
+            if (c >= 0 && (cell_stamp[c] >> 2) == P.frame && !(cell_flags[c] & CF_STATIC_SECTION)) act = true;
+        }
+        uint32_t na = sh_nact[s], ns = sh_nstat[s], b = sh_begin[s];
+        if (act && na) {
+            float d2 = distance_to_aabb(sh_aabb[s], P.cam[0], P.cam[1], P.cam[2]);
+            if (d2 < P.far_draw) { rbA = b; cntA = na; lodA = lod_index(d2, P.n_lod, P.lod_min, P.lod_max) | (1u << 8); }
+        }
+        int32_t ow = sh_owner[s];
+        if (ns && ow >= 0 && sh_cached[s]) {
+            uint32_t st = cell_stamp[ow];
+            if ((st >> 2) == P.frame) {
+                float d = distance_to_aabb(cell_tight[ow], P.cam[0], P.cam[1], P.cam[2]);      // extract_static_data uses the unique section's distance
+                if (!(d > P.far_draw)) { rbS = b + na; cntS = ns; uint32_t m = P.emit_duplicates ? (st & 3u) : 1u; lodS = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8); }
+            }
+        }
+    }
+    // two possible entries per lane: append active then static
+    for (int pass = 0; pass < 2; pass++) {
+        uint32_t rb = pass ? rbS : rbA, cnt = pass ? cntS : cntA, lod = pass ? lodS : lodA;
+        uint32_t nemit = cnt * ((lod >> 8) & 3u);
+        bool has = cnt > 0;
+        uint64_t mask = __ballot(has);
+        if (mask) {
+            uint32_t incl = wave_incl_scan(nemit);
+            uint32_t tot = __shfl(incl, 63, 64);
+            uint32_t ne = __popcll(mask);
+            unsigned long long base = 0;
+            if (lane_id() == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->cursor), (unsigned long long)ne | ((unsigned long long)tot << 32));
+            base = __shfl(base, 0, 64);
+            if (has) {
+                uint32_t slot = (uint32_t)base + mbcnt(mask);
+                if (slot < entry_cap) entries[slot] = make_uint4(rb, cnt, (uint32_t)(base >> 32) + (incl - nemit), lod);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2a: expand entries to instances, classify each into its (ModelId with LOD, sortable) group
+// (RenderFlow::add_entities, render_flow.rs:872-933) and count per group.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t find_entry(const uint4 *__restrict__ entries, uint32_t ne, uint32_t t) {
+    uint32_t lo = 0, hi = ne;                                 // largest e with entries[e].z <= t
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (entries[mid].z <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_emit_count(const uint4 *__restrict__ entries, uint32_t entry_cap, const FrameHeader *hdr,
+                                                    const uint32_t *__restrict__ rows, const uint32_t *__restrict__ row_gclass,
+                                                    uint32_t *__restrict__ item_row, uint32_t *__restrict__ item_slot, uint32_t item_cap,
+                                                    uint32_t *__restrict__ group_count, uint32_t nslots) {
+    extern __shared__ uint32_t s_hist[];
+    const bool use_lds = nslots <= LDS_HIST_SLOTS;
+    if (use_lds) { for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) s_hist[i] = 0; __syncthreads(); }
+    unsigned long long cur = hdr->cursor;
+    uint32_t ne = (uint32_t)cur; if (ne > entry_cap) ne = entry_cap;
+    uint32_t T = (uint32_t)(cur >> 32); if (T > item_cap) T = item_cap;
+    if (ne) {
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+            uint4 e = entries[find_entry(entries, ne, t)];
+            uint32_t k = t - e.z;
+            uint32_t slot = 0xFFFFFFFFu, row = 0xFFFFFFFFu;
+            if (k < e.y * ((e.w >> 8) & 3u)) {                 // entries beyond entry_cap were dropped: their items resolve to nothing
+                row = rows[e.x + (k % e.y)];
+                uint32_t gc = row_gclass[row];
+                if (gc != 0xFFFFFFFFu) {
+                    slot = gc * 8u + (e.w & 7u);
+                    if (use_lds) atomicAdd(&s_hist[slot], 1u); else atomicAdd(&group_count[slot], 1u);
+                }
+            }
+            item_row[t] = row; item_slot[t] = slot;
+        }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) { uint32_t v = s_hist[i]; if (v) atomicAdd(&group_count[i], v); }
+    }
+}
+
+// K2b: exclusive scan of the group counts -> InstanceRange table (upload_instance_data_to_render_system,
+// render_flow.rs:964-983).  One workgroup; also resets the per-frame counters.
+__global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
+                                                     uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
+                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr) {
+    __shared__ uint32_t s_wsum[16], s_wcnt[16];
+    __shared__ uint32_t s_carry, s_gcarry;
+    if (threadIdx.x == 0) { s_carry = 0; s_gcarry = 0; }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nslots; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < nslots ? group_count[i] : 0u;
+        uint32_t nz = v ? 1u : 0u;
+        uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
+        if (lane == 63) { s_wsum[wid] = incl; s_wcnt[wid] = incn; }
+        __syncthreads();
+        uint32_t woff = 0, wcn = 0;
+        for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
+        uint32_t begin = s_carry + woff + incl - v;
+        uint32_t gidx = s_gcarry + wcn + incn - nz;
+        if (i < nslots) {
+            group_begin[i] = begin; group_fill[i] = 0; group_count[i] = 0;
+            if (v && gidx < range_cap) {
+                uint32_t gc = i >> 3, lod = i & 7u;
+                InstanceRange r; r.model_index = gc_model[gc] | (lod << 25); r.render_system = gc_rs[gc]; r.sortable = gc_sort[gc]; r.begin = begin; r.count = v;
+                ranges[gidx] = r;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { s_carry = begin + v; s_gcarry = gidx + nz; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { hdr->total = s_carry; hdr->n_groups = s_gcarry; }
+}
+
+// K2c: scatter -- the instance pack (specify_type_ids! callback + MappedBuffer::write_data_serialized,
+// prelude/layout_update_macros.rs:15-21, render_components/mapped_buffer.rs:166-189).
+// Per workgroup iteration 256 instances: (A) one lane per instance ranks it inside its group with an
+// LDS histogram, one global atomic per (workgroup, group) reserves the slots; (B) 4 lanes per
+// instance each move one float4 of the 64-byte column-major matrix, so a wave instruction
+// reads/writes 16 whole 64-byte rows.
+__global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_slot, uint32_t item_cap,
+                                                      const uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill, uint32_t nslots,
+                                                      const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
+                                                      uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap) {
+    extern __shared__ uint32_t s_hist[];                       // [nslots] local counts, then the reserved bases
+    __shared__ uint32_t s_pos[256], s_row[256];
+    const bool use_lds = nslots <= LDS_HIST_SLOTS;
+    uint32_t T = (uint32_t)(hdr->cursor >> 32); if (T > item_cap) T = item_cap;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t t0 = blockIdx.x * 256u; t0 < T; t0 += gridDim.x * 256u) {   // uniform trip count per workgroup
+        uint32_t t = t0 + tid;
+        uint32_t slot = 0xFFFFFFFFu, row = 0, rank = 0, pos = 0xFFFFFFFFu;
+        if (t < T) { slot = item_slot[t]; row = item_row[t]; }
+        if (use_lds) {
+            for (uint32_t i = tid; i < nslots; i += 256u) s_hist[i] = 0;
+            __syncthreads();
+            if (slot != 0xFFFFFFFFu) rank = atomicAdd(&s_hist[slot], 1u);
+            __syncthreads();
+            for (uint32_t i = tid; i < nslots; i += 256u) { uint32_t v = s_hist[i]; if (v) s_hist[i] = atomicAdd(&group_fill[i], v); }
+            __syncthreads();
+            if (slot != 0xFFFFFFFFu) pos = group_begin[slot] + s_hist[slot] + rank;
+        } else if (slot != 0xFFFFFFFFu) pos = group_begin[slot] + atomicAdd(&group_fill[slot], 1u);
+        s_pos[tid] = pos; s_row[tid] = row;
+        if (pos < out_cap) out_ids[pos] = row_id[row];
+        __syncthreads();
+        const uint32_t part = tid & 3u;
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            uint32_t li = q * 64u + (tid >> 2);
+            uint32_t p = s_pos[li];
+            if (p < out_cap) {
+                const float4 *src = reinterpret_cast<const float4 *>(row_mat + (size_t)s_row[li] * 16);
+                float4 *dst = reinterpret_cast<float4 *>(out_mats + (size_t)p * 16);
+                dst[part] = src[part];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: the ECS tick.  LogicFlow::apply_kinematics (flows/logic_flow.rs:366-448) + the component math of
+// exports/movement_components.rs:210-299 + update_aabb_after_kinematic_change
+// (helper_things/entity_change_helpers.rs:217-262), in place on the SoA columns.
+// One lane per dynamic entity (entities carrying Velocity or VelocityRotation).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
+    float n = norm3(v[0], v[1], v[2]); o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+
+__global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+                                              float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
+                                              RowArrays R, const uint32_t *__restrict__ row_cell,
+                                              const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                              const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
+                                              FrameParams P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
+                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ndyn) return;
+    uint32_t r = dyn_row[j];
+    uint32_t fl = R.flags[r];
+    uint32_t rc = row_cell[r];
+    // reset_has_changed_component (logic_flow.rs:776-801)
+    uint32_t nfl = fl & ~(F_HAS_MOVED | F_HAS_ROTATED);
+    bool run = false;
+    if (fl & F_DEAD) run = false;
+    else if (tick_all) run = rc != ROW_CELL_NONE;
+    else if (rc == ROW_CELL_NONE) run = false;
+    else if (!(rc & ROW_CELL_SHARED)) {
+        bool vis = (cell_stamp[rc] >> 2) == P.frame;
+        // visible loop: local (non-static) entities of active visible sections; always-execute entities
+        // only when their section is NOT in visible_sections_map (find_always_execute_entities :803-836)
+        run = (!(fl & F_STATIC) && vis) || ((fl & F_ALWAYS_EXEC) && !vis);
+    } else {
+        uint32_t s = rc & ~ROW_CELL_SHARED;
+        bool anyvis = false, act = false;
+        for (int k = 0; k < 8; k++) {
+            int32_t c = sh_cells[s * 8 + k];
+            if (c >= 0 && (cell_stamp[c] >> 2) == P.frame) { anyvis = true; if (!(cell_flags[c] & CF_STATIC_SECTION)) act = true; }
+        }
+        bool inview = false;
+        if (act && !(fl & F_STATIC)) {
+            Aabb sa = sh_aabb[s];
+            inview = logic_aabb_in_view(P.lookahead, P.cam[0], P.cam[1], P.cam[2], sa) || frustum_aabb_visible(P.planes, sa);   // logic_flow.rs:338-339
+        }
+        run = (!(fl & F_STATIC) && act && inview) || ((fl & F_ALWAYS_EXEC) && !anyvis);
+    }
+    if (!run) { if (nfl != fl) R.flags[r] = nfl; return; }
+
+    bool pos_set = false, rot_set = false;
+    float pos[3] = { R.pos[r * 3 + 0], R.pos[r * 3 + 1], R.pos[r * 3 + 2] };
+    float rot[4] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2], R.rot[r * 4 + 3] };
+    if (fl & F_HAS_VEL) {
+        float v[3] = { dyn_vel[j * 3 + 0], dyn_vel[j * 3 + 1], dyn_vel[j * 3 + 2] };
+        if (fl & F_HAS_ACC) {
+            float a[3] = { dyn_acc[j * 3 + 0], dyn_acc[j * 3 + 1], dyn_acc[j * 3 + 2] };
+            if (norm3(a[0], a[1], a[2]) != 0.0f) {                            // :384  velocity += acceleration * dt
+                dyn_vel[j * 3 + 0] = v[0] + a[0] * dt; dyn_vel[j * 3 + 1] = v[1] + a[1] * dt; dyn_vel[j * 3 + 2] = v[2] + a[2] * dt;
+            }
+        }
+        if (norm3(v[0], v[1], v[2]) != 0.0f) {                                // :394  position += OLD velocity * dt (change requests are deferred)
+            pos[0] = pos[0] + v[0] * dt; pos[1] = pos[1] + v[1] * dt; pos[2] = pos[2] + v[2] * dt;
+            pos_set = true;
+        }
+    }
+    if (fl & F_HAS_ROTVEL) {
+        float w[4] = { dyn_rotvel[j * 4 + 0], dyn_rotvel[j * 4 + 1], dyn_rotvel[j * 4 + 2], dyn_rotvel[j * 4 + 3] };
+        if (fl & F_HAS_ROTACC) {
+            float a[4] = { dyn_rotacc[j * 4 + 0], dyn_rotacc[j * 4 + 1], dyn_rotacc[j * 4 + 2], dyn_rotacc[j * 4 + 3] };
+            if (a[3] != 0.0f) {                                               // :418
+                float sc[3] = { a[0] * dt, a[1] * dt, a[2] * dt }, nrm[3], sum[3], out[3];
+                normalize3(sc, nrm);
+                sum[0] = w[0] + nrm[0]; sum[1] = w[1] + nrm[1]; sum[2] = w[2] + nrm[2];
+                normalize3(sum, out);
+                dyn_rotvel[j * 4 + 0] = out[0]; dyn_rotvel[j * 4 + 1] = out[1]; dyn_rotvel[j * 4 + 2] = out[2]; dyn_rotvel[j * 4 + 3] = w[3] + a[3] * dt;
+            }
+        }
+        if (w[3] != 0.0f) {                                                   // :429  rotation += OLD rotation velocity * dt
+            float sc[3] = { w[0] * dt, w[1] * dt, w[2] * dt }, nrm[3], sum[3], out[3];
+            normalize3(sc, nrm);
+            sum[0] = rot[0] + nrm[0]; sum[1] = rot[1] + nrm[1]; sum[2] = rot[2] + nrm[2];
+            normalize3(sum, out);
+            rot[0] = out[0]; rot[1] = out[1]; rot[2] = out[2]; rot[3] = rot[3] + w[3] * dt;
+            rot_set = true;
+        }
+    }
+    if (pos_set) nfl |= F_HAS_MOVED;
+    if (rot_set) nfl |= F_HAS_ROTATED;
+    if (nfl != fl) R.flags[r] = nfl;
+    if (!pos_set && !rot_set) return;
+    atomicAdd(&th->n_changed, 1u);
+    if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
+    if (rot_set) { R.rot[r * 4 + 0] = rot[0]; R.rot[r * 4 + 1] = rot[1]; R.rot[r * 4 + 2] = rot[2]; R.rot[r * 4 + 3] = rot[3]; }
+
+    // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262)
+    Aabb orig = R.orig[r], a;
+    float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
+    if (pos_set && !rot_set) {
+        // translation-only fast path: column 3 xyz overwritten, OriginalAABB translated (rotation/scale ignored, :221-240)
+        float4 c3 = mo[3]; c3.x = pos[0]; c3.y = pos[1]; c3.z = pos[2]; mo[3] = c3;
+        a.xmin = orig.xmin + pos[0]; a.xmax = orig.xmax + pos[0]; a.ymin = orig.ymin + pos[1]; a.ymax = orig.ymax + pos[1]; a.zmin = orig.zmin + pos[2]; a.zmax = orig.zmax + pos[2];
+    } else {
+        float scl[3] = { R.scale[r * 3 + 0], R.scale[r * 3 + 1], R.scale[r * 3 + 2] };   // Scale::default() when absent (set at upload)
+        float m[16];
+        trs_matrix(pos, true, rot, rot[3], true, scl, m);                               // all three factors, defaults when absent (:245-250)
+        mo[0] = make_float4(m[0], m[1], m[2], m[3]); mo[1] = make_float4(m[4], m[5], m[6], m[7]);
+        mo[2] = make_float4(m[8], m[9], m[10], m[11]); mo[3] = make_float4(m[12], m[13], m[14], m[15]);
+        a = apply_transformation(orig, m);
+    }
+    R.aabb[r] = a;
+    // update_entity_in_tree -> add_entity (:325-351): same section => nothing else happens
+    Aabb bv = a;
+    bool oob = normalize_aabb(&bv, (float)outline);
+    if (oob && !(fl & F_OOB_LOGIC)) {
+        uint32_t slot = atomicAdd(&th->n_oob, 1u);
+        if (slot < list_cap) oob_rows[slot] = r;
+        R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
+        return;
+    }
+    uint64_t keys[8];
+    int nk = assign_sections(bv, atomic, keys);
+    bool same;
+    if (rc == ROW_CELL_NONE) same = false;
+    else if (!(rc & ROW_CELL_SHARED)) same = (nk == 1) && keys[0] == cell_key[rc];
+    else {
+        uint32_t s = rc & ~ROW_CELL_SHARED;
+        same = nk > 1;
+        for (int k = 0; k < 8 && same; k++) {
+            int32_t c = sh_cells[s * 8 + k];
+            if (k < nk) same = c >= 0 && cell_key[c] == keys[k]; else same = c < 0;
+        }
+    }
+    if (!same) {
+        uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
+        if (slot < list_cap) mover_rows[slot] = r;
+    }
+}
+
+// gathers the visible sections of the last cull for re_debug_get_visible_sections
+__global__ __launch_bounds__(256) void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    uint32_t st = cell_stamp[c];
+    if ((st >> 2) == frame) { uint32_t s = atomicAdd(count, 1u); if (s < cap) { out_idx[s] = c; out_mult[s] = (uint8_t)(st & 3u); } }
+}
+
+}  // namespace re

@@ -1,0 +1,255 @@
+"""Host-side mirror of the reference interface for the visible-set path, over the C ABI.
+
+Names follow the reference: `Pipeline.register_model_instances` (flows/pipeline.rs:186-208),
+`Pipeline.execute` = cull + render gather/pack + logic tick (flows/pipeline.rs:212-276), `Camera`
+built like `CameraBuilder::build` (exports/camera_object.rs:341-386), `CullResult`,
+`InstanceRange`.  All compute happens in librender_engine_hip.so; this file only marshals.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+# One entity as EntityTransformationBuilder fills it (exports/entity_transformer.rs:12-29)
+ENTITY_DT = np.dtype([
+    ("id", "u4"), ("model_index", "u4"), ("render_system", "u4"), ("sortable", "u4"), ("flags", "u4"),
+    ("original", "f4", 6),           # xmin,xmax,ymin,ymax,zmin,zmax
+    ("pos", "f4", 3), ("rot_axis", "f4", 3), ("rot_angle", "f4"), ("scale", "f4", 3),
+    ("vel", "f4", 3), ("acc", "f4", 3), ("rotvel_axis", "f4", 3), ("rotvel", "f4"),
+    ("rotacc_axis", "f4", 3), ("rotacc", "f4"),
+])
+
+
+class RenderEngineError(RuntimeError):
+    pass
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def perspective(aspect, fovy, near, far):
+    """nalgebra Perspective3::new(aspect, fovy, znear, zfar) (column-major 16 floats)."""
+    aspect, fovy, near, far = map(_f32, (aspect, fovy, near, far))
+    m = np.zeros(16, np.float32)
+    m11 = _f32(1.0) / _f32(np.tan(fovy / _f32(2.0)))
+    m[5] = m11; m[0] = m11 / aspect
+    m[10] = (far + near) / (near - far)
+    m[14] = far * near * _f32(2.0) / (near - far)
+    m[11] = -1.0
+    return m
+
+
+def look_at(eye, target, up=(0.0, 1.0, 0.0)):
+    """Right-handed look-at view matrix (glm::look_at convention), column-major."""
+    eye, target, up = (np.asarray(v, np.float32) for v in (eye, target, up))
+
+    def nrm(v):
+        return v / np.sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2], dtype=np.float32)
+    f = nrm(target - eye)
+    s = nrm(np.array([f[1] * up[2] - f[2] * up[1], f[2] * up[0] - f[0] * up[2], f[0] * up[1] - f[1] * up[0]], np.float32))
+    u = np.array([s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]], np.float32)
+    m = np.zeros(16, np.float32); m[15] = 1.0
+    m[0], m[4], m[8] = s; m[1], m[5], m[9] = u; m[2], m[6], m[10] = -f
+    m[12] = -((s[0] * eye[0] + s[1] * eye[1]) + s[2] * eye[2])
+    m[13] = -((u[0] * eye[0] + u[1] * eye[1]) + u[2] * eye[2])
+    m[14] = ((f[0] * eye[0] + f[1] * eye[1]) + f[2] * eye[2])
+    return m
+
+
+def mat4_mul(a, b):
+    """Column-major product with nalgebra's accumulation order (k = 0..3, separately rounded)."""
+    a = np.asarray(a, np.float32).reshape(4, 4); b = np.asarray(b, np.float32).reshape(4, 4)   # [col][row]
+    out = np.zeros((4, 4), np.float32)
+    for j in range(4):
+        for i in range(4):
+            y = a[0, i] * b[j, 0]
+            y = a[1, i] * b[j, 1] + y
+            y = a[2, i] * b[j, 2] + y
+            y = a[3, i] * b[j, 3] + y
+            out[j, i] = y
+    return out.reshape(16)
+
+
+def create_level_of_views(render_distance):
+    """prelude/default_render_system.rs:240-256"""
+    rd = _f32(render_distance)
+    v1 = rd * _f32(0.10); v2 = rd * _f32(0.15) + v1; v3 = rd * _f32(0.20) + v2; v4 = rd * _f32(0.25) + v3; v5 = rd * _f32(0.30) + v4
+    return np.array([0.0, v1, v2, v3, v4], np.float32), np.array([v1, v2, v3, v4, v5], np.float32)
+
+
+class Camera:
+    """CameraBuilder defaults of the sample game: fov 45 deg, near 0.1 (main.rs:25-30)."""
+
+    def __init__(self, position, direction, far_draw_distance, fov_degrees=45.0, window_dimensions=(1280, 720),
+                 near_draw_distance=0.1, level_of_views=None, projection_view=None):
+        self.position = np.asarray(position, np.float32)
+        self.direction = np.asarray(direction, np.float32)
+        self.far_draw_distance = float(far_draw_distance)
+        if projection_view is None:
+            proj = perspective(_f32(window_dimensions[0]) / _f32(window_dimensions[1]), np.radians(_f32(fov_degrees)),
+                               near_draw_distance, far_draw_distance)
+            view = look_at(self.position, self.position + self.direction)
+            projection_view = mat4_mul(proj, view)
+        self.projection_view = np.asarray(projection_view, np.float32).reshape(16)
+        self.level_of_views = level_of_views if level_of_views is not None else create_level_of_views(far_draw_distance)
+
+    def to_c(self):
+        c = _capi.CameraC()
+        c.projection_view[:] = [float(x) for x in self.projection_view]
+        c.position[:] = [float(x) for x in self.position]; c.direction[:] = [float(x) for x in self.direction]
+        c.far_draw = self.far_draw_distance
+        lo, hi = self.level_of_views
+        c.n_lod = len(lo)
+        for i in range(len(lo)):
+            c.lod_min[i] = float(lo[i]); c.lod_max[i] = float(hi[i])
+        return c
+
+
+class Pipeline:
+    """One GPU's share of the world: BoundingBoxTree + ECS columns resident in HBM."""
+
+    def __init__(self, tree_outline_length=16384, tree_atomic_length=64, device=0, max_instances=0):
+        self._L = _capi.load()
+        cfg = _capi.Config(device, tree_outline_length, tree_atomic_length, max_instances, 0)
+        h = C.c_void_p()
+        rc = self._L.re_create(C.byref(cfg), C.byref(h))
+        if rc != _capi.RE_OK:
+            raise RenderEngineError(f"re_create failed ({rc}): {self._L.re_last_error(None).decode()}")
+        self._h = h
+        self.outline_length, self.atomic_length = tree_outline_length, tree_atomic_length
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.re_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != _capi.RE_OK:
+            raise RenderEngineError(f"{what} failed ({rc}): {self._L.re_last_error(self._h).decode()}")
+
+    # -- Pipeline::register_model_instances ------------------------------------------------------
+    def register_model_instances(self, ents):
+        """ents: numpy structured array of ENTITY_DT.  Returns the number rejected as out of bounds."""
+        e = np.ascontiguousarray(ents, ENTITY_DT)
+        n = len(e)
+        cols = dict(
+            entity_id=np.ascontiguousarray(e["id"]), model_index=np.ascontiguousarray(e["model_index"]),
+            render_system=np.ascontiguousarray(e["render_system"]), sortable=np.ascontiguousarray(e["sortable"]),
+            flags=np.ascontiguousarray(e["flags"]), original_aabb=np.ascontiguousarray(e["original"]),
+            position=np.ascontiguousarray(e["pos"]),
+            rotation=np.ascontiguousarray(np.concatenate([e["rot_axis"], e["rot_angle"][:, None]], axis=1)) if n else np.zeros((0, 4), np.float32),
+            scale=np.ascontiguousarray(e["scale"]), velocity=np.ascontiguousarray(e["vel"]), acceleration=np.ascontiguousarray(e["acc"]),
+            rotation_velocity=np.ascontiguousarray(np.concatenate([e["rotvel_axis"], e["rotvel"][:, None]], axis=1)) if n else np.zeros((0, 4), np.float32),
+            rotation_acceleration=np.ascontiguousarray(np.concatenate([e["rotacc_axis"], e["rotacc"][:, None]], axis=1)) if n else np.zeros((0, 4), np.float32),
+        )
+        return self.upload_columns(n, **cols)
+
+    def upload_columns(self, n, entity_id, model_index, flags, original_aabb, position, render_system=None, sortable=None,
+                       rotation=None, scale=None, velocity=None, acceleration=None, rotation_velocity=None, rotation_acceleration=None):
+        """SoA upload straight into re_upload_entities (no structured-array staging)."""
+        E = _capi.Entities(); E.n = n
+        keep = []
+
+        def u32(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, np.uint32); keep.append(a); return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+        def f32(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, np.float32); keep.append(a); return a.ctypes.data_as(C.POINTER(C.c_float))
+        E.entity_id = u32(entity_id); E.model_index = u32(model_index); E.render_system = u32(render_system); E.sortable = u32(sortable)
+        E.flags = u32(flags); E.original_aabb = f32(original_aabb); E.position = f32(position); E.rotation = f32(rotation)
+        E.scale = f32(scale); E.velocity = f32(velocity); E.acceleration = f32(acceleration)
+        E.rotation_velocity = f32(rotation_velocity); E.rotation_acceleration = f32(rotation_acceleration)
+        rej = C.c_uint32()
+        self._check(self._L.re_upload_entities(self._h, C.byref(E), C.byref(rej)), "re_upload_entities")
+        return rej.value
+
+    # -- Pipeline::execute, split at the reference's own seams -----------------------------------
+    def cull_and_pack(self, camera, emit_duplicates=False, asynchronous=False, copy=True):
+        """pipeline.rs:216-229 + render_flow.rs:401-410.  Returns dict(total, ids, mats, groups, ...)."""
+        cam = camera.to_c()
+        vis = _capi.Visible()
+        flags = (_capi.CULL_EMIT_DUPLICATES if emit_duplicates else 0) | (_capi.CULL_ASYNC if asynchronous else 0)
+        self._check(self._L.re_cull_pack(self._h, C.byref(cam), flags, C.byref(vis)), "re_cull_pack")
+        if asynchronous:
+            return None
+        return self._visible_to_py(vis, copy)
+
+    def _visible_to_py(self, vis, copy=True):
+        groups = np.zeros(vis.n_groups, dtype=[("model_index", "u4"), ("render_system", "u4"), ("sortable", "u4"), ("begin", "u4"), ("count", "u4")])
+        for g in range(vis.n_groups):
+            r = vis.groups[g]
+            groups[g] = (r.model_index, r.render_system, r.sortable, r.begin_instance, r.count)
+        out = dict(n_visible_sections=vis.n_visible_sections, n_visible_vec=vis.n_visible_vec, total=vis.n_instances,
+                   n_written=vis.n_written, groups=groups, d_entity_ids=vis.d_entity_ids, d_matrices=vis.d_matrices)
+        if copy:
+            ids = np.zeros(vis.n_written, np.uint32); mats = np.zeros((vis.n_written, 16), np.float32); nw = C.c_uint32()
+            self._check(self._L.re_copy_visible(self._h, ids.ctypes.data, mats.ctypes.data, vis.n_written, C.byref(nw)), "re_copy_visible")
+            out["ids"], out["mats"] = ids[:nw.value], mats[:nw.value]
+        return out
+
+    def tick(self, delta_time, all_dynamic=False, asynchronous=False):
+        """logic_flow.rs:230 update_positions + :255 apply_change."""
+        tr = _capi.TickResult()
+        flags = (_capi.TICK_ALL_DYNAMIC if all_dynamic else 0) | (_capi.TICK_ASYNC if asynchronous else 0)
+        self._check(self._L.re_tick(self._h, np.float32(delta_time), flags, C.byref(tr)), "re_tick")
+        return None if asynchronous else dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
+
+    def wait(self, copy=False):
+        vis = _capi.Visible(); tr = _capi.TickResult()
+        self._check(self._L.re_wait(self._h, C.byref(vis), C.byref(tr)), "re_wait")
+        return self._visible_to_py(vis, copy), dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
+
+    def set_output_buffers(self, ids_ptr, mats_ptr, capacity):
+        self._check(self._L.re_set_output_buffers(self._h, ids_ptr, mats_ptr, capacity), "re_set_output_buffers")
+
+    # -- ECS read-back -----------------------------------------------------------------------------
+    def read_component(self, entity_id, component):
+        if component == _capi.C_FLAGS:
+            v = np.zeros(1, np.uint32)
+        else:
+            v = np.zeros(_capi.COMPONENT_FLOATS[component], np.float32)
+        self._check(self._L.re_read_component(self._h, entity_id, component, v.ctypes.data), "re_read_component")
+        return v
+
+    def out_of_bounds(self, cap=4096):
+        ids = np.zeros(cap, np.uint32); n = C.c_uint32()
+        self._check(self._L.re_get_out_of_bounds(self._h, ids.ctypes.data, cap, C.byref(n)), "re_get_out_of_bounds")
+        return ids[:min(n.value, cap)]
+
+    # -- introspection -----------------------------------------------------------------------------
+    def stats(self):
+        s = _capi.Stats(); self._check(self._L.re_get_stats(self._h, C.byref(s)), "re_get_stats")
+        return {k: getattr(s, k) for k, _ in s._fields_}
+
+    def sections(self):
+        n = self.stats()["n_sections"]
+        keys = np.zeros(n, np.uint64); tight = np.zeros((n, 6), np.float32); nl = np.zeros(n, np.uint32); ns = np.zeros(n, np.uint32)
+        st = np.zeros(n, np.uint8); cnt = C.c_uint32()
+        self._check(self._L.re_debug_get_sections(self._h, n, keys.ctypes.data, tight.ctypes.data, nl.ctypes.data, ns.ctypes.data, st.ctypes.data, C.byref(cnt)), "re_debug_get_sections")
+        return dict(keys=keys, tight=tight, n_local=nl, n_static=ns, is_static_section=st)
+
+    def visible_sections(self):
+        n = self.stats()["n_sections"]
+        keys = np.zeros(n, np.uint64); mult = np.zeros(n, np.uint8); cnt = C.c_uint32()
+        self._check(self._L.re_debug_get_visible_sections(self._h, n, keys.ctypes.data, mult.ctypes.data, C.byref(cnt)), "re_debug_get_visible_sections")
+        return keys[:cnt.value], mult[:cnt.value]
+
+    def timings_us(self):
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        self._check(self._L.re_get_timings(self._h, C.byref(a), C.byref(b), C.byref(c)), "re_get_timings")
+        return dict(cull=a.value, pack=b.value, tick=c.value)
+
+    def stream(self):
+        return self._L.re_get_stream(self._h)

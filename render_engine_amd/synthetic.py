@@ -1,0 +1,145 @@
+"""Deterministic synthetic worlds for the configs of BASELINE.json.
+
+Counter-based RNG: splitmix64(seed ^ (index * 0x9E3779B97F4A7C15)), float = top 24 bits / 2^24,
+so every entity is reproducible from its index alone (any rank can generate its own shard).
+"""
+import numpy as np
+
+from . import _capi
+from .pipeline import ENTITY_DT
+
+SEED_LAYOUT, SEED_SPIN, SEED_MIX = 0x5EED0001, 0x5EED0002, 0x5EED0003
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64(x):
+    x = np.asarray(x, np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + _GOLD
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed, index, stream):
+    """float32 in [0,1) for (seed, entity index, stream number)"""
+    with np.errstate(over="ignore"):
+        k = np.uint64(seed) ^ (np.asarray(index, np.uint64) * _GOLD) ^ (np.uint64(stream) * np.uint64(0xD1B54A32D192ED03))
+    return ((splitmix64(k) >> np.uint64(40)).astype(np.float32) / np.float32(16777216.0)).astype(np.float32)
+
+
+def lattice_world(cells_per_axis=216, first_cell=20, atomic=64, index_range=None, spinner_every=0, n_models=8,
+                  straddler_fraction=0.0, mover_every=0):
+    """Config 2/3: one entity per level-0 section of a cubic lattice (uniform spatial-hash fill).
+
+    Entity i sits in section (cx,cy,cz) = first_cell + unravel(i) (x major, then z, then y: the
+    key order), half extent h = 0.5 + 1.5*u0, centre jittered inside the section.  All static,
+    model ids round-robin.  spinner_every=k: ids == 0 mod k are non-static asteroids
+    (space_logic/solar_system/asteroid.rs:118-123): VelocityRotation about +y, rate in
+    [-20,20] deg/s, Rotation((0,1,0), 0.1 deg), Scale 2, h <= 1 so the rotated box stays inside.
+    straddler_fraction: that share of entities gets h in [20,40] (shared sections, higher levels).
+    mover_every=k: ids == 1 mod k additionally carry a Velocity of up to 30 units/s.
+    """
+    n_total = cells_per_axis ** 3
+    lo, hi = (0, n_total) if index_range is None else index_range
+    idx = np.arange(lo, hi, dtype=np.uint64)
+    n = len(idx)
+    cx = (idx // np.uint64(cells_per_axis * cells_per_axis)).astype(np.int64) + first_cell
+    cz = ((idx // np.uint64(cells_per_axis)) % np.uint64(cells_per_axis)).astype(np.int64) + first_cell
+    cy = (idx % np.uint64(cells_per_axis)).astype(np.int64) + first_cell
+    e = np.zeros(n, ENTITY_DT)
+    e["id"] = idx.astype(np.uint32)
+    e["model_index"] = (idx % np.uint64(n_models)).astype(np.uint32)
+    u0, u1, u2, u3 = (uniform(SEED_LAYOUT, idx, s) for s in range(4))
+    h = (np.float32(0.5) + np.float32(1.5) * u0).astype(np.float32)
+    flags = np.full(n, _capi.F_STATIC, np.uint32)
+    scale = np.ones((n, 3), np.float32)
+    if spinner_every:
+        spin = (idx % np.uint64(spinner_every)) == 0
+        h = np.where(spin, np.float32(0.25) + np.float32(0.25) * u0, h).astype(np.float32)      # scaled by 2 -> <= 1
+        flags = np.where(spin, np.uint32(_capi.F_HAS_ROT | _capi.F_HAS_ROTVEL | _capi.F_HAS_SCALE), flags).astype(np.uint32)
+        scale[spin] = 2.0
+        rate = (np.radians(np.float32(40.0)) * (uniform(SEED_SPIN, idx, 0) - np.float32(0.5))).astype(np.float32)
+        rate = np.where(rate == 0, np.float32(0.01), rate)
+        e["rotvel"] = np.where(spin, rate, 0).astype(np.float32)
+        e["rotvel_axis"][:, 1] = 1.0
+        e["rot_axis"][:, 1] = 1.0
+        e["rot_angle"] = np.where(spin, np.radians(np.float32(0.1)), 0).astype(np.float32)
+    else:
+        e["rot_axis"][:, 0] = 1.0; e["rotvel_axis"][:, 0] = 1.0
+    e["rotacc_axis"][:, 0] = 1.0
+    if straddler_fraction > 0:
+        big = uniform(SEED_MIX, idx, 0) < np.float32(straddler_fraction)
+        if spinner_every:
+            big &= ~spin
+        h = np.where(big, np.float32(20.0) + np.float32(20.0) * u0, h).astype(np.float32)
+    if mover_every:
+        mv = (idx % np.uint64(mover_every)) == 1
+        if spinner_every:
+            mv &= ~spin
+        flags = np.where(mv, (flags & ~np.uint32(_capi.F_STATIC)) | np.uint32(_capi.F_HAS_VEL), flags).astype(np.uint32)
+        for k in range(3):
+            e["vel"][:, k] = np.where(mv, np.float32(60.0) * (uniform(SEED_MIX, idx, 1 + k) - np.float32(0.5)), 0).astype(np.float32)
+    ext = h * scale[:, 0]                                        # world-space half extent
+    span = (np.float32(atomic) - np.float32(2.0) * ext) * np.float32(0.999)
+    span = np.maximum(span, np.float32(0.0))
+    a = np.float32(atomic)
+    e["pos"][:, 0] = cx.astype(np.float32) * a + ext + span * u1
+    e["pos"][:, 1] = cy.astype(np.float32) * a + ext + span * u2
+    e["pos"][:, 2] = cz.astype(np.float32) * a + ext + span * u3
+    for k in range(3):
+        e["original"][:, 2 * k] = -h
+        e["original"][:, 2 * k + 1] = h
+    e["scale"] = scale
+    e["flags"] = flags
+    return e
+
+
+def mixed_world(n, seed=1234, centre=(8192.0, 8192.0, 8192.0), spread=900.0, atomic=64):
+    """Small adversarial world for parity tests: random sizes (unique sections at several levels
+    and shared sections), static and active entities, spinners, movers, always-execute entities,
+    several models / render systems / sortable buckets, clustered around `centre`."""
+    idx = np.arange(n, dtype=np.uint64)
+    e = np.zeros(n, ENTITY_DT)
+    e["id"] = (idx * np.uint64(3) + np.uint64(7)).astype(np.uint32)          # non-dense ids
+    u = lambda s: uniform(seed, idx, s)
+    e["model_index"] = (u(0) * 5).astype(np.uint32)
+    e["render_system"] = (u(1) * 2).astype(np.uint32)
+    e["sortable"] = np.where(u(2) < 0.15, (u(3) * 4).astype(np.uint32), 0).astype(np.uint32)
+    size_class = u(4)
+    h = np.where(size_class < 0.6, 0.5 + 3.0 * u(5), np.where(size_class < 0.85, 8.0 + 30.0 * u(5), 40.0 + 150.0 * u(5))).astype(np.float32)
+    hy = (h * (0.5 + u(6))).astype(np.float32); hz = (h * (0.5 + u(7))).astype(np.float32)
+    e["original"][:, 0] = -h; e["original"][:, 1] = h; e["original"][:, 2] = -hy; e["original"][:, 3] = hy; e["original"][:, 4] = -hz; e["original"][:, 5] = hz
+    for k in range(3):
+        e["pos"][:, k] = np.float32(centre[k]) + np.float32(spread) * (np.float32(2.0) * u(8 + k) - np.float32(1.0))
+    kind = u(11)
+    flags = np.zeros(n, np.uint32)
+    static = kind < 0.45
+    flags[static] |= _capi.F_STATIC
+    spin = (kind >= 0.45) & (kind < 0.7)
+    flags[spin] |= _capi.F_HAS_ROT | _capi.F_HAS_ROTVEL
+    accel_spin = spin & (u(12) < 0.3)
+    flags[accel_spin] |= _capi.F_HAS_ROTACC
+    mover = (kind >= 0.6) & (kind < 0.85)
+    flags[mover] |= _capi.F_HAS_VEL
+    accel_mv = mover & (u(13) < 0.4)
+    flags[accel_mv] |= _capi.F_HAS_ACC
+    scaled = u(14) < 0.3
+    flags[scaled] |= _capi.F_HAS_SCALE
+    rotated = (u(15) < 0.3) | spin
+    flags[rotated] |= _capi.F_HAS_ROT
+    flags[u(16) < 0.05] |= _capi.F_ALWAYS_EXEC
+    flags[u(17) < 0.5] |= _capi.F_OOB_LOGIC
+    for k in range(3):
+        e["rot_axis"][:, k] = u(20 + k) - np.float32(0.5) + (np.float32(0.6) if k == 1 else 0)
+        e["rotvel_axis"][:, k] = u(23 + k) - np.float32(0.5) + (np.float32(0.6) if k == 0 else 0)
+        e["rotacc_axis"][:, k] = u(26 + k) - np.float32(0.5) + (np.float32(0.6) if k == 2 else 0)
+        e["scale"][:, k] = np.float32(0.5) + np.float32(1.5) * u(29 + k)
+        e["vel"][:, k] = np.float32(40.0) * (u(32 + k) - np.float32(0.5))
+        e["acc"][:, k] = np.float32(10.0) * (u(35 + k) - np.float32(0.5))
+    e["rot_angle"] = (np.float32(6.0) * (u(38) - np.float32(0.5))).astype(np.float32)
+    e["rotvel"] = (np.float32(2.0) * (u(39) - np.float32(0.5))).astype(np.float32)
+    e["rotacc"] = (np.float32(0.5) * (u(40) - np.float32(0.5))).astype(np.float32)
+    e["vel"][u(41) < 0.1] = 0                                   # zero-velocity branch
+    e["flags"] = flags
+    return e
