@@ -475,7 +475,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     if (c->dirty_pending) {
         if (c->ncells) hipLaunchKernelGGL(k_static_cache_cells, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_tight.p, c->d_cell_flags.p, P);
         if (c->nsh) hipLaunchKernelGGL(k_static_cache_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_dirty.p, c->d_sh_owner.p, c->d_sh_cached.p, P);
-        c->dirty_pending = false;
+        // the changed-static set is consumed by every render until the frame ends (re_tick clears it)
     }
     if (c->ncells) hipLaunchKernelGGL(k_cull_sections, dim3((c->ncells + CULL_CHUNK - 1) / CULL_CHUNK), dim3(CULL_THREADS), 0, st, c->d_cell_key.p, c->ncells, c->d_cell_tight.p,
                                       c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
@@ -525,6 +525,11 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
     if (c->ndyn) hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                                     row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->P, dt,
                                     (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap);
+    if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
+        uint32_t m = std::max(c->ncells, c->nsh);
+        if (m) hipLaunchKernelGGL(k_clear_static_dirty, dim3((m + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_flags.p, c->nsh, c->d_sh_dirty.p);
+        c->dirty_pending = false;
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev[4], st));
     HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, sizeof(TickHeader), hipMemcpyDeviceToHost, st));

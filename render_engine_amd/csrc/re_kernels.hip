@@ -109,9 +109,15 @@ __global__ __launch_bounds__(256) void k_static_cache_cells(uint32_t ncells, con
     uint8_t f = cell_flags[c];
     if (!(f & CF_STATIC_DIRTY)) return;
     float d = distance_to_aabb(cell_tight[c], P.cam[0], P.cam[1], P.cam[2]);
-    f &= ~(CF_STATIC_DIRTY | CF_STATIC_CACHED);
+    f &= ~CF_STATIC_CACHED;                                   // the dirty bit stays until the frame ends (pipeline.rs:271)
     if (d < P.far_draw) f |= CF_STATIC_CACHED;
     cell_flags[c] = f;
+}
+// Pipeline::execute -> clear_changed_static_unique (flows/pipeline.rs:271)
+__global__ __launch_bounds__(256) void k_clear_static_dirty(uint32_t ncells, uint8_t *cell_flags, uint32_t nsh, uint8_t *sh_dirty) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncells) { uint8_t f = cell_flags[i]; if (f & CF_STATIC_DIRTY) cell_flags[i] = f & ~CF_STATIC_DIRTY; }
+    if (i < nsh) sh_dirty[i] = 0;
 }
 // shared sections reached from a re-cached unique section (sort_shared_world_sections(is_static) :808-866):
 // the first unique section (ascending key == ascending index) that reaches it caches its static entities
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void k_static_cache_shared(uint32_t nsh, const
     int32_t owner = -1;
     for (int k = 0; k < 8; k++) { int32_t c = sh_cells[s * 8 + k]; if (c >= 0 && (owner < 0 || c < owner)) owner = c; }
     float d2 = distance_to_aabb(sh_aabb[s], P.cam[0], P.cam[1], P.cam[2]);
-    sh_owner[s] = owner; sh_cached[s] = (uint8_t)(d2 < P.far_draw); sh_dirty[s] = 0;
+    sh_owner[s] = owner; sh_cached[s] = (uint8_t)(d2 < P.far_draw);
 }
 
 // ---------------------------------------------------------------------------------------------
