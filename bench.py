@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py -- entities/sec through cull + transform on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the hot path over the resident world: re_cull_pack (visibility query over the
+spatial hash + frustum/logic cull + instance pack) followed by re_tick (ECS kinematic / TRS->mat4
+tick) -- Pipeline::execute of the reference (flows/pipeline.rs:212-276).  Inputs are resident in HBM
+before the timed region starts.  N=1: BASELINE.json configs[1] (10,077,696 static entities, one
+per level-0 world section, uniform spatial-hash fill, one camera frustum).  N>1 (weak scaling):
+N x 10,077,696 entities sharded by contiguous section-key range, one process per GPU, with an RCCL
+all-gather of every GPU's packed visible-instance buffer each step (configs[3] at N=8).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+PER_GPU_AXIS = 216             # 216^3 = 10,077,696 sections/entities per GPU
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--far", type=float, default=1000.0, help="camera far draw distance (reference default 1000, main.rs:23)")
+    ap.add_argument("--axis", type=int, default=PER_GPU_AXIS, help="sections per axis per GPU (216 -> 10,077,696 entities)")
+    ap.add_argument("--spinner-every", type=int, default=0, help="0 = configs[1] (all static); 100 = configs[2] (100k rotating bodies)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-axis", type=int, default=100)
+    return ap.parse_args()
+
+
+def world_dims(n_gpus, axis):
+    """N x axis^3 sections as a box whose x extent grows first (key order is x-major)."""
+    f = [1, 1, 1]
+    n, i = n_gpus, 0
+    while n > 1:
+        if n % 2:
+            raise SystemExit("--gpus must be a power of two")
+        f[i % 3] *= 2; n //= 2; i += 1
+    return axis * f[0], axis * f[1], axis * f[2]     # nx, nz, ny
+
+
+def make_shard(rank, n_gpus, axis, atomic, spinner_every):
+    """Entities of this rank: a contiguous range of the x-major section index space."""
+    from render_engine_amd import synthetic
+    nx, nz, ny = world_dims(n_gpus, axis)
+    total = nx * nz * ny
+    per = total // n_gpus
+    lo, hi = rank * per, (rank + 1) * per if rank < n_gpus - 1 else total
+    first = (16384 // atomic - max(nx, nz, ny)) // 2
+    return synthetic.box_world((nx, nz, ny), first_cell=first, atomic=atomic, index_range=(lo, hi), spinner_every=spinner_every), (nx, nz, ny), first
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import render_engine_amd as R
+    from render_engine_amd import parallel
+
+    atomic = 64 if world == 1 else 32            # 432 sections per axis need atomic 32
+    t0 = time.time()
+    ents, dims, first = make_shard(rank, world, a.axis, atomic, a.spinner_every)
+    n_local = len(ents)
+    cap = 1 << 16 if a.far <= 2000 else max(1 << 16, n_local // 2)
+    p = R.Pipeline(16384, atomic, device=local, max_instances=cap)
+    p.register_model_instances(ents)
+    stats = p.stats()
+    del ents
+    t_setup = time.time() - t0
+    centre = [(first + d / 2.0) * atomic for d in (dims[0], dims[2], dims[1])]      # x, y, z
+    cam = R.Camera(centre, (0.0, 0.0, -1.0), a.far)
+    camc = cam.to_c()
+    gather = parallel.VisibleAllGather(p, cap, dist) if world > 1 else None
+
+    def step(sync_each):
+        if gather is not None:
+            vis = p.cull_and_pack(camc, copy=False)          # the packed buffer must be complete before the exchange
+            gather.exchange(vis["n_written"])
+            p.tick(0.016, asynchronous=not sync_each)
+        else:
+            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False)
+            p.tick(0.016, asynchronous=not sync_each)
+
+    def fence():
+        p.wait()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        step(False)
+    fence()
+    p.timing_begin(a.steps)
+    t_start = time.perf_counter()
+    for _ in range(a.steps):
+        step(False)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    k1_us = p.timing_collect(a.steps)
+    vis, _ = p.wait()
+    n_cand = p.last_candidates()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        tot = torch.tensor([n_local], dtype=torch.int64, device="cuda"); dist.all_reduce(tot); n_total = int(tot.item())
+    else:
+        n_total = n_local
+
+    # per-frame latency with a host sync after every call (what a frame loop that draws each frame sees)
+    lat = []
+    for _ in range(min(50, a.steps)):
+        t1 = time.perf_counter(); step(True); p.wait(); lat.append(time.perf_counter() - t1)
+    tm = p.timings_us()
+
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        # roofline of the dominant kernel (k_cull_sections): algorithmic bytes per launch, see DESIGN.md
+        C_sections = stats["n_sections"]
+        n_entries = vis["n_visible_sections"]
+        alg_bytes = 8 * C_sections + 41 * n_cand + 20 * n_entries
+        k1_mean = float(np.mean(k1_us)) if len(k1_us) else float("nan")
+        achieved = alg_bytes / (k1_mean * 1e-6) / 1e9 if k1_mean > 0 else None
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_k_cull_sections.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "entities/sec through cull+transform; visible-set ms/frame @ 10M entities",
+            "value": n_total / (elapsed / a.steps), "unit": "entities/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[1]: %d static entities, one per level-0 world section (uniform spatial-hash fill), 1 camera frustum far=%g"
+                                    % (n_total, a.far)) if not a.spinner_every else
+                                   ("configs[2]: %d entities incl. every %dth rotating (ECS tick + cull), far=%g" % (n_total, a.spinner_every, a.far)),
+                       "entities": n_total, "sections": C_sections * world, "dynamic_entities": stats["n_dynamic"] * world,
+                       "visible_sections": vis["n_visible_sections"], "visible_instances": vis["total"], "far": a.far,
+                       "sharding": "none" if world == 1 else "contiguous section-key ranges, RCCL all-gather of packed visible buffers"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_cull_sections", "algorithmic_bytes_per_launch": alg_bytes,
+                         "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us))},
+            "frame_latency_ms_sync": float(np.median(lat) * 1e3),
+            "kernel_us_last_frame": tm, "setup_s": t_setup,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a, atomic, n_total)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, atomic, n_total):
+    """The CPU oracle (oracle/, a port of the reference algorithm: hash-map spatial index, candidate-box
+    enumeration + probe in chunks of 25, per-entity 64-byte append, sequential apply_change), timed on
+    the host cores of this box over a bounded sample."""
+    import oracle as ro
+    from render_engine_amd import synthetic, Camera
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import to_oracle, oracle_camera
+    ax = min(a.cpu_sample_axis, a.axis)
+    first = (16384 // atomic - ax) // 2
+    ents = synthetic.lattice_world(cells_per_axis=ax, first_cell=first, atomic=atomic, spinner_every=a.spinner_every)
+    threads = os.cpu_count() or 1
+    w = ro.World(16384, atomic, threads=threads)
+    w.register(to_oracle(ents))
+    c = (first + ax / 2.0) * atomic
+    cam = oracle_camera(Camera((c, c, c), (0.0, 0.0, -1.0), a.far))
+    L, h = w.L, w.h
+    def frame():
+        L.ro_frame_cull(h, C.byref(cam), 0, None)
+        L.ro_frame_render(h, C.byref(cam), 0, 0, None, None, 0, None, None)
+        L.ro_frame_tick(h, C.byref(cam), np.float32(0.016), 0, None, None)
+    for _ in range(3):
+        frame()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        frame(); n += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or n >= 20000:
+            break
+    per_frame = el / n
+    w.close()
+    return {"value": n_total / per_frame, "unit": "entities/s", "cores": threads, "kind": "port",
+            "ms_per_frame": per_frame * 1e3,
+            "sample": ("%d frames over the %d^3-section sub-lattice (%d entities) centred on the camera: it contains every world section the "
+                       "reference's candidate-box enumeration touches at far=%g, and the hash-based CPU path does no work for sections outside "
+                       "the box, so its frame time equals that of the full %d-entity world; value = %d / that frame time"
+                       % (n, ax, len(ents), a.far, n_total, n_total))}
+
+
+if __name__ == "__main__":
+    main()

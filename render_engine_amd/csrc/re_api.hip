@@ -56,7 +56,14 @@ struct re_ctx {
     DevBuf<uint64_t> d_row_key; DevBuf<uint8_t> d_row_nk; DevBuf<SharedRec> d_shrec; DevBuf<uint32_t> d_counter;
     std::vector<uint32_t> h_id, h_flags, h_dyn_row;      // host mirrors of the immutable id column / upload flags / dynamic-row list
     bool has_rotvel = false;
-    std::unordered_map<uint32_t, uint32_t> id_to_row;
+    bool ids_identity = false;                           // entity id == row index (dense ids): no lookup table needed
+    std::vector<std::pair<uint32_t, uint32_t>> id_rows;  // otherwise (id, row) sorted by id
+    bool row_of(uint32_t id, uint32_t *row) const {
+        if (ids_identity) { if (id >= n) return false; *row = id; return true; }
+        auto p = std::lower_bound(id_rows.begin(), id_rows.end(), std::make_pair(id, 0u));
+        if (p == id_rows.end() || p->first != id) return false;
+        *row = p->second; return true;
+    }
     // sections
     uint32_t ncells = 0, nsh = 0, nrows_csr = 0;
     DevBuf<uint64_t> d_cell_key; DevBuf<Aabb> d_cell_tight; DevBuf<uint32_t> d_cell_begin, d_cell_nlocal, d_cell_nstatic, d_cell_stamp, d_rows;
@@ -80,6 +87,7 @@ struct re_ctx {
     bool cull_inflight = false, tick_inflight = false;
     re_tick_result last_tick{};
     float t_cull = 0, t_pack = 0, t_tick = 0;
+    std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0; bool k1_timing = false;   // per-launch timing of k_cull_sections
 
     int fail(int code, const char *fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -135,6 +143,7 @@ extern "C" void re_destroy(re_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_world(c);
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : c->k1_events) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -291,7 +300,8 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     std::vector<uint32_t> dyn_row; std::vector<float> dvel, dacc, drv, dra;
     std::unordered_map<GroupKey, uint32_t, GroupKeyHash> gmap; std::vector<GroupKey> gkeys;
     c->h_id.assign(E->entity_id, E->entity_id + n);
-    c->id_to_row.clear(); c->id_to_row.reserve(n);
+    c->ids_identity = true; c->id_rows.clear();
+    for (uint32_t r = 0; r < n && c->ids_identity; r++) if (E->entity_id[r] != r) c->ids_identity = false;
     for (uint32_t r = 0; r < n; r++) {
         uint32_t fl = E->flags[r] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
         flags[r] = fl;
@@ -319,9 +329,13 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
             if (fl & F_HAS_ROTACC) { const float *a = E->rotation_acceleration + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]); ra[0] = a[0] / nn; ra[1] = a[1] / nn; ra[2] = a[2] / nn; ra[3] = a[3]; }
             for (int k = 0; k < 4; k++) { drv.push_back(rv[k]); dra.push_back(ra[k]); }
         }
-        c->id_to_row[E->entity_id[r]] = r;
     }
-    if (c->id_to_row.size() != n) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity ids");
+    if (!c->ids_identity) {
+        c->id_rows.resize(n);
+        for (uint32_t r = 0; r < n; r++) c->id_rows[r] = { E->entity_id[r], r };
+        std::sort(c->id_rows.begin(), c->id_rows.end());
+        for (uint32_t r = 1; r < n; r++) if (c->id_rows[r].first == c->id_rows[r - 1].first) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity id %u", c->id_rows[r].first);
+    }
     c->h_flags = flags; c->h_dyn_row = dyn_row; c->has_rotvel = false;
     for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
     c->ndyn = (uint32_t)dyn_row.size();
@@ -477,8 +491,12 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
         if (c->nsh) hipLaunchKernelGGL(k_static_cache_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_dirty.p, c->d_sh_owner.p, c->d_sh_cached.p, P);
         // the changed-static set is consumed by every render until the frame ends (re_tick clears it)
     }
+    hipEvent_t k1a = nullptr, k1b = nullptr;
+    if (c->k1_timing && c->k1_used + 2 <= c->k1_events.size()) { k1a = c->k1_events[c->k1_used]; k1b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
+    if (k1a) HIPCHK(c, hipEventRecord(k1a, st));
     if (c->ncells) hipLaunchKernelGGL(k_cull_sections, dim3((c->ncells + CULL_CHUNK - 1) / CULL_CHUNK), dim3(CULL_THREADS), 0, st, c->d_cell_key.p, c->ncells, c->d_cell_tight.p,
                                       c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
+    if (k1b) HIPCHK(c, hipEventRecord(k1b, st));
     if (c->nsh) hipLaunchKernelGGL(k_cull_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p,
                                    c->d_sh_owner.p, c->d_sh_cached.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
     HIPCHK(c, hipEventRecord(c->ev[1], st));
@@ -571,9 +589,8 @@ extern "C" int re_set_output_buffers(re_ctx *c, uint32_t *d_ids, float *d_mats, 
 
 extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, void *dst) {
     if (!c || !dst) return RE_E_ARG;
-    auto it = c->id_to_row.find(entity_id);
-    if (it == c->id_to_row.end()) return c->fail(RE_E_ARG, "re_read_component: unknown entity %u", entity_id);
-    uint32_t r = it->second;
+    uint32_t r = 0;
+    if (!c->row_of(entity_id, &r)) return c->fail(RE_E_ARG, "re_read_component: unknown entity %u", entity_id);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     auto dynidx = [&](uint32_t &j) -> bool {                      // dynamic rows are kept in ascending row order
@@ -664,3 +681,27 @@ extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *
 }
 
 extern "C" void *re_get_stream(re_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// per-launch HIP-event timing of the dominant kernel (k_cull_sections) over a timed region:
+// re_timing_begin(ctx, max_launches) ... frames ... re_timing_collect(ctx, us[], cap, &n)
+extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches) {
+    if (!c) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    while (c->k1_events.size() < (size_t)max_launches * 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->k1_events.push_back(e); }
+    c->k1_used = 0; c->k1_timing = max_launches > 0;
+    return RE_OK;
+}
+extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) {
+    if (!c) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t launches = c->k1_used / 2;
+    for (uint32_t i = 0; i < launches && i < capacity; i++) { float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->k1_events[2 * i], c->k1_events[2 * i + 1])); if (us) us[i] = ms * 1000.f; }
+    if (n) *n = launches;
+    c->k1_timing = false; c->k1_used = 0;
+    return RE_OK;
+}
+extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {
+    if (!c || !c->h_hdr || !n_candidates) return RE_E_ARG;
+    *n_candidates = c->h_hdr->n_candidates; return RE_OK;
+}

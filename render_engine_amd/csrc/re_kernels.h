@@ -43,6 +43,7 @@ struct FrameParams {
 struct FrameHeader {
     unsigned long long cursor;              // low 32: entries, high 32: instances
     uint32_t n_vis_map, n_vis_vec, n_groups, total;
+    uint32_t n_candidates, pad0;            // sections inside a candidate box (== hash probes of the reference)
 };
 struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, pad; };
 struct InstanceRange { uint32_t model_index, render_system, sortable, begin, count; };

@@ -203,6 +203,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
 
     // ---- phase 2: predicates on the candidates, dense lanes ----
     const uint32_t qn = s_qn;
+    if (tid == 0 && qn) atomicAdd(&hdr->n_candidates, qn);
     uint32_t vis_map_acc = 0, vis_vec_acc = 0;
     for (uint32_t i0 = 0; i0 < qn; i0 += CULL_THREADS) {                     // uniform trip count per workgroup
         uint32_t i = i0 + tid;

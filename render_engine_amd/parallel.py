@@ -1,0 +1,67 @@
+"""Multi-GPU: one process per GPU, world sections sharded by contiguous key range, one exchange
+step per frame -- the all-gather of every GPU's packed visible-instance buffer (RCCL over xGMI via
+torch.distributed; backend "nccl" is RCCL on ROCm).  Sections are independent for cull and pack, so
+there is no data-path collective before the exchange.
+
+The functions work on whatever device the tensors live on, so the N>1 logic is covered by
+world_size-2 gloo tests on CPU (tests/test_parallel_gloo.py).
+"""
+import numpy as np
+import torch
+
+
+def shard_bounds(n_units, world_size):
+    """Contiguous, near-equal ranges of the key-sorted unit (section / entity index) space."""
+    base, rem = divmod(n_units, world_size)
+    out, lo = [], 0
+    for r in range(world_size):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi)); lo = hi
+    return out
+
+
+def allgather_packed(ids, mats, n_local, dist, group=None):
+    """Variable-length all-gather of {entity id, 4x4 matrix} slabs.
+
+    ids: int32/uint32-as-int32 tensor [cap]; mats: float32 [cap, 16]; n_local valid rows.
+    Returns (ids_all [sum n], mats_all [sum n, 16], counts list) in rank order -- deterministic
+    given the partition.  Two collectives: the counts (one int per rank), then slabs padded to the
+    largest count (each GPU's slab crosses each xGMI link once in a direct all-gather).
+    """
+    world = dist.get_world_size(group)
+    dev = ids.device
+    cnt = torch.tensor([int(n_local)], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    m = max(counts)
+    if m == 0:
+        return ids[:0].clone(), mats[:0].clone(), counts
+    if m > ids.shape[0]:
+        raise ValueError(f"all-gather slab of {m} instances exceeds the local buffer capacity {ids.shape[0]}")
+    send_i, send_m = ids[:m].contiguous(), mats[:m].contiguous()
+    recv_i = [torch.empty_like(send_i) for _ in range(world)]
+    recv_m = [torch.empty_like(send_m) for _ in range(world)]
+    dist.all_gather(recv_i, send_i, group=group)
+    dist.all_gather(recv_m, send_m, group=group)
+    ids_all = torch.cat([recv_i[r][:counts[r]] for r in range(world)])
+    mats_all = torch.cat([recv_m[r][:counts[r]] for r in range(world)])
+    return ids_all, mats_all, counts
+
+
+class VisibleAllGather:
+    """Binds a Pipeline's packed output to torch tensors (the all-gather send slab) and runs the
+    per-frame exchange."""
+
+    def __init__(self, pipeline, capacity, dist):
+        self.p, self.dist, self.cap = pipeline, dist, capacity
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.ids = torch.zeros(capacity, dtype=torch.int32, device=dev)
+        self.mats = torch.zeros(capacity, 16, dtype=torch.float32, device=dev)
+        pipeline.set_output_buffers(self.ids.data_ptr(), self.mats.data_ptr(), capacity)
+        self.last = None
+
+    def exchange(self, n_written):
+        self.last = allgather_packed(self.ids, self.mats, n_written, self.dist)
+        torch.cuda.current_stream().synchronize()      # the send slab is rewritten by the next cull
+        return self.last

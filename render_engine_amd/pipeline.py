@@ -178,7 +178,7 @@ class Pipeline:
     # -- Pipeline::execute, split at the reference's own seams -----------------------------------
     def cull_and_pack(self, camera, emit_duplicates=False, asynchronous=False, copy=True):
         """pipeline.rs:216-229 + render_flow.rs:401-410.  Returns dict(total, ids, mats, groups, ...)."""
-        cam = camera.to_c()
+        cam = camera if isinstance(camera, _capi.CameraC) else camera.to_c()
         vis = _capi.Visible()
         flags = (_capi.CULL_EMIT_DUPLICATES if emit_duplicates else 0) | (_capi.CULL_ASYNC if asynchronous else 0)
         self._check(self._L.re_cull_pack(self._h, C.byref(cam), flags, C.byref(vis)), "re_cull_pack")
@@ -250,6 +250,18 @@ class Pipeline:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         self._check(self._L.re_get_timings(self._h, C.byref(a), C.byref(b), C.byref(c)), "re_get_timings")
         return dict(cull=a.value, pack=b.value, tick=c.value)
+
+    def timing_begin(self, max_launches):
+        self._check(self._L.re_timing_begin(self._h, max_launches), "re_timing_begin")
+
+    def timing_collect(self, cap=65536):
+        us = np.zeros(cap, np.float32); n = C.c_uint32()
+        self._check(self._L.re_timing_collect(self._h, us.ctypes.data, cap, C.byref(n)), "re_timing_collect")
+        return us[:min(n.value, cap)]
+
+    def last_candidates(self):
+        n = C.c_uint32(); self._check(self._L.re_get_last_candidates(self._h, C.byref(n)), "re_get_last_candidates")
+        return n.value
 
     def stream(self):
         return self._L.re_get_stream(self._h)

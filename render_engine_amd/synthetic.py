@@ -30,23 +30,31 @@ def uniform(seed, index, stream):
 
 def lattice_world(cells_per_axis=216, first_cell=20, atomic=64, index_range=None, spinner_every=0, n_models=8,
                   straddler_fraction=0.0, mover_every=0):
+    """Cubic lattice: see box_world."""
+    return box_world((cells_per_axis,) * 3, first_cell, atomic, index_range, spinner_every, n_models, straddler_fraction, mover_every)
+
+
+def box_world(dims, first_cell=20, atomic=64, index_range=None, spinner_every=0, n_models=8,
+              straddler_fraction=0.0, mover_every=0):
     """Config 2/3: one entity per level-0 section of a cubic lattice (uniform spatial-hash fill).
 
-    Entity i sits in section (cx,cy,cz) = first_cell + unravel(i) (x major, then z, then y: the
-    key order), half extent h = 0.5 + 1.5*u0, centre jittered inside the section.  All static,
+    dims = (nx, nz, ny) sections per axis.  Entity i sits in section (cx,cz,cy) = first_cell +
+    unravel(i) (x major, then z, then y: the key order, so a contiguous index range is a
+    contiguous section-key range -- the multi-GPU shard), half extent h = 0.5 + 1.5*u0, centre jittered inside the section.  All static,
     model ids round-robin.  spinner_every=k: ids == 0 mod k are non-static asteroids
     (space_logic/solar_system/asteroid.rs:118-123): VelocityRotation about +y, rate in
     [-20,20] deg/s, Rotation((0,1,0), 0.1 deg), Scale 2, h <= 1 so the rotated box stays inside.
     straddler_fraction: that share of entities gets h in [20,40] (shared sections, higher levels).
     mover_every=k: ids == 1 mod k additionally carry a Velocity of up to 30 units/s.
     """
-    n_total = cells_per_axis ** 3
+    nx, nz, ny = dims
+    n_total = nx * nz * ny
     lo, hi = (0, n_total) if index_range is None else index_range
     idx = np.arange(lo, hi, dtype=np.uint64)
     n = len(idx)
-    cx = (idx // np.uint64(cells_per_axis * cells_per_axis)).astype(np.int64) + first_cell
-    cz = ((idx // np.uint64(cells_per_axis)) % np.uint64(cells_per_axis)).astype(np.int64) + first_cell
-    cy = (idx % np.uint64(cells_per_axis)).astype(np.int64) + first_cell
+    cx = (idx // np.uint64(nz * ny)).astype(np.int64) + first_cell
+    cz = ((idx // np.uint64(ny)) % np.uint64(nz)).astype(np.int64) + first_cell
+    cy = (idx % np.uint64(ny)).astype(np.int64) + first_cell
     e = np.zeros(n, ENTITY_DT)
     e["id"] = idx.astype(np.uint32)
     e["model_index"] = (idx % np.uint64(n_models)).astype(np.uint32)

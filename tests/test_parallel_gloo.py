@@ -1,0 +1,85 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank owns a contiguous section-key range of the world,
+computes its visible set (here with the CPU oracle as the per-shard stand-in -- the product's
+exchange code is device-agnostic), and the variable-length all-gather must reproduce the
+single-process result in rank order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIMS, FIRST = (24, 12, 12), 118
+
+
+def _camera():
+    from render_engine_amd import Camera
+    from helpers import oracle_camera
+    return oracle_camera(Camera(((FIRST + 12) * 64.0, (FIRST + 6) * 64.0, (FIRST + 6) * 64.0 + 200), (0, 0, -1), 1000.0))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as ro
+    from render_engine_amd import synthetic, parallel
+    from helpers import to_oracle
+    n_total = DIMS[0] * DIMS[1] * DIMS[2]
+    lo, hi = parallel.shard_bounds(n_total, world)[rank]
+    ents = synthetic.box_world(DIMS, first_cell=FIRST, index_range=(lo, hi), spinner_every=9)
+    w = ro.World(16384, 64); w.register(to_oracle(ents))
+    cam = _camera()
+    w.cull(cam); r = w.render(cam)
+    cap = 4096
+    ids = torch.zeros(cap, dtype=torch.int32); mats = torch.zeros(cap, 16)
+    ids[:r["total"]] = torch.from_numpy(r["ids"].astype(np.int32)); mats[:r["total"]] = torch.from_numpy(r["mats"])
+    ids_all, mats_all, counts = parallel.allgather_packed(ids, mats, r["total"], dist)
+    q.put((rank, r["total"], counts, ids_all.numpy().copy(), mats_all.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from render_engine_amd import parallel
+    assert parallel.shard_bounds(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert parallel.shard_bounds(8, 8)[-1] == (7, 8)
+    b = parallel.shard_bounds(10077696 * 8, 8)
+    assert all(hi - lo == 10077696 for lo, hi in b)
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_allgather_matches_single_process():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as ro
+    from render_engine_amd import synthetic
+    from helpers import to_oracle
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30); assert p.exitcode == 0
+    ents = synthetic.box_world(DIMS, first_cell=FIRST, spinner_every=9)          # single-process result over the whole world
+    w = ro.World(16384, 64); w.register(to_oracle(ents))
+    cam = _camera()
+    w.cull(cam); full = w.render(cam)
+    counts = res[0][2]
+    assert counts == [res[0][1], res[1][1]] and sum(counts) == full["total"] and min(counts) > 0
+    for rank, n, cts, ids_all, mats_all in res:
+        assert cts == counts
+        np.testing.assert_array_equal(ids_all, res[0][3])            # every rank ends with the same buffer
+        np.testing.assert_array_equal(mats_all, res[0][4])
+    ids_all, mats_all = res[0][3].astype(np.uint32), res[0][4]
+    assert set(ids_all.tolist()) == set(full["ids"].tolist()) and len(ids_all) == full["total"]
+    o1, o2 = np.argsort(ids_all), np.argsort(full["ids"])
+    np.testing.assert_array_equal(mats_all[o1], full["mats"][o2])
+    half = DIMS[0] * DIMS[1] * DIMS[2] // 2
+    assert np.all(ids_all[:counts[0]] < half) and np.all(ids_all[counts[0]:] >= half)      # rank order
