@@ -2,6 +2,7 @@
 // include/re_hip.h, device-memory ownership, world build and per-frame kernel orchestration on one
 // HIP stream per context.  No CPU fallback exists: every entry point needs a HIP device.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -74,19 +75,20 @@ struct re_ctx {
     // groups
     uint32_t ngclass = 0, nslots = 0;
     DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
-    DevBuf<InstanceRange> d_ranges;
     // frame
     uint32_t frame = 0; bool have_cull = false;
     FrameParams P{};
-    uint32_t entry_cap = 0, item_cap = 0, out_cap = 0, list_cap = 0;
-    DevBuf<uint4> d_entries; DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
+    uint32_t item_cap = 0, out_cap = 0, list_cap = 0;
+    DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
     uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0;
     DevBuf<FrameHeader> d_hdr; DevBuf<TickHeader> d_th; DevBuf<uint32_t> d_movers, d_oob;
-    FrameHeader *h_hdr = nullptr; InstanceRange *h_ranges = nullptr; TickHeader *h_th = nullptr;   // pinned
+    // results land in mapped pinned host memory, written directly by the kernels (d_* = device view)
+    HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr; TickHeader *h_th = nullptr, *d_hth = nullptr;
+    bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
     re_tick_result last_tick{};
-    float t_cull = 0, t_pack = 0, t_tick = 0;
+    float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0; bool k1_timing = false;   // per-launch timing of k_cull_sections
 
     int fail(int code, const char *fmt, ...) {
@@ -129,9 +131,9 @@ static void free_world(re_ctx *c) {
     c->d_cell_stamp.release(a); c->d_rows.release(a); c->d_cell_flags.release(a); c->d_sh_cells.release(a); c->d_sh_owner.release(a); c->d_sh_aabb.release(a);
     c->d_sh_begin.release(a); c->d_sh_nact.release(a); c->d_sh_nstat.release(a); c->d_sh_cached.release(a); c->d_sh_dirty.release(a);
     c->d_gc_model.release(a); c->d_gc_rs.release(a); c->d_gc_sort.release(a); c->d_group_count.release(a); c->d_group_begin.release(a); c->d_group_fill.release(a);
-    c->d_ranges.release(a); c->d_entries.release(a); c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
+    c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
     c->d_hdr.release(a); c->d_th.release(a); c->d_movers.release(a); c->d_oob.release(a);
-    if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
+    if (c->h_res) { (void)hipHostFree(c->h_res); c->h_res = nullptr; }
     if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
     if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false;
@@ -277,9 +279,6 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
                                    c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, too_many);
     if (nsh) hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
     HIPCHK(c, hipGetLastError());
-    // --- frame buffers sized for this world
-    c->entry_cap = ncells + 2 * nsh + 64;
-    HIPCHK(c, c->d_entries.alloc(c->entry_cap, acct));
     HIPCHK(c, hipStreamSynchronize(st));
     c->dirty_pending = true; c->have_cull = false;
     return RE_OK;
@@ -369,7 +368,6 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
         for (uint32_t g = 0; g < c->ngclass; g++) { gm[g] = gkeys[g].model; gr[g] = gkeys[g].rs; gs[g] = gkeys[g].sort; }
         HIPCHK(c, c->d_gc_model.alloc(c->ngclass, acct)); HIPCHK(c, c->d_gc_rs.alloc(c->ngclass, acct)); HIPCHK(c, c->d_gc_sort.alloc(c->ngclass, acct));
         HIPCHK(c, c->d_group_count.alloc(c->nslots, acct)); HIPCHK(c, c->d_group_begin.alloc(c->nslots, acct)); HIPCHK(c, c->d_group_fill.alloc(c->nslots, acct));
-        HIPCHK(c, c->d_ranges.alloc(c->nslots, acct));
         if (c->ngclass) {
             HIPCHK(c, hipMemcpyAsync(c->d_gc_model.p, gm.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipMemcpyAsync(c->d_gc_rs.p, gr.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice, st));
@@ -404,12 +402,18 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->list_cap = std::max(c->ndyn, 1u);
     HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
-    HIPCHK(c, c->d_hdr.alloc(1, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_hdr), sizeof(FrameHeader), hipHostMallocDefault));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocDefault));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_th), sizeof(TickHeader), hipHostMallocDefault));
-    memset(c->h_hdr, 0, sizeof(FrameHeader)); memset(c->h_th, 0, sizeof(TickHeader));
-    c->frame = 0;
+    HIPCHK(c, c->d_hdr.alloc(2, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_res), sizeof(HostResult), hipHostMallocMapped));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocMapped));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_th), sizeof(TickHeader), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hres), c->h_res, 0));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hranges), c->h_ranges, 0));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hth), c->h_th, 0));
+    memset(c->h_res, 0, sizeof(HostResult)); memset(c->h_th, 0, sizeof(TickHeader));
+    HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, 2 * sizeof(FrameHeader), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->frame = 0; c->th_clean = true; c->pred_total = 0;
     return RE_OK;
 }
 
@@ -449,9 +453,9 @@ static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
 }
 
 static void fill_visible(re_ctx *c, re_visible *out) {
-    const FrameHeader &h = *c->h_hdr;
+    const HostResult &h = *c->h_res;
     uint32_t cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
-    c->groups_out.resize(h.n_groups);
+    c->groups_out.resize(std::min(h.n_groups, c->nslots));
     for (uint32_t g = 0; g < h.n_groups && g < c->nslots; g++) {
         const InstanceRange &r = c->h_ranges[g];
         c->groups_out[g] = re_instance_range{ r.model_index, r.render_system, r.sortable, r.begin, r.count };
@@ -459,18 +463,50 @@ static void fill_visible(re_ctx *c, re_visible *out) {
     if (!out) return;
     out->n_visible_sections = h.n_vis_map; out->n_visible_vec = h.n_vis_vec;
     out->n_instances = h.total; out->n_written = std::min(h.total, cap);
-    out->n_groups = h.n_groups; out->groups = c->groups_out.data();
+    out->n_groups = (uint32_t)c->groups_out.size(); out->groups = c->groups_out.data();
     out->d_entity_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p;
     out->d_matrices = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
+}
+
+static ItemSink item_sink(re_ctx *c) {
+    ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.row_gclass = c->d_gclass.p; return K;
+}
+static SharedArrays shared_arrays(re_ctx *c) {
+    SharedArrays S; S.n = c->nsh; S.cells = c->d_sh_cells.p; S.aabb = c->d_sh_aabb.p; S.begin = c->d_sh_begin.p; S.nact = c->d_sh_nact.p; S.nstat = c->d_sh_nstat.p;
+    S.owner = c->d_sh_owner.p; S.cached = c->d_sh_cached.p; return S;
+}
+
+// multi-kernel pack for large visible sets: count -> scan -> scatter
+static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next) {
+    hipStream_t st = c->stream;
+    uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
+    uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
+    uint32_t grid = std::min(2048u, (c->item_cap + 255u) / 256u);
+    size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
+    hipLaunchKernelGGL(k_emit_count, dim3(grid), dim3(256), lds, st, hdr, c->d_item_slot.p, c->item_cap, c->d_group_count.p, c->nslots);
+    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
+                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres);
+    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
+                       c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap);
+    HIPCHK(c, hipGetLastError());
+    return RE_OK;
 }
 
 static int finish_cull(re_ctx *c, re_visible *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cull_inflight = false;
-    (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
-    c->t_cull *= 1000.f; c->t_pack *= 1000.f;
-    if ((uint32_t)c->h_hdr->cursor > c->entry_cap) return c->fail(RE_E_CAPACITY, "visible-section entry capacity exceeded");
-    if ((uint32_t)(c->h_hdr->cursor >> 32) > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", (uint32_t)(c->h_hdr->cursor >> 32), c->item_cap);
+    if (c->h_res->overflow) {
+        // the single-workgroup pack declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
+        int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u));
+        if (rc != RE_OK) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (c->timed_frame) {
+        (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
+        c->t_cull *= 1000.f; c->t_pack *= 1000.f;
+    }
+    c->pred_total = c->h_res->total;
+    if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
     fill_visible(c, out);
     return RE_OK;
 }
@@ -478,14 +514,16 @@ static int finish_cull(re_ctx *c, re_visible *out) {
 extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_visible *out) {
     if (!c) return RE_E_ARG;
     if (!cam) return c->fail(RE_E_ARG, "re_cull_pack: camera is NULL");
-    if (!c->h_hdr) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    if (c->cull_inflight && c->h_res->overflow == 0) c->pred_total = std::max(c->pred_total, c->h_res->total);   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
     const FrameParams &P = c->P;
-    HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, sizeof(FrameHeader), st));
-    HIPCHK(c, hipEventRecord(c->ev[0], st));
+    FrameHeader *hdr = c->d_hdr.p + (c->frame & 1u), *hdr_next = c->d_hdr.p + ((c->frame + 1u) & 1u);
+    c->timed_frame = !(flags & RE_CULL_ASYNC);
+    if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (c->dirty_pending) {
         if (c->ncells) hipLaunchKernelGGL(k_static_cache_cells, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_tight.p, c->d_cell_flags.p, P);
         if (c->nsh) hipLaunchKernelGGL(k_static_cache_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_dirty.p, c->d_sh_owner.p, c->d_sh_cached.p, P);
@@ -493,28 +531,26 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     }
     hipEvent_t k1a = nullptr, k1b = nullptr;
     if (c->k1_timing && c->k1_used + 2 <= c->k1_events.size()) { k1a = c->k1_events[c->k1_used]; k1b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
-    if (k1a) HIPCHK(c, hipEventRecord(k1a, st));
-    if (c->ncells) hipLaunchKernelGGL(k_cull_sections, dim3((c->ncells + CULL_CHUNK - 1) / CULL_CHUNK), dim3(CULL_THREADS), 0, st, c->d_cell_key.p, c->ncells, c->d_cell_tight.p,
-                                      c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
-    if (k1b) HIPCHK(c, hipEventRecord(k1b, st));
-    if (c->nsh) hipLaunchKernelGGL(k_cull_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p,
-                                   c->d_sh_owner.p, c->d_sh_cached.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p, c->d_entries.p, c->entry_cap, c->d_hdr.p, P);
-    HIPCHK(c, hipEventRecord(c->ev[1], st));
+    // hipExtLaunchKernelGGL ties the two events to this dispatch's own begin/end timestamps
+    if (c->ncells) hipExtLaunchKernelGGL(k_cull_sections, dim3((c->ncells + CULL_CHUNK - 1) / CULL_CHUNK), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, c->d_cell_key.p, c->ncells,
+                                         c->d_cell_tight.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p, item_sink(c), hdr, P);
+    if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
-    uint32_t grid = std::min(1024u, (c->item_cap + 255u) / 256u);
-    size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
-    hipLaunchKernelGGL(k_emit_count, dim3(grid), dim3(256), lds, st, c->d_entries.p, c->entry_cap, c->d_hdr.p, c->d_rows.p, c->d_gclass.p, c->d_item_row.p, c->d_item_slot.p,
-                       c->item_cap, c->d_group_count.p, c->nslots);
-    hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
-                       c->d_ranges.p, c->nslots, c->d_hdr.p);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, c->d_hdr.p, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
-                       c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[2], st));
-    HIPCHK(c, hipMemcpyAsync(c->h_hdr, c->d_hdr.p, sizeof(FrameHeader), hipMemcpyDeviceToHost, st));
-    if (c->nslots) HIPCHK(c, hipMemcpyAsync(c->h_ranges, c->d_ranges.p, sizeof(InstanceRange) * c->nslots, hipMemcpyDeviceToHost, st));
-    c->have_cull = true; c->cull_inflight = true;
+    bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
+    if (small) {
+        hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(PACK_SMALL_THREADS), (size_t)std::max(c->nslots, 1u) * 4, st, hdr, hdr_next, c->d_th.p, c->d_hres, item_sink(c),
+                           c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p, c->d_hranges,
+                           shared_arrays(c), c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p, P);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        if (c->nsh) hipLaunchKernelGGL(k_cull_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, shared_arrays(c), c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p,
+                                       item_sink(c), hdr, P);
+        int rc = launch_pack_large(c, hdr, hdr_next);
+        if (rc != RE_OK) return rc;
+    }
+    if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[2], st));
+    c->have_cull = true; c->cull_inflight = true; c->th_clean = true;
     if (flags & RE_CULL_ASYNC) return RE_OK;
     return finish_cull(c, out);
 }
@@ -522,35 +558,36 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
 static int finish_tick(re_ctx *c, re_tick_result *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tick_inflight = false;
-    (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f;
-    c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob;
+    if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
+    if (c->ndyn) { c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
+    else c->last_tick = re_tick_result{ 0, 0, 0 };
     if (out) *out = c->last_tick;
     return RE_OK;
 }
 
 extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out) {
     if (!c) return RE_E_ARG;
-    if (!c->h_hdr) return c->fail(RE_E_STATE, "re_tick: no world uploaded");
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_tick: no world uploaded");
     if (!(flags & RE_TICK_ALL_DYNAMIC) && !c->have_cull) return c->fail(RE_E_STATE, "re_tick: reference semantics tick entities of the last visibility query; call re_cull_pack first or pass RE_TICK_ALL_DYNAMIC");
-    if (dt == 0.0f) {
-        // VelocityRotation * 0.0 asserts in the reference (exports/movement_components.rs:287)
-        if (c->has_rotvel) return c->fail(RE_E_ARG, "re_tick: delta_time == 0 with rotating entities (the reference asserts)");
-    }
+    if (dt == 0.0f && c->has_rotvel) return c->fail(RE_E_ARG, "re_tick: delta_time == 0 with rotating entities (the reference asserts, exports/movement_components.rs:287)");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));
-    HIPCHK(c, hipEventRecord(c->ev[3], st));
-    if (c->ndyn) hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
-                                    row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->P, dt,
-                                    (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap);
+    c->timed_tick = !(flags & RE_TICK_ASYNC);
+    if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[3], st));
+    if (c->ndyn) {
+        if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
+        hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
+                           row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->P, dt,
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_hth);
+        c->th_clean = false;
+    }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
         uint32_t m = std::max(c->ncells, c->nsh);
         if (m) hipLaunchKernelGGL(k_clear_static_dirty, dim3((m + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_flags.p, c->nsh, c->d_sh_dirty.p);
         c->dirty_pending = false;
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev[4], st));
-    HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, sizeof(TickHeader), hipMemcpyDeviceToHost, st));
+    if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[4], st));
     c->tick_inflight = true;
     if (flags & RE_TICK_ASYNC) return RE_OK;
     return finish_tick(c, out);
@@ -560,18 +597,18 @@ extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_t
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = RE_OK;
-    if (c->cull_inflight) rc = finish_cull(c, out_visible); else { HIPCHK(c, hipStreamSynchronize(c->stream)); if (out_visible && c->h_hdr) fill_visible(c, out_visible); }
+    if (c->cull_inflight) rc = finish_cull(c, out_visible); else { HIPCHK(c, hipStreamSynchronize(c->stream)); if (out_visible && c->h_res) fill_visible(c, out_visible); }
     if (rc != RE_OK) return rc;
     if (c->tick_inflight) rc = finish_tick(c, out_tick); else if (out_tick) *out_tick = c->last_tick;
     return rc;
 }
 
 extern "C" int re_copy_visible(re_ctx *c, uint32_t *ids_host, float *mats_host, uint32_t capacity, uint32_t *n_written) {
-    if (!c || !c->h_hdr) return RE_E_ARG;
+    if (!c || !c->h_res) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->cull_inflight) { int rc = finish_cull(c, nullptr); if (rc) return rc; }
     uint32_t cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
-    uint32_t nw = std::min(std::min(c->h_hdr->total, cap), capacity);      // truncate and report (mapped_buffer.rs:171-186)
+    uint32_t nw = std::min(std::min(c->h_res->total, cap), capacity);      // truncate and report (mapped_buffer.rs:171-186)
     const uint32_t *src_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; const float *src_m = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     if (nw && ids_host) HIPCHK(c, hipMemcpyAsync(ids_host, src_ids, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
     if (nw && mats_host) HIPCHK(c, hipMemcpyAsync(mats_host, src_m, (size_t)nw * 64, hipMemcpyDeviceToHost, c->stream));
@@ -702,6 +739,6 @@ extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32
     return RE_OK;
 }
 extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {
-    if (!c || !c->h_hdr || !n_candidates) return RE_E_ARG;
-    *n_candidates = c->h_hdr->n_candidates; return RE_OK;
+    if (!c || !c->h_res || !n_candidates) return RE_E_ARG;
+    *n_candidates = c->h_res->n_candidates; return RE_OK;
 }

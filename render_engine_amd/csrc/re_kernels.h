@@ -19,7 +19,8 @@ constexpr uint8_t CF_STATIC_DIRTY = 4;     // member of changed_static_unique_se
 constexpr uint32_t ROW_CELL_NONE = 0xFFFFFFFFu, ROW_CELL_SHARED = 0x80000000u;
 constexpr int MAX_LEVELS = 16;
 constexpr int CULL_THREADS = 256;
-constexpr int CULL_CHUNK = 4096;           // sections per workgroup of k_cull_sections (LDS queue of 16 KiB)
+constexpr int CULL_ITERS = 8;               // 16-byte key loads in flight per lane
+constexpr int CULL_CHUNK = CULL_THREADS * CULL_ITERS * 2;   // 4096 sections per workgroup of k_cull_sections (LDS queue of 16 KiB)
 constexpr uint32_t LDS_HIST_SLOTS = 4096;  // group slots (gclass*8+lod) that fit the LDS histograms
 
 struct RowArrays {                          // one row per entity, in upload order
@@ -45,7 +46,18 @@ struct FrameHeader {
     uint32_t n_vis_map, n_vis_vec, n_groups, total;
     uint32_t n_candidates, pad0;            // sections inside a candidate box (== hash probes of the reference)
 };
-struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, pad; };
+struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; };
+// per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
+struct HostResult {
+    uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
+};
+constexpr uint32_t PACK_SMALL_THREADS = 1024;
+constexpr uint32_t PACK_SMALL_PER_THREAD = 16;
+constexpr uint32_t PACK_SMALL_ITEMS = PACK_SMALL_THREADS * PACK_SMALL_PER_THREAD;   // 16384 instances in one workgroup
+struct SharedArrays {                       // shared world sections (bounding_box_tree_v2.rs:113-155, 253-316)
+    uint32_t n;
+    const int32_t *cells; const Aabb *aabb; const uint32_t *begin, *nact, *nstat; const int32_t *owner; const uint8_t *cached;
+};
 struct InstanceRange { uint32_t model_index, render_system, sortable, begin, count; };
 
 __global__ void k_transform_assign(RowArrays R, uint32_t n, uint32_t outline, uint32_t atomic, uint64_t *row_key, uint8_t *row_nk,
@@ -56,21 +68,22 @@ __global__ void k_fold_shared(uint32_t nsh, const uint32_t *sh_begin, const uint
 __global__ void k_static_cache_cells(uint32_t ncells, const Aabb *cell_tight, uint8_t *cell_flags, FrameParams P);
 __global__ void k_clear_static_dirty(uint32_t ncells, uint8_t *cell_flags, uint32_t nsh, uint8_t *sh_dirty);
 __global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty, int32_t *sh_owner, uint8_t *sh_cached, FrameParams P);
+struct ItemSink { uint32_t *item_row, *item_slot; uint32_t item_cap; const uint32_t *rows, *row_gclass; };
 __global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const Aabb *cell_tight, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
-                                const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, uint4 *entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P);
-__global__ void k_cull_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat,
-                              const int32_t *sh_owner, const uint8_t *sh_cached, const uint32_t *cell_stamp, const uint8_t *cell_flags, const Aabb *cell_tight,
-                              uint4 *entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P);
-__global__ void k_emit_count(const uint4 *entries, uint32_t entry_cap, const FrameHeader *hdr, const uint32_t *rows, const uint32_t *row_gclass,
-                             uint32_t *item_row, uint32_t *item_slot, uint32_t item_cap, uint32_t *group_count, uint32_t nslots);
+                                const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, ItemSink K, FrameHeader *hdr, FrameParams P);
+__global__ void k_cull_shared(SharedArrays S, const uint32_t *cell_stamp, const uint8_t *cell_flags, const Aabb *cell_tight, ItemSink K, FrameHeader *hdr, FrameParams P);
+__global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t item_cap, uint32_t *group_count, uint32_t nslots);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
-                             const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr);
+                             const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres);
+__global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, ItemSink K, const uint32_t *row_id, const float *row_mat,
+                             uint32_t *out_ids, float *out_mats, uint32_t out_cap, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs, const uint32_t *gc_sort,
+                             InstanceRange *ranges, SharedArrays S, const uint32_t *cell_stamp, const uint8_t *cell_flags, const Aabb *cell_tight, FrameParams P);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, FrameParams P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
-                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap);
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th);
 __global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
 
 }  // namespace re

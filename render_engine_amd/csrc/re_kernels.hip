@@ -132,6 +132,48 @@ __global__ __launch_bounds__(256) void k_static_cache_shared(uint32_t nsh, const
     sh_owner[s] = owner; sh_cached[s] = (uint8_t)(d2 < P.far_draw);
 }
 
+// Appends the instances of up to 64 visible sections (one per lane; cnt == 0: nothing) to the frame's
+// instance list: one 64-bit atomic per wave reserves {emitting sections, instances}, an in-wave prefix
+// sum gives every lane its offset, then every lane expands its own rows (RenderFlow::add_entities,
+// render_flow.rs:872-933: ModelId + LOD -> group slot).  Sections with many rows are expanded by the
+// whole wave so one crowded section does not serialise behind a single lane.
+__device__ __forceinline__ void emit_sections(uint32_t rb, uint32_t cnt, uint32_t lodm, FrameHeader *hdr, const ItemSink &K) {
+    const uint32_t m = (lodm >> 8) & 3u, lod = lodm & 7u;
+    const uint32_t nemit = cnt * m;
+    uint64_t mask = __ballot(nemit > 0);
+    if (!mask) return;
+    uint32_t incl = wave_incl_scan(nemit);
+    uint32_t tot = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if (lane_id() == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->cursor), (unsigned long long)__popcll(mask) | ((unsigned long long)tot << 32));
+    base = __shfl(base, 0, 64);
+    uint32_t off = (uint32_t)(base >> 32) + (incl - nemit);
+    const uint32_t WIDE = 32u;
+    if (nemit && nemit <= WIDE) {
+        for (uint32_t k = 0; k < nemit; k++) {
+            uint32_t t = off + k;
+            if (t < K.item_cap) {
+                uint32_t row = K.rows[rb + (k % cnt)];
+                uint32_t gc = K.row_gclass[row];
+                K.item_row[t] = row; K.item_slot[t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
+            }
+        }
+    }
+    uint64_t wide = __ballot(nemit > WIDE);
+    while (wide) {                                              // wave-cooperative expansion of crowded sections
+        int src = __ffsll((long long)wide) - 1; wide &= wide - 1;
+        uint32_t w_rb = __shfl(rb, src, 64), w_cnt = __shfl(cnt, src, 64), w_n = __shfl(nemit, src, 64), w_off = __shfl(off, src, 64);
+        for (uint32_t k = lane_id(); k < w_n; k += 64u) {
+            uint32_t t = w_off + k;
+            if (t < K.item_cap) {
+                uint32_t row = K.rows[w_rb + (k % w_cnt)];
+                uint32_t gc = K.row_gclass[row];
+                K.item_row[t] = row; K.item_slot[t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: visibility query over the spatial hash == VisibleWorldFlow::find_visible_world_ids for both
 // cullers (flows/visible_world_flow.rs:40-146, flows/pipeline.rs:216-229) fused with the
@@ -150,7 +192,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
                                                                 const Aabb *__restrict__ cell_tight, const uint32_t *__restrict__ cell_begin,
                                                                 const uint32_t *__restrict__ cell_nlocal, const uint32_t *__restrict__ cell_nstatic,
                                                                 const uint8_t *__restrict__ cell_flags, uint32_t *__restrict__ cell_stamp,
-                                                                uint4 *__restrict__ entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P) {
+                                                                ItemSink K, FrameHeader *hdr, FrameParams P) {
     __shared__ LevelBox s_box[2][MAX_LEVELS];
     __shared__ uint32_t s_queue[CULL_CHUNK];
     __shared__ uint32_t s_qn;
@@ -160,43 +202,48 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
     __syncthreads();
 
     // ---- phase 1: stream the keys of this chunk, queue candidates ----
-    const uint32_t chunk_begin = blockIdx.x * CULL_CHUNK;
-    const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);      // key array is padded to an even count
+    // All CULL_ITERS 16-byte loads of a lane are issued back to back (independent addresses) before
+    // the first key is examined: 8 x 16 B in flight per lane is what hides the HBM latency.
+    const uint32_t chunk_pair0 = blockIdx.x * (CULL_CHUNK / 2);
+    const uint32_t npairs = (ncells + 1u) >> 1;                              // key array is padded to an even count with never-candidate keys
+    const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);
+    ulonglong2 kk[CULL_ITERS];
 #pragma unroll
-    for (uint32_t it = 0; it < CULL_CHUNK / (2 * CULL_THREADS); it++) {
-        uint32_t c0 = chunk_begin + (it * CULL_THREADS + tid) * 2;
-        bool cand0 = false, cand1 = false;
-        if (c0 < ncells) {
-            ulonglong2 kk = kp[c0 >> 1];
-            {
-                uint32_t lv = key_level(kk.x);
+    for (uint32_t it = 0; it < CULL_ITERS; it++) {
+        uint32_t pair = chunk_pair0 + it * CULL_THREADS + tid;
+        kk[it] = kp[pair < npairs ? pair : npairs - 1u];
+    }
+    uint32_t cmask = 0;
+#pragma unroll
+    for (uint32_t it = 0; it < CULL_ITERS; it++) {
+        uint32_t pair = chunk_pair0 + it * CULL_THREADS + tid;
+        if (pair < npairs) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint64_t key = h ? kk[it].y : kk[it].x;
+                uint32_t lv = key_level(key);
                 if (lv < P.max_level) {
                     LevelBox a = s_box[0][lv], b = s_box[1][lv];
-                    uint32_t x = key_x(kk.x), y = key_y(kk.x), z = key_z(kk.x);
+                    uint32_t x = key_x(key), y = key_y(key), z = key_z(key);
                     bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
                     bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
-                    cand0 = inl | inr;
-                }
-            }
-            if (c0 + 1 < ncells) {
-                uint32_t lv = key_level(kk.y);
-                if (lv < P.max_level) {
-                    LevelBox a = s_box[0][lv], b = s_box[1][lv];
-                    uint32_t x = key_x(kk.y), y = key_y(kk.y), z = key_z(kk.y);
-                    bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
-                    bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
-                    cand1 = inl | inr;
+                    if (inl | inr) cmask |= 1u << (it * 2 + h);
                 }
             }
         }
-        uint64_t m0 = __ballot(cand0), m1 = __ballot(cand1);
-        uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
-        if (n0 + n1) {                                                       // wave-uniform
+    }
+    {   // one LDS atomic per wave reserves queue space for all of its candidates
+        uint32_t cnt = __popc(cmask);
+        if (__ballot(cnt != 0)) {                                           // wave-uniform
+            uint32_t incl = wave_incl_scan(cnt);
+            uint32_t tot = __shfl(incl, 63, 64);
             uint32_t base = 0;
-            if (lane_id() == 0) base = atomicAdd(&s_qn, n0 + n1);
-            base = __shfl(base, 0, 64);
-            if (cand0) s_queue[base + mbcnt(m0)] = c0;
-            if (cand1) s_queue[base + n0 + mbcnt(m1)] = c0 + 1;
+            if (lane_id() == 0) base = atomicAdd(&s_qn, tot);
+            base = __shfl(base, 0, 64) + incl - cnt;
+            while (cmask) {
+                uint32_t bit = __ffs(cmask) - 1u; cmask &= cmask - 1u;
+                s_queue[base++] = (chunk_pair0 + (bit >> 1) * CULL_THREADS + tid) * 2u + (bit & 1u);
+            }
         }
     }
     __syncthreads();
@@ -207,7 +254,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
     uint32_t vis_map_acc = 0, vis_vec_acc = 0;
     for (uint32_t i0 = 0; i0 < qn; i0 += CULL_THREADS) {                     // uniform trip count per workgroup
         uint32_t i = i0 + tid;
-        bool has = false; uint32_t rb = 0, cnt = 0, lod = 0, mult = 0, nemit = 0;
+        bool has = false; uint32_t rb = 0, cnt = 0, lod = 0, mult = 0;
         if (i < qn) {
             uint32_t c = s_queue[i];
             uint64_t key = cell_key[c];
@@ -242,24 +289,11 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
                 cnt = (act ? nl : 0u) + (sta ? ns : 0u);
                 lod = lod_index(d, P.n_lod, P.lod_min, P.lod_max);
                 uint32_t m = P.emit_duplicates ? mult : 1u;
-                nemit = cnt * m;
                 has = cnt > 0;
                 lod |= m << 8;
             }
         }
-        uint64_t mask = __ballot(has);
-        if (mask) {
-            uint32_t incl = wave_incl_scan(nemit);
-            uint32_t tot = __shfl(incl, 63, 64);
-            uint32_t ne = __popcll(mask);
-            unsigned long long base = 0;
-            if (lane_id() == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->cursor), (unsigned long long)ne | ((unsigned long long)tot << 32));
-            base = __shfl(base, 0, 64);
-            if (has) {
-                uint32_t slot = (uint32_t)base + mbcnt(mask);
-                if (slot < entry_cap) entries[slot] = make_uint4(rb, cnt, (uint32_t)(base >> 32) + (incl - nemit), lod);
-            }
-        }
+        emit_sections(rb, has ? cnt : 0u, lod, hdr, K);
     }
     // visible-section counters: one atomic per wave
     for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); }
@@ -268,26 +302,23 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
 
 // K1b: shared world sections (render_flow.rs:808-866): emitted once per frame when some linking
 // unique section is visible and active; static members through the unique section that cached them.
-__global__ __launch_bounds__(256) void k_cull_shared(uint32_t nsh, const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
-                                                     const uint32_t *__restrict__ sh_begin, const uint32_t *__restrict__ sh_nact, const uint32_t *__restrict__ sh_nstat,
-                                                     const int32_t *__restrict__ sh_owner, const uint8_t *__restrict__ sh_cached,
-                                                     const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags, const Aabb *__restrict__ cell_tight,
-                                                     uint4 *__restrict__ entries, uint32_t entry_cap, FrameHeader *hdr, FrameParams P) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// Called by whole waves (lanes with s >= S.n contribute nothing).
+__device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                                    const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P) {
     uint32_t rbA = 0, cntA = 0, lodA = 0, rbS = 0, cntS = 0, lodS = 0;
-    if (s < nsh) {
+    if (s < S.n) {
         bool act = false;
         for (int k = 0; k < 8; k++) {
-            int32_t c = sh_cells[s * 8 + k];
+            int32_t c = S.cells[s * 8 + k];
             if (c >= 0 && (cell_stamp[c] >> 2) == P.frame && !(cell_flags[c] & CF_STATIC_SECTION)) act = true;
         }
-        uint32_t na = sh_nact[s], ns = sh_nstat[s], b = sh_begin[s];
+        uint32_t na = S.nact[s], ns = S.nstat[s], b = S.begin[s];
         if (act && na) {
-            float d2 = distance_to_aabb(sh_aabb[s], P.cam[0], P.cam[1], P.cam[2]);
+            float d2 = distance_to_aabb(S.aabb[s], P.cam[0], P.cam[1], P.cam[2]);
             if (d2 < P.far_draw) { rbA = b; cntA = na; lodA = lod_index(d2, P.n_lod, P.lod_min, P.lod_max) | (1u << 8); }
         }
-        int32_t ow = sh_owner[s];
-        if (ns && ow >= 0 && sh_cached[s]) {
+        int32_t ow = S.owner[s];
+        if (ns && ow >= 0 && S.cached[s]) {
             uint32_t st = cell_stamp[ow];
             if ((st >> 2) == P.frame) {
                 float d = distance_to_aabb(cell_tight[ow], P.cam[0], P.cam[1], P.cam[2]);      // extract_static_data uses the unique section's distance
@@ -295,62 +326,27 @@ __global__ __launch_bounds__(256) void k_cull_shared(uint32_t nsh, const int32_t
             }
         }
     }
-    // two possible entries per lane: append active then static
-    for (int pass = 0; pass < 2; pass++) {
-        uint32_t rb = pass ? rbS : rbA, cnt = pass ? cntS : cntA, lod = pass ? lodS : lodA;
-        uint32_t nemit = cnt * ((lod >> 8) & 3u);
-        bool has = cnt > 0;
-        uint64_t mask = __ballot(has);
-        if (mask) {
-            uint32_t incl = wave_incl_scan(nemit);
-            uint32_t tot = __shfl(incl, 63, 64);
-            uint32_t ne = __popcll(mask);
-            unsigned long long base = 0;
-            if (lane_id() == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->cursor), (unsigned long long)ne | ((unsigned long long)tot << 32));
-            base = __shfl(base, 0, 64);
-            if (has) {
-                uint32_t slot = (uint32_t)base + mbcnt(mask);
-                if (slot < entry_cap) entries[slot] = make_uint4(rb, cnt, (uint32_t)(base >> 32) + (incl - nemit), lod);
-            }
-        }
-    }
+    emit_sections(rbA, cntA, lodA, hdr, K);                       // active members
+    emit_sections(rbS, cntS, lodS, hdr, K);                       // static members
+}
+
+__global__ __launch_bounds__(256) void k_cull_shared(SharedArrays S, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags, const Aabb *__restrict__ cell_tight,
+                                                     ItemSink K, FrameHeader *hdr, FrameParams P) {
+    cull_shared_section(blockIdx.x * blockDim.x + threadIdx.x, S, cell_stamp, cell_flags, cell_tight, K, hdr, P);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2a: expand entries to instances, classify each into its (ModelId with LOD, sortable) group
-// (RenderFlow::add_entities, render_flow.rs:872-933) and count per group.
+// K2a (large visible sets): per-group instance counts from the expanded item list.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t find_entry(const uint4 *__restrict__ entries, uint32_t ne, uint32_t t) {
-    uint32_t lo = 0, hi = ne;                                 // largest e with entries[e].z <= t
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (entries[mid].z <= t) lo = mid; else hi = mid; }
-    return lo;
-}
-
-__global__ __launch_bounds__(256) void k_emit_count(const uint4 *__restrict__ entries, uint32_t entry_cap, const FrameHeader *hdr,
-                                                    const uint32_t *__restrict__ rows, const uint32_t *__restrict__ row_gclass,
-                                                    uint32_t *__restrict__ item_row, uint32_t *__restrict__ item_slot, uint32_t item_cap,
+__global__ __launch_bounds__(256) void k_emit_count(const FrameHeader *hdr, const uint32_t *__restrict__ item_slot, uint32_t item_cap,
                                                     uint32_t *__restrict__ group_count, uint32_t nslots) {
     extern __shared__ uint32_t s_hist[];
     const bool use_lds = nslots <= LDS_HIST_SLOTS;
     if (use_lds) { for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) s_hist[i] = 0; __syncthreads(); }
-    unsigned long long cur = hdr->cursor;
-    uint32_t ne = (uint32_t)cur; if (ne > entry_cap) ne = entry_cap;
-    uint32_t T = (uint32_t)(cur >> 32); if (T > item_cap) T = item_cap;
-    if (ne) {
-        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-            uint4 e = entries[find_entry(entries, ne, t)];
-            uint32_t k = t - e.z;
-            uint32_t slot = 0xFFFFFFFFu, row = 0xFFFFFFFFu;
-            if (k < e.y * ((e.w >> 8) & 3u)) {                 // entries beyond entry_cap were dropped: their items resolve to nothing
-                row = rows[e.x + (k % e.y)];
-                uint32_t gc = row_gclass[row];
-                if (gc != 0xFFFFFFFFu) {
-                    slot = gc * 8u + (e.w & 7u);
-                    if (use_lds) atomicAdd(&s_hist[slot], 1u); else atomicAdd(&group_count[slot], 1u);
-                }
-            }
-            item_row[t] = row; item_slot[t] = slot;
-        }
+    uint32_t T = (uint32_t)(hdr->cursor >> 32); if (T > item_cap) T = item_cap;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        uint32_t slot = item_slot[t];
+        if (slot != 0xFFFFFFFFu) { if (use_lds) atomicAdd(&s_hist[slot], 1u); else atomicAdd(&group_count[slot], 1u); }
     }
     if (use_lds) {
         __syncthreads();
@@ -362,7 +358,7 @@ __global__ __launch_bounds__(256) void k_emit_count(const uint4 *__restrict__ en
 // render_flow.rs:964-983).  One workgroup; also resets the per-frame counters.
 __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
                                                      uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
-                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr) {
+                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres) {
     __shared__ uint32_t s_wsum[16], s_wcnt[16];
     __shared__ uint32_t s_carry, s_gcarry;
     if (threadIdx.x == 0) { s_carry = 0; s_gcarry = 0; }
@@ -391,7 +387,98 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         if (threadIdx.x == 1023) { s_carry = begin + v; s_gcarry = gidx + nz; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { hdr->total = s_carry; hdr->n_groups = s_gcarry; }
+    if (threadIdx.x == 0) {
+        hdr->total = s_carry; hdr->n_groups = s_gcarry;
+        unsigned long long cur = hdr->cursor;
+        HostResult r; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
+        r.overflow = 0; r.n_entries = (uint32_t)cur; r.n_items = (uint32_t)(cur >> 32);
+        *hres = r;                                              // mapped pinned host memory
+        FrameHeader z = {}; *hdr_next = z;                      // next frame's cursor/counters
+        TickHeader tz = {}; *th = tz;
+    }
+}
+
+// K2 (small): the whole pack in ONE workgroup when the visible set is small (the common case at the
+// reference's draw distance: ~10^3 instances).  Replaces k_cull_shared + k_emit_count + k_group_scan
+// + k_emit_scatter + every result copy: at these sizes each launch boundary costs more than the work.
+// An LDS atomic per instance yields both the group histogram and the instance's rank inside its group.
+__global__ __launch_bounds__(PACK_SMALL_THREADS) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, ItemSink K,
+                                                                  const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
+                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap,
+                                                                  uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
+                                                                  InstanceRange *ranges, SharedArrays S, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                                                  const Aabb *__restrict__ cell_tight, FrameParams P) {
+    extern __shared__ uint32_t s_hist[];                        // [nslots] counts, then group begins
+    __shared__ uint32_t s_wsum[16], s_wcnt[16], s_carry, s_gcarry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    // shared world sections first (they append instances through the same cursor)
+    for (uint32_t s0 = 0; s0 < S.n; s0 += PACK_SMALL_THREADS) cull_shared_section(s0 + tid, S, cell_stamp, cell_flags, cell_tight, K, hdr, P);
+    for (uint32_t i = tid; i < nslots; i += PACK_SMALL_THREADS) s_hist[i] = 0;
+    if (tid == 0) { s_carry = 0; s_gcarry = 0; }
+    __threadfence();
+    __syncthreads();
+    unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&hdr->cursor), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t nsec = (uint32_t)cur, T = (uint32_t)(cur >> 32);
+    const bool overflow = T > PACK_SMALL_ITEMS || T > K.item_cap || nslots > LDS_HIST_SLOTS;
+    uint32_t my_row[PACK_SMALL_PER_THREAD], my_slot[PACK_SMALL_PER_THREAD], my_rank[PACK_SMALL_PER_THREAD];
+    if (!overflow) {
+#pragma unroll
+        for (uint32_t k = 0; k < PACK_SMALL_PER_THREAD; k++) {
+            uint32_t t = k * PACK_SMALL_THREADS + tid;
+            my_slot[k] = 0xFFFFFFFFu; my_row[k] = 0; my_rank[k] = 0;
+            if (t < T) {
+                // items appended by this workgroup's own shared-section pass are read back at agent scope
+                uint32_t slot = __hip_atomic_load(&K.item_slot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                my_row[k] = __hip_atomic_load(&K.item_row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                my_slot[k] = slot;
+                if (slot != 0xFFFFFFFFu) my_rank[k] = atomicAdd(&s_hist[slot], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the group counts -> InstanceRange table (render_flow.rs:964-983)
+    for (uint32_t base = 0; base < nslots && !overflow; base += PACK_SMALL_THREADS) {
+        uint32_t i = base + tid;
+        uint32_t v = i < nslots ? s_hist[i] : 0u;
+        uint32_t nz = v ? 1u : 0u;
+        uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
+        if (lane == 63) { s_wsum[wid] = incl; s_wcnt[wid] = incn; }
+        __syncthreads();
+        uint32_t woff = 0, wcn = 0;
+        for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
+        uint32_t begin = s_carry + woff + incl - v;
+        uint32_t gidx = s_gcarry + wcn + incn - nz;
+        if (i < nslots) {
+            s_hist[i] = begin;
+            if (v) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = gc_model[gc] | (lod << 25); r.render_system = gc_rs[gc]; r.sortable = gc_sort[gc]; r.begin = begin; r.count = v; ranges[gidx] = r; }
+        }
+        __syncthreads();
+        if (tid == PACK_SMALL_THREADS - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
+        __syncthreads();
+    }
+    // scatter: the instance pack (64-byte column-major matrix + entity id per instance)
+    if (!overflow) {
+#pragma unroll
+        for (uint32_t k = 0; k < PACK_SMALL_PER_THREAD; k++) {
+            if (my_slot[k] != 0xFFFFFFFFu) {
+                uint32_t pos = s_hist[my_slot[k]] + my_rank[k];
+                if (pos < out_cap) {
+                    const float4 *src = reinterpret_cast<const float4 *>(row_mat + (size_t)my_row[k] * 16);
+                    float4 *dst = reinterpret_cast<float4 *>(out_mats + (size_t)pos * 16);
+                    float4 a = src[0], b = src[1], c = src[2], d = src[3];
+                    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+                    out_ids[pos] = row_id[my_row[k]];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        HostResult r; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
+        r.overflow = overflow ? 1u : 0u; r.n_entries = nsec; r.n_items = T;
+        *hres = r;
+        FrameHeader z = {}; *hdr_next = z; TickHeader tz = {}; *th = tz;     // next frame's counters (this frame's header stays readable)
+    }
 }
 
 // K2c: scatter -- the instance pack (specify_type_ids! callback + MappedBuffer::write_data_serialized,
@@ -450,14 +537,43 @@ __device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
     float n = norm3(v[0], v[1], v[2]); o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
 }
 
+__device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+                                            float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc, RowArrays R, const uint32_t *__restrict__ row_cell,
+                                            const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                            const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb, const FrameParams &P, float dt, uint32_t tick_all,
+                                            uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap);
+
 __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                               float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
                                               RowArrays R, const uint32_t *__restrict__ row_cell,
                                               const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                               FrameParams P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, TickHeader *h_th) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, P, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap);
+    // the last workgroup to finish publishes the counters into mapped pinned host memory
+    __shared__ uint32_t s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&th->ticket, 1u) == gridDim.x - 1u);
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        TickHeader r;
+        r.n_changed = __hip_atomic_load(&th->n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.n_rebucket = __hip_atomic_load(&th->n_rebucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.n_oob = __hip_atomic_load(&th->n_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.ticket = gridDim.x;
+        *h_th = r;
+    }
+}
+
+__device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+                                            float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
+                                            RowArrays R, const uint32_t *__restrict__ row_cell,
+                                            const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                            const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
+                                            const FrameParams &P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
+                                            TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
     if (j >= ndyn) return;
     uint32_t r = dyn_row[j];
     uint32_t fl = R.flags[r];

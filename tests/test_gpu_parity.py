@@ -35,10 +35,10 @@ def check_sections(p, w):
     np.testing.assert_array_equal(s["tight"], tight)
 
 
-def check_frame(R, p, w, cam, dups):
+def check_frame(R, p, w, cam, dups, force_large_pack=False):
     oc = oracle_camera(cam)
     vis_o = w.cull(oc)
-    g = p.cull_and_pack(cam, emit_duplicates=dups)
+    g = p.cull_and_pack(cam, emit_duplicates=dups, force_large_pack=force_large_pack)
     keys, mult = p.visible_sections()
     np.testing.assert_array_equal(expand_vis(keys, mult), vis_o)
     assert g["n_visible_vec"] == len(vis_o) and g["n_visible_sections"] == len(np.unique(vis_o))
@@ -151,6 +151,44 @@ def test_kinematics_one_tick_all_branches(R):
     assert t["n_changed"] == n_o and n_o > 50
     assert t["n_out_of_bounds"] == len(oob_o)
     check_entities(R, p, w, ents)
+    p.close(); w.close()
+
+
+def test_pack_paths_agree(R):
+    """single-workgroup pack, multi-kernel pack, and the overflow hand-over between them"""
+    ents = R.synthetic.mixed_world(6000, seed=7, spread=700.0)
+    p, w = build_pair(R, ents)
+    cam_small = R.Camera((8192, 8192, 9300), (0, 0, -1), 700.0)
+    cam_big = R.Camera((8192, 8192, 9300), (0, 0, -1), 4000.0)
+    g1, _ = check_frame(R, p, w, cam_small, False)                       # small path
+    g2, _ = check_frame(R, p, w, cam_small, False, force_large_pack=True)
+    assert g1["total"] == g2["total"] > 0
+    w.tick(oracle_camera(cam_small), 0.016); p.tick(0.016)
+    big = R.synthetic.lattice_world(cells_per_axis=48, first_cell=104)   # > 16384 visible instances: the fused pack must hand over
+    p2, w2 = build_pair(R, big)
+    g3, _ = check_frame(R, p2, w2, R.Camera((8192, 8192, 11000), (0, 0, -1), 6000.0), False)
+    assert g3["total"] > 16384
+    g4, _ = check_frame(R, p2, w2, R.Camera((8192, 8192, 11000), (0, 0, -1), 6000.0), True)   # predicted large now
+    assert g4["total"] >= g3["total"]
+    g5, _ = check_frame(R, p2, w2, R.Camera((8192, 8192, 8192), (0, 0, -1), 500.0), False)    # and back to a small set
+    for q in (p, p2):
+        q.close()
+    w.close(); w2.close()
+
+
+def test_async_frames_match_sync(R):
+    ents = R.synthetic.lattice_world(cells_per_axis=32, first_cell=112, spinner_every=5)
+    p, w = build_pair(R, ents)
+    cams = [R.Camera((8192 + 11 * i, 8192, 8350 - 9 * i), (0, 0, -1), 1000.0) for i in range(6)]
+    for cam in cams:                                                     # async: enqueue everything, wait once
+        p.cull_and_pack(cam, asynchronous=True)
+        p.tick(0.016, asynchronous=True)
+        oc = oracle_camera(cam); w.cull(oc); o = w.render(oc); n_o, _ = w.tick(oc, 0.016)
+    vis, tick = p.wait(copy=True)
+    assert_render_equal(vis, o)
+    assert tick["n_changed"] == n_o
+    spin = ents[(ents["flags"] & R.F_HAS_ROTVEL) != 0]
+    check_entities(R, p, w, spin[:200])
     p.close(); w.close()
 
 
