@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--axis", type=int, default=PER_GPU_AXIS, help="sections per axis per GPU (216 -> 10,077,696 entities)")
     ap.add_argument("--spinner-every", type=int, default=0, help="0 = configs[1] (all static); 100 = configs[2] (100k rotating bodies)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-large-pack", action="store_true", help="always use the multi-kernel pack")
     ap.add_argument("--cpu-sample-axis", type=int, default=100)
     return ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
             gather.exchange(vis["n_written"])
             p.tick(0.016, asynchronous=not sync_each)
         else:
-            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False)
+            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False, force_large_pack=a.force_large_pack)
             p.tick(0.016, asynchronous=not sync_each)
 
     def fence():
@@ -136,7 +137,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        # roofline of the dominant kernel (k_cull_sections): algorithmic bytes per launch, see DESIGN.md
+        # roofline of the dominant kernel (k_scan_keys): algorithmic bytes per launch, see DESIGN.md
         C_sections = stats["n_sections"]
         n_entries = vis["n_visible_sections"]
         alg_bytes = 8 * C_sections + 41 * n_cand + 20 * n_entries
@@ -162,7 +163,7 @@ def main():
                        "sharding": "none" if world == 1 else "contiguous section-key ranges, RCCL all-gather of packed visible buffers"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_cull_sections", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "k_scan_keys", "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us))},
             "frame_latency_ms_sync": float(np.median(lat) * 1e3),
             "kernel_us_last_frame": tm, "setup_s": t_setup,

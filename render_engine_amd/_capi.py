@@ -65,7 +65,7 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    return os.environ.get("RE_HIP_LIBRARY", _build.LIB_PATH)     # override only for A/B experiments with alternative builds
 
 
 def load():

@@ -66,7 +66,7 @@ struct re_ctx {
         *row = p->second; return true;
     }
     // sections
-    uint32_t ncells = 0, nsh = 0, nrows_csr = 0;
+    uint32_t ncells = 0, nsh = 0, nrows_csr = 0, n_real_sections = 0;   // ncells counts padding slots too
     DevBuf<uint64_t> d_cell_key; DevBuf<Aabb> d_cell_tight; DevBuf<uint32_t> d_cell_begin, d_cell_nlocal, d_cell_nstatic, d_cell_stamp, d_rows;
     DevBuf<uint8_t> d_cell_flags;
     DevBuf<int32_t> d_sh_cells, d_sh_owner; DevBuf<Aabb> d_sh_aabb; DevBuf<uint32_t> d_sh_begin, d_sh_nact, d_sh_nstat; DevBuf<uint8_t> d_sh_cached, d_sh_dirty;
@@ -77,7 +77,8 @@ struct re_ctx {
     DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
     // frame
     uint32_t frame = 0; bool have_cull = false;
-    FrameParams P{};
+    FrameParams P{}; PBoxTable PB{}; DevBuf<FrameParams> d_params;
+    DevBuf<uint32_t> d_wave_count, d_cand; uint32_t nlists = 0, pred_candidates = 0;
     uint32_t item_cap = 0, out_cap = 0, list_cap = 0;
     DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
     uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0;
@@ -113,7 +114,7 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) {
     re_ctx *c = new re_ctx();
     c->cfg = *cfg; c->device = cfg->device;
     c->maxlevel = max_level(cfg->outline_length, cfg->atomic_length);
-    if (c->maxlevel > (uint32_t)MAX_LEVELS) { g_create_error = "re_create: outline/atomic gives more than 16 levels"; delete c; return RE_E_ARG; }
+    if (c->maxlevel > (uint32_t)MAX_LEVELS || cfg->outline_length / cfg->atomic_length > 32768u) { g_create_error = "re_create: outline/atomic must give at most 16 levels and 32768 sections per axis"; delete c; return RE_E_ARG; }
     if ((e = hipSetDevice(c->device)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         g_create_error = std::string("re_create: ") + hipGetErrorString(e); delete c; return RE_E_HIP;
     }
@@ -132,7 +133,7 @@ static void free_world(re_ctx *c) {
     c->d_sh_begin.release(a); c->d_sh_nact.release(a); c->d_sh_nstat.release(a); c->d_sh_cached.release(a); c->d_sh_dirty.release(a);
     c->d_gc_model.release(a); c->d_gc_rs.release(a); c->d_gc_sort.release(a); c->d_group_count.release(a); c->d_group_begin.release(a); c->d_group_fill.release(a);
     c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
-    c->d_hdr.release(a); c->d_th.release(a); c->d_movers.release(a); c->d_oob.release(a);
+    c->d_hdr.release(a); c->d_th.release(a); c->d_wave_count.release(a); c->d_cand.release(a); c->d_params.release(a); c->d_movers.release(a); c->d_oob.release(a);
     if (c->h_res) { (void)hipHostFree(c->h_res); c->h_res = nullptr; }
     if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
     if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
@@ -196,6 +197,20 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         std::set_union(keys.begin(), keys.end(), lk.begin(), lk.end(), std::back_inserter(merged));
         keys.swap(merged);
     }
+    // pad every level run to whole wave chunks of k_cull_sections (so the level is uniform inside a wave); a pad slot
+    // carries the largest key of its level (x = z = y = 0xFFFF: never a world section, outline/atomic <= 32768)
+    c->n_real_sections = (uint32_t)keys.size();
+    {
+        std::vector<uint64_t> padded; padded.reserve(keys.size() + MAX_LEVELS * WAVE_KEYS);
+        size_t i = 0;
+        while (i < keys.size()) {
+            uint32_t lv = key_level(keys[i]);
+            while (i < keys.size() && key_level(keys[i]) == lv) padded.push_back(keys[i++]);
+            while (padded.size() % WAVE_KEYS) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
+        }
+        keys.swap(padded);
+    }
+    auto is_pad = [](uint64_t k) { return (k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull; };
     const uint32_t ncells = (uint32_t)keys.size();
     std::vector<uint32_t> begin(ncells + 1, 0), nlocal(ncells, 0), nstatic(ncells, 0), rows; rows.reserve(n);
     std::vector<uint32_t> row_cell(n, ROW_CELL_NONE);
@@ -234,7 +249,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
             if (it == cell_link_idx.end()) st = true;
             else for (uint32_t s : cell_links[it->second]) if (sh_nact[s] == 0) st = true;
         }
-        cflags[ci] = (st ? CF_STATIC_SECTION : 0) | CF_STATIC_DIRTY;
+        cflags[ci] = is_pad(keys[ci]) ? (uint8_t)(CF_PAD | CF_STATIC_SECTION) : (uint8_t)((st ? CF_STATIC_SECTION : 0) | CF_STATIC_DIRTY);
     }
     for (uint32_t s = 0; s < nsh; s++)
         for (uint32_t k = 0; k < shids[s].nk; k++) {
@@ -279,6 +294,10 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
                                    c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, too_many);
     if (nsh) hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->nlists = std::max(1u, (((ncells + 1u) >> 1) + 64u * CULL_ITERS - 1u) / (64u * CULL_ITERS));
+    HIPCHK(c, c->d_wave_count.alloc(c->nlists, acct)); HIPCHK(c, c->d_cand.alloc((size_t)c->nlists * WAVE_KEYS, acct));
+    HIPCHK(c, hipMemsetAsync(c->d_wave_count.p, 0, (size_t)c->nlists * 4, st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->dirty_pending = true; c->have_cull = false;
     return RE_OK;
@@ -402,7 +421,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->list_cap = std::max(c->ndyn, 1u);
     HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
-    HIPCHK(c, c->d_hdr.alloc(2, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
+    HIPCHK(c, c->d_hdr.alloc(2, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_res), sizeof(HostResult), hipHostMallocMapped));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocMapped));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_th), sizeof(TickHeader), hipHostMallocMapped));
@@ -434,6 +453,19 @@ static void fill_level_boxes(LevelBox *out, uint32_t maxlevel, float wsl, float 
     }
 }
 
+static void fill_packed_boxes(PBox *out, const LevelBox *in, uint32_t maxlevel) {
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
+        const LevelBox &b = in[l]; PBox p;
+        bool ok = l < maxlevel && b.nx && b.ny && b.nz;
+        auto m1 = [](uint32_t n) { return (n > 65536u ? 65536u : n) - 1u; };
+        p.sub_hi = ((ok ? l : (l ^ 0x8000u)) << 16) | (b.bx & 0xFFFFu);          // an empty box gets an unmatchable level field
+        p.sub_lo = ((b.bz & 0xFFFFu) << 16) | (b.by & 0xFFFFu);
+        p.min_hi = ok ? m1(b.nx) : 0u;                                           // level difference must be 0
+        p.min_lo = ok ? ((m1(b.nz) << 16) | m1(b.ny)) : 0u;
+        out[l] = p;
+    }
+}
+
 static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     FrameParams &P = c->P;
     make_planes(cam->projection_view, P.planes);
@@ -450,6 +482,7 @@ static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     float half = cam->far_draw / 2.0f;                                          // find_visible_world_ids_frustum_aabb
     float cx = cam->direction[0] * half + cam->position[0], cy = cam->direction[1] * half + cam->position[1], cz = cam->direction[2] * half + cam->position[2];
     fill_level_boxes(P.box[1], c->maxlevel, wsl, rmax(cx - half, 0.0f), cx + half, rmax(cy - half, 0.0f), cy + half, rmax(cz - half, 0.0f), cz + half);
+    fill_packed_boxes(c->PB.box[0], P.box[0], c->maxlevel); fill_packed_boxes(c->PB.box[1], P.box[1], c->maxlevel);
 }
 
 static void fill_visible(re_ctx *c, re_visible *out) {
@@ -505,7 +538,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
         c->t_cull *= 1000.f; c->t_pack *= 1000.f;
     }
-    c->pred_total = c->h_res->total;
+    c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
     if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
     fill_visible(c, out);
     return RE_OK;
@@ -517,7 +550,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     if (!c->h_res) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    if (c->cull_inflight && c->h_res->overflow == 0) c->pred_total = std::max(c->pred_total, c->h_res->total);   // hint from an earlier async frame, if it has landed
+    if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
     const FrameParams &P = c->P;
@@ -531,21 +564,25 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     }
     hipEvent_t k1a = nullptr, k1b = nullptr;
     if (c->k1_timing && c->k1_used + 2 <= c->k1_events.size()) { k1a = c->k1_events[c->k1_used]; k1b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
-    // hipExtLaunchKernelGGL ties the two events to this dispatch's own begin/end timestamps
-    if (c->ncells) hipExtLaunchKernelGGL(k_cull_sections, dim3((c->ncells + CULL_CHUNK - 1) / CULL_CHUNK), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, c->d_cell_key.p, c->ncells,
-                                         c->d_cell_tight.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p, item_sink(c), hdr, P);
-    if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
-    if (small) {
-        hipLaunchKernelGGL(k_pack_small, dim3(1), dim3(PACK_SMALL_THREADS), (size_t)std::max(c->nslots, 1u) * 4, st, hdr, hdr_next, c->d_th.p, c->d_hres, item_sink(c),
-                           c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p, c->d_hranges,
-                           shared_arrays(c), c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p, P);
-        HIPCHK(c, hipGetLastError());
-    } else {
-        if (c->nsh) hipLaunchKernelGGL(k_cull_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, shared_arrays(c), c->d_cell_stamp.p, c->d_cell_flags.p, c->d_cell_tight.p,
-                                       item_sink(c), hdr, P);
+    PackArgs A{}; A.do_pack = small ? 1u : 0u; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
+    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.do_shared = c->nsh ? 1u : 0u;
+    // K1a: the streaming key scan (the dominant kernel).  hipExtLaunchKernelGGL ties the two events to this
+    // dispatch's own begin/end timestamps.
+    uint32_t scan_grid = (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64);
+    hipExtLaunchKernelGGL(k_scan_keys, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, c->d_cell_key.p, c->ncells, c->PB, c->d_wave_count.p, c->d_cand.p, P, c->d_params.p);
+    // K1b: one wave per 64 candidate lists when few sections are candidates (the usual case), one wave per list otherwise
+    uint32_t lpw = c->pred_candidates <= 65536u ? 64u : 1u;
+    uint32_t cull_waves = (c->nlists + lpw - 1) / lpw;
+    uint32_t cull_grid = std::max(1u, (cull_waves + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
+    hipLaunchKernelGGL(k_cull_sections, dim3(cull_grid), dim3(CULL_THREADS), small ? (size_t)std::max(c->nslots, 1u) * 4 : 0, st, c->d_cell_key.p, c->ncells,
+                       c->d_wave_count.p, c->d_cand.p, c->d_cell_tight.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p,
+                       item_sink(c), hdr, hdr_next, c->d_th.p, A, shared_arrays(c), c->d_params.p, lpw);
+    HIPCHK(c, hipGetLastError());
+    if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
+    if (!small) {
         int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;
     }
@@ -577,7 +614,7 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
     if (c->ndyn) {
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
         hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
-                           row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->P, dt,
+                           row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
                            (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_hth);
         c->th_clean = false;
     }
@@ -667,7 +704,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->ncells; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes;
     return RE_OK;
 }
 
@@ -675,16 +712,23 @@ extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *key
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint32_t m = std::min(capacity, c->ncells);
-    if (n) *n = c->ncells;
-    if (!m) return RE_OK;
-    if (keys) memcpy(keys, c->h_cell_key.data(), (size_t)m * 8);
-    if (tight) HIPCHK(c, hipMemcpy(tight, c->d_cell_tight.p, (size_t)m * 24, hipMemcpyDeviceToHost));
-    if (n_local) HIPCHK(c, hipMemcpy(n_local, c->d_cell_nlocal.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-    if (n_static) HIPCHK(c, hipMemcpy(n_static, c->d_cell_nstatic.p, (size_t)m * 4, hipMemcpyDeviceToHost));
-    if (is_static_section) {
-        std::vector<uint8_t> f(m); HIPCHK(c, hipMemcpy(f.data(), c->d_cell_flags.p, m, hipMemcpyDeviceToHost));
-        for (uint32_t i = 0; i < m; i++) is_static_section[i] = f[i] & CF_STATIC_SECTION;
+    if (n) *n = c->n_real_sections;
+    const uint32_t m = c->ncells;
+    if (!m || !capacity) return RE_OK;
+    std::vector<Aabb> t(m); std::vector<uint32_t> nl(m), ns(m); std::vector<uint8_t> f(m);
+    HIPCHK(c, hipMemcpy(t.data(), c->d_cell_tight.p, (size_t)m * 24, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(nl.data(), c->d_cell_nlocal.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ns.data(), c->d_cell_nstatic.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(f.data(), c->d_cell_flags.p, m, hipMemcpyDeviceToHost));
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < m && o < capacity; i++) {
+        if (f[i] & CF_PAD) continue;                               // padding slots are not world sections
+        if (keys) keys[o] = c->h_cell_key[i];
+        if (tight) memcpy(tight + (size_t)o * 6, &t[i], 24);
+        if (n_local) n_local[o] = nl[i];
+        if (n_static) n_static[o] = ns[i];
+        if (is_static_section) is_static_section[o] = f[i] & CF_STATIC_SECTION;
+        o++;
     }
     return RE_OK;
 }
@@ -738,6 +782,25 @@ extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32
     c->k1_timing = false; c->k1_used = 0;
     return RE_OK;
 }
+// development aid: launches the key-scan kernel alone, back to back, and returns the per-launch device times
+extern "C" int re_debug_bench_cull(re_ctx *c, uint32_t reps, float *us) {
+    if (!c || !c->have_cull || !us) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipStreamSynchronize(st));
+    hipEvent_t a, b; HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
+    uint32_t scan_grid = (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64);
+    for (uint32_t i = 0; i < reps; i++) {
+        hipExtLaunchKernelGGL(k_scan_keys, dim3(scan_grid), dim3(CULL_THREADS), 0, st, a, b, 0, c->d_cell_key.p, c->ncells, c->PB, c->d_wave_count.p, c->d_cand.p, c->P, c->d_params.p);
+        HIPCHK(c, hipStreamSynchronize(st));
+        float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, a, b)); us[i] = ms * 1000.f;
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return RE_OK;
+}
+
+extern "C" int re_debug_get_stamps(re_ctx *c, unsigned long long *out8) { if (!c || !c->h_res || !out8) return RE_E_ARG; memcpy(out8, c->h_res->stamps, 64); return RE_OK; }
+
 extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {
     if (!c || !c->h_res || !n_candidates) return RE_E_ARG;
     *n_candidates = c->h_res->n_candidates; return RE_OK;

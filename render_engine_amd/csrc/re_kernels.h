@@ -15,13 +15,15 @@ constexpr uint32_t F_STATIC = 0x001, F_HAS_VEL = 0x002, F_HAS_ACC = 0x004, F_HAS
 constexpr uint8_t CF_STATIC_SECTION = 1;   // member of static_world_sections (bounding_box_tree_v2.rs:1133-1213)
 constexpr uint8_t CF_STATIC_CACHED = 2;    // its static entities are in the render cache (render_flow.rs:549-594)
 constexpr uint8_t CF_STATIC_DIRTY = 4;     // member of changed_static_unique_sections
+constexpr uint8_t CF_PAD = 8;              // padding slot that aligns a level run to a wave chunk (not a world section)
 
 constexpr uint32_t ROW_CELL_NONE = 0xFFFFFFFFu, ROW_CELL_SHARED = 0x80000000u;
 constexpr int MAX_LEVELS = 16;
 constexpr int CULL_THREADS = 256;
-constexpr int CULL_ITERS = 8;               // 16-byte key loads in flight per lane
+constexpr int CULL_ITERS = 4;               // 16-byte key loads in flight per lane
 constexpr int CULL_CHUNK = CULL_THREADS * CULL_ITERS * 2;   // 4096 sections per workgroup of k_cull_sections (LDS queue of 16 KiB)
-constexpr uint32_t LDS_HIST_SLOTS = 4096;  // group slots (gclass*8+lod) that fit the LDS histograms
+constexpr uint32_t LDS_HIST_SLOTS = 4096;   // must stay < 2^15 (slot<<16|rank packing)
+constexpr uint32_t LDS_HIST_SLOTS_UNUSED = 0;  // group slots (gclass*8+lod) that fit the LDS histograms
 
 struct RowArrays {                          // one row per entity, in upload order
     uint32_t *id, *gclass, *flags;
@@ -32,6 +34,11 @@ struct RowArrays {                          // one row per entity, in upload ord
 struct SharedRec { uint32_t row, nk; uint64_t keys[8]; };
 
 struct LevelBox { uint32_t bx, by, bz, nx, ny, nz; float level_length; uint32_t pad; };
+// the same box packed for 16-bit SIMD-within-a-register tests on the key halves (hi = level:16|x:16, lo = z:16|y:16):
+// inside  <=>  pk_min_u16(pk_sub_u16(word, sub), min) == pk_sub_u16(word, sub) for both words
+struct PBox { uint32_t sub_hi, sub_lo, min_hi, min_lo; };
+struct PBoxTable { PBox box[2][16]; };
+constexpr uint32_t WAVE_KEYS = 64u * 4u * 2u;   // keys one wave of k_cull_sections owns (64 lanes x CULL_ITERS x 2); level runs are padded to it
 
 struct FrameParams {
     float planes[24];
@@ -41,19 +48,21 @@ struct FrameParams {
     uint32_t max_level, frame, emit_duplicates, pad;
     LevelBox box[2][MAX_LEVELS];            // [0] logic box, [1] render box, per level
 };
+constexpr uint32_t TICKET_SHARDS = 64;
 struct FrameHeader {
     unsigned long long cursor;              // low 32: entries, high 32: instances
     uint32_t n_vis_map, n_vis_vec, n_groups, total;
-    uint32_t n_candidates, pad0;            // sections inside a candidate box (== hash probes of the reference)
+    uint32_t n_candidates, ticket;          // sections inside a candidate box (== hash probes of the reference); completed ticket shards
+    uint32_t pad1[8];
+    uint32_t shard[TICKET_SHARDS * 16];     // finished-workgroup counters, one per 64-byte line (a single word saturates near 88 atomics/us)
 };
 struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; };
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
+    unsigned long long stamps[8];           // development builds (-DRE_EXP_STAMPS): 100 MHz wall-clock stamps of the pack phases
 };
-constexpr uint32_t PACK_SMALL_THREADS = 1024;
-constexpr uint32_t PACK_SMALL_PER_THREAD = 16;
-constexpr uint32_t PACK_SMALL_ITEMS = PACK_SMALL_THREADS * PACK_SMALL_PER_THREAD;   // 16384 instances in one workgroup
+constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances the last workgroup of k_cull_sections packs itself (rank fits 14 bits)
 struct SharedArrays {                       // shared world sections (bounding_box_tree_v2.rs:113-155, 253-316)
     uint32_t n;
     const int32_t *cells; const Aabb *aabb; const uint32_t *begin, *nact, *nstat; const int32_t *owner; const uint8_t *cached;
@@ -69,20 +78,23 @@ __global__ void k_static_cache_cells(uint32_t ncells, const Aabb *cell_tight, ui
 __global__ void k_clear_static_dirty(uint32_t ncells, uint8_t *cell_flags, uint32_t nsh, uint8_t *sh_dirty);
 __global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty, int32_t *sh_owner, uint8_t *sh_cached, FrameParams P);
 struct ItemSink { uint32_t *item_row, *item_slot; uint32_t item_cap; const uint32_t *rows, *row_gclass; };
-__global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const Aabb *cell_tight, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
-                                const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, ItemSink K, FrameHeader *hdr, FrameParams P);
-__global__ void k_cull_shared(SharedArrays S, const uint32_t *cell_stamp, const uint8_t *cell_flags, const Aabb *cell_tight, ItemSink K, FrameHeader *hdr, FrameParams P);
+struct PackArgs {                           // what the fused small pack needs besides the item list
+    uint32_t do_pack, nslots, out_cap, do_shared;
+    const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
+    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres;
+};
+__global__ void k_scan_keys(const uint64_t *cell_key, uint32_t ncells, PBoxTable B, uint32_t *wave_count, uint32_t *cand, FrameParams Pfull, FrameParams *P_dev);
+__global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const uint32_t *wave_count, const uint32_t *cand, const Aabb *cell_tight, const uint32_t *cell_begin,
+                                const uint32_t *cell_nlocal, const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, ItemSink K, FrameHeader *hdr,
+                                FrameHeader *hdr_next, TickHeader *th, PackArgs A, SharedArrays S, const FrameParams *P, uint32_t lists_per_wave);
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t item_cap, uint32_t *group_count, uint32_t nslots);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres);
-__global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, ItemSink K, const uint32_t *row_id, const float *row_mat,
-                             uint32_t *out_ids, float *out_mats, uint32_t out_cap, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs, const uint32_t *gc_sort,
-                             InstanceRange *ranges, SharedArrays S, const uint32_t *cell_stamp, const uint8_t *cell_flags, const Aabb *cell_tight, FrameParams P);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
-                       const Aabb *sh_aabb, FrameParams P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
+                       const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th);
 __global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
 

@@ -182,147 +182,222 @@ __device__ __forceinline__ void emit_sections(uint32_t rb, uint32_t cnt, uint32_
 // The reference enumerates every candidate id of a camera-centred box per level and probes a hash
 // map.  Here the occupied sections are one key-sorted array: a section is a candidate iff its own
 // index lies inside the box of its level, so the query is ONE streaming pass over the 8-byte keys
-// (the only per-section bytes read for non-candidates).  Phase 1: each workgroup scans a
-// contiguous chunk of keys (2 keys = 16 B per lane per load) and compacts candidates into an LDS
-// queue with wave ballots.  Phase 2: dense lanes run the predicates on the queued candidates and
-// append {row range, count, running instance offset, LOD} entries with one 64-bit atomic per wave.
-// Per-level box tables live in LDS (levels are not wave-uniform at level boundaries).
+// (the only per-section bytes read for non-candidates).
+//
+// Two launches: k_scan_keys (K1a, the HBM-bound stream over all keys) and k_cull_sections (K1b, the
+// exact predicates on the few candidates).  Keeping K1a free of everything phase 2 needs (1.7 KB of frame
+// parameters, a dozen pointers, ~50 VGPRs) is worth more than the launch boundary: its waves start
+// loading keys after one scalar load instead of six.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *__restrict__ cell_key, uint32_t ncells,
-                                                                const Aabb *__restrict__ cell_tight, const uint32_t *__restrict__ cell_begin,
-                                                                const uint32_t *__restrict__ cell_nlocal, const uint32_t *__restrict__ cell_nstatic,
-                                                                const uint8_t *__restrict__ cell_flags, uint32_t *__restrict__ cell_stamp,
-                                                                ItemSink K, FrameHeader *hdr, FrameParams P) {
-    __shared__ LevelBox s_box[2][MAX_LEVELS];
-    __shared__ uint32_t s_queue[CULL_CHUNK];
-    __shared__ uint32_t s_qn;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t i = tid; i < 2 * MAX_LEVELS; i += CULL_THREADS) s_box[i / MAX_LEVELS][i % MAX_LEVELS] = P.box[i / MAX_LEVELS][i % MAX_LEVELS];
-    if (tid == 0) s_qn = 0;
-    __syncthreads();
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) { u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b); return __builtin_bit_cast(uint32_t, r); }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)); return __builtin_bit_cast(uint32_t, r); }
+__device__ __forceinline__ bool pk_in_box(uint32_t hi, uint32_t lo, const PBox &b) {
+    uint32_t dh = pk_sub_u16(hi, b.sub_hi), dl = pk_sub_u16(lo, b.sub_lo);
+    return (pk_min_u16(dh, b.min_hi) == dh) && (pk_min_u16(dl, b.min_lo) == dl);
+}
+__device__ __forceinline__ bool in_box(uint32_t x, uint32_t y, uint32_t z, const LevelBox &b) {
+    return ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
+}
 
-    // ---- phase 1: stream the keys of this chunk, queue candidates ----
-    // All CULL_ITERS 16-byte loads of a lane are issued back to back (independent addresses) before
-    // the first key is examined: 8 x 16 B in flight per lane is what hides the HBM latency.
-    const uint32_t chunk_pair0 = blockIdx.x * (CULL_CHUNK / 2);
+// Visibility of one world section from its key alone: 0 = not visible, 1 = in one of the two query results,
+// 2 = in both (the section then appears twice in visible_sections_vec).  *candidate: inside a candidate box.
+__device__ __forceinline__ uint32_t section_multiplicity(uint64_t key, const FrameParams &P, bool *candidate) {
+    uint32_t lv = key_level(key);
+    if (lv >= P.max_level) { if (candidate) *candidate = false; return 0u; }
+    uint32_t x = key_x(key), y = key_y(key), z = key_z(key);
+    LevelBox a = P.box[0][lv], b = P.box[1][lv];
+    bool inl = in_box(x, y, z, a), inr = in_box(x, y, z, b);
+    if (candidate) *candidate = inl | inr;
+    // candidate AABB as visible_world_flow.rs:73-82: base = (base_unique + i) as f32 * level_length
+    float ll = a.level_length;
+    bool visl = false, visr = false;
+    if (inl) {
+        float fx = (float)(a.bx + ((x - a.bx) & 0xFFFFu)) * ll, fy = (float)(a.by + ((y - a.by) & 0xFFFFu)) * ll, fz = (float)(a.bz + ((z - a.bz) & 0xFFFFu)) * ll;
+        Aabb g = { fx, fx + ll, fy, fy + ll, fz, fz + ll };
+        visl = logic_aabb_in_view(P.lookahead, P.cam[0], P.cam[1], P.cam[2], g);
+    }
+    if (inr) {
+        float fx = (float)(b.bx + ((x - b.bx) & 0xFFFFu)) * ll, fy = (float)(b.by + ((y - b.by) & 0xFFFFu)) * ll, fz = (float)(b.bz + ((z - b.bz) & 0xFFFFu)) * ll;
+        Aabb g = { fx, fx + ll, fy, fy + ll, fz, fz + ll };
+        visr = frustum_aabb_visible(P.planes, g);
+    }
+    return (visl && visr) ? 2u : ((visl || visr) ? 1u : 0u);
+}
+
+__device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_hist, uint32_t *s_tmp);
+__device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
+                                                    const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P);
+
+// K1a: the streaming pass.  Lean on purpose (two pointers + 512 B of packed boxes): every wave issues its
+// CULL_ITERS x 16-byte key loads immediately, runs the packed 16-bit box tests (~12 VALU per key) against
+// the two boxes of its level held in SGPRs, and writes its candidate list (section indices) and the list
+// length to HBM.  No atomics, no LDS, no barrier.  Level runs are padded to whole wave chunks on the host,
+// so the level of the first key is the level of every real key of the wave; keys of any other level fail
+// the packed test by themselves.
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_keys(const uint64_t *__restrict__ cell_key, uint32_t ncells, PBoxTable B,
+                                                            uint32_t *__restrict__ wave_count, uint32_t *__restrict__ cand, FrameParams Pfull, FrameParams *P_dev) {
+    if (blockIdx.x == gridDim.x - 1u) {
+        // the last workgroup (it owns the short tail of the key array) stages the frame parameters from kernarg memory
+        // (host-resident) into device memory, where K1b and the tick read them at L2 latency
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&Pfull); uint32_t *dst = reinterpret_cast<uint32_t *>(P_dev);
+        for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
+    }
+    const uint32_t lane = lane_id(), wave = blockIdx.x * (CULL_THREADS / 64) + (threadIdx.x >> 6);
     const uint32_t npairs = (ncells + 1u) >> 1;                              // key array is padded to an even count with never-candidate keys
+    const uint32_t wave_pair0 = wave * (64u * CULL_ITERS);
+    if (wave_pair0 >= npairs) return;                                       // wave-uniform
     const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);
     ulonglong2 kk[CULL_ITERS];
 #pragma unroll
     for (uint32_t it = 0; it < CULL_ITERS; it++) {
-        uint32_t pair = chunk_pair0 + it * CULL_THREADS + tid;
+        uint32_t pair = wave_pair0 + it * 64u + lane;
         kk[it] = kp[pair < npairs ? pair : npairs - 1u];
     }
-    uint32_t cmask = 0;
+    const uint32_t lv0 = __builtin_amdgcn_readfirstlane(key_level(kk[0].x)) & (MAX_LEVELS - 1);
+    const PBox a0 = B.box[0][lv0], b0 = B.box[1][lv0];                       // uniform index: scalar loads into SGPRs
+    uint64_t m[CULL_ITERS * 2]; uint64_t any = 0;
 #pragma unroll
     for (uint32_t it = 0; it < CULL_ITERS; it++) {
-        uint32_t pair = chunk_pair0 + it * CULL_THREADS + tid;
-        if (pair < npairs) {
+        const bool valid = (wave_pair0 + it * 64u + lane) < npairs;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                uint64_t key = h ? kk[it].y : kk[it].x;
-                uint32_t lv = key_level(key);
-                if (lv < P.max_level) {
-                    LevelBox a = s_box[0][lv], b = s_box[1][lv];
-                    uint32_t x = key_x(key), y = key_y(key), z = key_z(key);
-                    bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
-                    bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
-                    if (inl | inr) cmask |= 1u << (it * 2 + h);
-                }
-            }
+        for (int h = 0; h < 2; h++) {
+            uint64_t key = h ? kk[it].y : kk[it].x;
+            uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+            bool c = valid && (pk_in_box(hi, lo, a0) || pk_in_box(hi, lo, b0));
+            m[it * 2 + h] = __ballot(c); any |= m[it * 2 + h];
         }
     }
-    {   // one LDS atomic per wave reserves queue space for all of its candidates
-        uint32_t cnt = __popc(cmask);
-        if (__ballot(cnt != 0)) {                                           // wave-uniform
-            uint32_t incl = wave_incl_scan(cnt);
-            uint32_t tot = __shfl(incl, 63, 64);
-            uint32_t base = 0;
-            if (lane_id() == 0) base = atomicAdd(&s_qn, tot);
-            base = __shfl(base, 0, 64) + incl - cnt;
-            while (cmask) {
-                uint32_t bit = __ffs(cmask) - 1u; cmask &= cmask - 1u;
-                s_queue[base++] = (chunk_pair0 + (bit >> 1) * CULL_THREADS + tid) * 2u + (bit & 1u);
-            }
+    uint32_t qn = 0;
+    if (any) {                                                              // wave-uniform (scalar) branch
+        uint32_t *q = cand + (size_t)wave * WAVE_KEYS;
+#pragma unroll
+        for (uint32_t k = 0; k < CULL_ITERS * 2; k++) {
+            if ((m[k] >> lane) & 1ull) q[qn + mbcnt(m[k])] = (wave_pair0 + (k >> 1) * 64u + lane) * 2u + (k & 1u);
+            qn += (uint32_t)__popcll(m[k]);
         }
     }
-    __syncthreads();
-
-    // ---- phase 2: predicates on the candidates, dense lanes ----
-    const uint32_t qn = s_qn;
-    if (tid == 0 && qn) atomicAdd(&hdr->n_candidates, qn);
-    uint32_t vis_map_acc = 0, vis_vec_acc = 0;
-    for (uint32_t i0 = 0; i0 < qn; i0 += CULL_THREADS) {                     // uniform trip count per workgroup
-        uint32_t i = i0 + tid;
-        bool has = false; uint32_t rb = 0, cnt = 0, lod = 0, mult = 0;
-        if (i < qn) {
-            uint32_t c = s_queue[i];
-            uint64_t key = cell_key[c];
-            uint32_t lv = key_level(key), x = key_x(key), y = key_y(key), z = key_z(key);
-            LevelBox a = s_box[0][lv], b = s_box[1][lv];
-            bool inl = ((x - a.bx) & 0xFFFFu) < a.nx && ((y - a.by) & 0xFFFFu) < a.ny && ((z - a.bz) & 0xFFFFu) < a.nz;
-            bool inr = ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
-            // candidate AABB as visible_world_flow.rs:73-82: base = (base_unique + i) as f32 * level_length
-            float ll = a.level_length;
-            bool visl = false, visr = false;
-            if (inl) {
-                float fx = (float)(a.bx + ((x - a.bx) & 0xFFFFu)) * ll, fy = (float)(a.by + ((y - a.by) & 0xFFFFu)) * ll, fz = (float)(a.bz + ((z - a.bz) & 0xFFFFu)) * ll;
-                Aabb g = { fx, fx + ll, fy, fy + ll, fz, fz + ll };
-                visl = logic_aabb_in_view(P.lookahead, P.cam[0], P.cam[1], P.cam[2], g);
-            }
-            if (inr) {
-                float fx = (float)(b.bx + ((x - b.bx) & 0xFFFFu)) * ll, fy = (float)(b.by + ((y - b.by) & 0xFFFFu)) * ll, fz = (float)(b.bz + ((z - b.bz) & 0xFFFFu)) * ll;
-                Aabb g = { fx, fx + ll, fy, fy + ll, fz, fz + ll };
-                visr = frustum_aabb_visible(P.planes, g);
-            }
-            if (visl | visr) {
-                mult = (visl && visr) ? 2u : 1u;
-                cell_stamp[c] = (P.frame << 2) | mult;
-                vis_map_acc += 1; vis_vec_acc += mult;
-                Aabb t = cell_tight[c];
-                float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
-                uint8_t f = cell_flags[c];
-                bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
-                bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
-                uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c];
-                rb = cell_begin[c] + (act ? 0u : nl);
-                cnt = (act ? nl : 0u) + (sta ? ns : 0u);
-                lod = lod_index(d, P.n_lod, P.lod_min, P.lod_max);
-                uint32_t m = P.emit_duplicates ? mult : 1u;
-                has = cnt > 0;
-                lod |= m << 8;
-            }
-        }
-        emit_sections(rb, has ? cnt : 0u, lod, hdr, K);
-    }
-    // visible-section counters: one atomic per wave
-    for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); }
-    if (lane_id() == 0 && vis_map_acc) { atomicAdd(&hdr->n_vis_map, vis_map_acc); atomicAdd(&hdr->n_vis_vec, vis_vec_acc); }
+    if (lane == 0) wave_count[wave] = qn;
 }
 
-// K1b: shared world sections (render_flow.rs:808-866): emitted once per frame when some linking
-// unique section is visible and active; static members through the unique section that cached them.
+// K1b: exact predicates on the candidate lists of K1a, instance expansion, the shared world sections, and
+// -- with do_pack -- the instance pack in the last workgroup to finish.  lists_per_wave = 64 when few
+// sections are candidates (lane j looks at list wave + j*nwaves, interleaved so clustered non-empty
+// lists spread over the waves), 1 when the candidate set is large (one wave per list).
+__global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *__restrict__ cell_key, uint32_t ncells,
+                                                                const uint32_t *__restrict__ wave_count, const uint32_t *__restrict__ cand,
+                                                                const Aabb *__restrict__ cell_tight, const uint32_t *__restrict__ cell_begin,
+                                                                const uint32_t *__restrict__ cell_nlocal, const uint32_t *__restrict__ cell_nstatic,
+                                                                const uint8_t *__restrict__ cell_flags, uint32_t *__restrict__ cell_stamp,
+                                                                ItemSink K, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, SharedArrays S,
+                                                                const FrameParams *__restrict__ Pp, uint32_t lists_per_wave) {
+    __shared__ uint32_t s_tmp[32];
+    extern __shared__ uint32_t s_dyn[];                                     // pack histogram (only when do_pack)
+    const FrameParams &P = *Pp;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = blockIdx.x * (CULL_THREADS / 64) + (tid >> 6);
+    const uint32_t nlists = (((ncells + 1u) >> 1) + 64u * CULL_ITERS - 1u) / (64u * CULL_ITERS);
+    const uint32_t nwaves = gridDim.x * (CULL_THREADS / 64);
+    bool wrote = false;
+#ifdef RE_EXP_STAMPS
+    if (blockIdx.x == 0 && tid == 0) A.hres->stamps[6] = wall_clock64();
+#endif
+    uint32_t my_list = wave + lane * nwaves;
+    uint32_t my_count = (lane < lists_per_wave && my_list < nlists) ? wave_count[my_list] : 0u;
+    uint64_t todo = __ballot(my_count != 0);
+    uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
+        const uint32_t qn = __shfl(my_count, src, 64);
+        const uint32_t *q = cand + (size_t)__shfl(my_list, src, 64) * WAVE_KEYS;
+        for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {                         // dense lanes
+            uint32_t i = i0 + lane;
+            uint32_t rb = 0, cnt = 0, lod = 0;
+            if (i < qn) {
+                uint32_t c = q[i];
+                uint64_t key = cell_key[c];
+                uint8_t f = cell_flags[c];
+                bool is_cand = false;
+                uint32_t mult = (f & CF_PAD) ? 0u : section_multiplicity(key, P, &is_cand);
+                cand_acc += is_cand ? 1u : 0u;
+                if (mult) {
+                    cell_stamp[c] = (P.frame << 2) | mult;
+                    wrote = true;
+                    vis_map_acc += 1; vis_vec_acc += mult;
+                    Aabb t = cell_tight[c];
+                    float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
+                    bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
+                    bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
+                    uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c];
+                    rb = cell_begin[c] + (act ? 0u : nl);
+                    cnt = (act ? nl : 0u) + (sta ? ns : 0u);
+                    uint32_t m = P.emit_duplicates ? mult : 1u;
+                    lod = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8);
+                }
+            }
+            emit_sections(rb, cnt, lod, hdr, K);
+        }
+    }
+    if (__ballot(cand_acc != 0)) {                                          // per-wave counters: one atomic each
+        for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
+        if (lane == 0) {
+            if (cand_acc) atomicAdd(&hdr->n_candidates, cand_acc);
+            if (vis_map_acc) { atomicAdd(&hdr->n_vis_map, vis_map_acc); atomicAdd(&hdr->n_vis_vec, vis_vec_acc); }
+        }
+    }
+    // shared world sections: their visibility follows from the keys of the sections linking them, so any
+    // workgroup can process them concurrently with the candidate lists
+    if (A.do_shared)
+        for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < S.n; s0 += gridDim.x * CULL_THREADS) {
+            if (s0 + tid < S.n) wrote = true;
+            cull_shared_section(s0 + tid, S, cell_key, cell_flags, cell_tight, K, hdr, P);
+        }
+    if (!A.do_pack) return;
+    // ---- the last workgroup to finish packs the frame (small visible sets) ----
+    __shared__ uint32_t s_last;
+    if (__ballot(wrote)) __threadfence();                                   // release this wave's stamps / instances before the ticket
+    __syncthreads();
+    if (tid == 0) {
+        // sharded completion ticket: the workgroup that completes its shard bumps the top counter
+        uint32_t k = blockIdx.x % TICKET_SHARDS;
+        uint32_t in_shard = (gridDim.x - 1u - k) / TICKET_SHARDS + 1u;
+        uint32_t nshards = gridDim.x < TICKET_SHARDS ? gridDim.x : TICKET_SHARDS;
+        uint32_t last = 0;
+        if (atomicAdd(&hdr->shard[k * 16u], 1u) == in_shard - 1u) last = (atomicAdd(&hdr->ticket, 1u) == nshards - 1u) ? 1u : 0u;
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#ifdef RE_EXP_STAMPS
+    if (tid == 0) A.hres->stamps[7] = wall_clock64();
+#endif
+    __threadfence();                                                        // acquire: every other workgroup's writes
+    pack_small_body(hdr, hdr_next, th, A, K, s_dyn, s_tmp);
+}
+
+// Shared world sections (render_flow.rs:808-866): emitted once per frame when some linking unique
+// section is visible and active; static members through the unique section that cached them.
 // Called by whole waves (lanes with s >= S.n contribute nothing).
-__device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+__device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
                                                     const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P) {
     uint32_t rbA = 0, cntA = 0, lodA = 0, rbS = 0, cntS = 0, lodS = 0;
     if (s < S.n) {
         bool act = false;
-        for (int k = 0; k < 8; k++) {
-            int32_t c = S.cells[s * 8 + k];
-            if (c >= 0 && (cell_stamp[c] >> 2) == P.frame && !(cell_flags[c] & CF_STATIC_SECTION)) act = true;
-        }
         uint32_t na = S.nact[s], ns = S.nstat[s], b = S.begin[s];
-        if (act && na) {
+        if (na)
+            for (int k = 0; k < 8; k++) {
+                int32_t c = S.cells[s * 8 + k];
+                if (c >= 0 && !act && !(cell_flags[c] & CF_STATIC_SECTION) && section_multiplicity(cell_key[c], P, nullptr)) act = true;
+            }
+        if (act) {
             float d2 = distance_to_aabb(S.aabb[s], P.cam[0], P.cam[1], P.cam[2]);
             if (d2 < P.far_draw) { rbA = b; cntA = na; lodA = lod_index(d2, P.n_lod, P.lod_min, P.lod_max) | (1u << 8); }
         }
         int32_t ow = S.owner[s];
         if (ns && ow >= 0 && S.cached[s]) {
-            uint32_t st = cell_stamp[ow];
-            if ((st >> 2) == P.frame) {
+            uint32_t mult = section_multiplicity(cell_key[ow], P, nullptr);
+            if (mult) {
                 float d = distance_to_aabb(cell_tight[ow], P.cam[0], P.cam[1], P.cam[2]);      // extract_static_data uses the unique section's distance
-                if (!(d > P.far_draw)) { rbS = b + na; cntS = ns; uint32_t m = P.emit_duplicates ? (st & 3u) : 1u; lodS = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8); }
+                if (!(d > P.far_draw)) { rbS = b + na; cntS = ns; uint32_t m = P.emit_duplicates ? mult : 1u; lodS = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8); }
             }
         }
     }
@@ -330,10 +405,7 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
     emit_sections(rbS, cntS, lodS, hdr, K);                       // static members
 }
 
-__global__ __launch_bounds__(256) void k_cull_shared(SharedArrays S, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags, const Aabb *__restrict__ cell_tight,
-                                                     ItemSink K, FrameHeader *hdr, FrameParams P) {
-    cull_shared_section(blockIdx.x * blockDim.x + threadIdx.x, S, cell_stamp, cell_flags, cell_tight, K, hdr, P);
-}
+
 
 // ---------------------------------------------------------------------------------------------
 // K2a (large visible sets): per-group instance counts from the expanded item list.
@@ -393,51 +465,51 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         HostResult r; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
         r.overflow = 0; r.n_entries = (uint32_t)cur; r.n_items = (uint32_t)(cur >> 32);
         *hres = r;                                              // mapped pinned host memory
-        FrameHeader z = {}; *hdr_next = z;                      // next frame's cursor/counters
         TickHeader tz = {}; *th = tz;
     }
+    for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
 }
 
 // K2 (small): the whole pack in ONE workgroup when the visible set is small (the common case at the
 // reference's draw distance: ~10^3 instances).  Replaces k_cull_shared + k_emit_count + k_group_scan
 // + k_emit_scatter + every result copy: at these sizes each launch boundary costs more than the work.
-// An LDS atomic per instance yields both the group histogram and the instance's rank inside its group.
-__global__ __launch_bounds__(PACK_SMALL_THREADS) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, ItemSink K,
-                                                                  const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
-                                                                  uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap,
-                                                                  uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
-                                                                  InstanceRange *ranges, SharedArrays S, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
-                                                                  const Aabb *__restrict__ cell_tight, FrameParams P) {
-    extern __shared__ uint32_t s_hist[];                        // [nslots] counts, then group begins
-    __shared__ uint32_t s_wsum[16], s_wcnt[16], s_carry, s_gcarry;
+// Runs in the last workgroup of k_cull_sections.  An LDS atomic per instance yields both the group
+// histogram and the instance's rank inside its group.
+__device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_hist, uint32_t *s_tmp) {
+    const uint32_t NT = CULL_THREADS;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    // shared world sections first (they append instances through the same cursor)
-    for (uint32_t s0 = 0; s0 < S.n; s0 += PACK_SMALL_THREADS) cull_shared_section(s0 + tid, S, cell_stamp, cell_flags, cell_tight, K, hdr, P);
-    for (uint32_t i = tid; i < nslots; i += PACK_SMALL_THREADS) s_hist[i] = 0;
-    if (tid == 0) { s_carry = 0; s_gcarry = 0; }
-    __threadfence();
+    uint32_t *s_wsum = s_tmp, *s_wcnt = s_tmp + 8, *s_carry = s_tmp + 16, *s_gcarry = s_tmp + 17;
+#ifdef RE_EXP_STAMPS
+#define STAMP(i) do { if (tid == 0) A.hres->stamps[i] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    const uint32_t nslots = A.nslots;
+    STAMP(0);
+    for (uint32_t i = tid; i < nslots; i += NT) s_hist[i] = 0;
+    if (tid == 0) { *s_carry = 0; *s_gcarry = 0; }
     __syncthreads();
+    STAMP(1);
     unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&hdr->cursor), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t nsec = (uint32_t)cur, T = (uint32_t)(cur >> 32);
     const bool overflow = T > PACK_SMALL_ITEMS || T > K.item_cap || nslots > LDS_HIST_SLOTS;
-    uint32_t my_row[PACK_SMALL_PER_THREAD], my_slot[PACK_SMALL_PER_THREAD], my_rank[PACK_SMALL_PER_THREAD];
     if (!overflow) {
+        // ranks: 8 independent slot loads in flight per lane
+        for (uint32_t t0 = 0; t0 < T; t0 += NT * 8u) {
+            uint32_t sl[8];
 #pragma unroll
-        for (uint32_t k = 0; k < PACK_SMALL_PER_THREAD; k++) {
-            uint32_t t = k * PACK_SMALL_THREADS + tid;
-            my_slot[k] = 0xFFFFFFFFu; my_row[k] = 0; my_rank[k] = 0;
-            if (t < T) {
-                // items appended by this workgroup's own shared-section pass are read back at agent scope
-                uint32_t slot = __hip_atomic_load(&K.item_slot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                my_row[k] = __hip_atomic_load(&K.item_row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                my_slot[k] = slot;
-                if (slot != 0xFFFFFFFFu) my_rank[k] = atomicAdd(&s_hist[slot], 1u);
+            for (uint32_t u = 0; u < 8; u++) { uint32_t t = t0 + u * NT + tid; sl[u] = t < T ? __hip_atomic_load(&K.item_slot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                uint32_t t = t0 + u * NT + tid;
+                if (sl[u] != 0xFFFFFFFFu) { uint32_t rank = atomicAdd(&s_hist[sl[u]], 1u); K.item_slot[t] = (sl[u] << 16) | rank; }   // slot < 2^15, rank < 2^14
             }
         }
     }
     __syncthreads();
+    STAMP(2);
     // exclusive scan of the group counts -> InstanceRange table (render_flow.rs:964-983)
-    for (uint32_t base = 0; base < nslots && !overflow; base += PACK_SMALL_THREADS) {
+    for (uint32_t base = 0; base < nslots && !overflow; base += NT) {
         uint32_t i = base + tid;
         uint32_t v = i < nslots ? s_hist[i] : 0u;
         uint32_t nz = v ? 1u : 0u;
@@ -446,39 +518,47 @@ __global__ __launch_bounds__(PACK_SMALL_THREADS) void k_pack_small(FrameHeader *
         __syncthreads();
         uint32_t woff = 0, wcn = 0;
         for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
-        uint32_t begin = s_carry + woff + incl - v;
-        uint32_t gidx = s_gcarry + wcn + incn - nz;
+        uint32_t begin = *s_carry + woff + incl - v;
+        uint32_t gidx = *s_gcarry + wcn + incn - nz;
         if (i < nslots) {
             s_hist[i] = begin;
-            if (v) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = gc_model[gc] | (lod << 25); r.render_system = gc_rs[gc]; r.sortable = gc_sort[gc]; r.begin = begin; r.count = v; ranges[gidx] = r; }
+            if (v) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
         }
         __syncthreads();
-        if (tid == PACK_SMALL_THREADS - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
+        if (tid == NT - 1) { *s_carry = begin + v; *s_gcarry = gidx + nz; }
         __syncthreads();
     }
-    // scatter: the instance pack (64-byte column-major matrix + entity id per instance)
+    STAMP(3);
+    // scatter: the instance pack (64-byte column-major matrix + entity id per instance).  4 lanes per
+    // instance (each moves one float4, so a wave instruction covers 16 whole 64-byte rows), 8 instances in
+    // flight per lane group: a single workgroup hides latency only through its own independent loads.
     if (!overflow) {
-#pragma unroll
-        for (uint32_t k = 0; k < PACK_SMALL_PER_THREAD; k++) {
-            if (my_slot[k] != 0xFFFFFFFFu) {
-                uint32_t pos = s_hist[my_slot[k]] + my_rank[k];
-                if (pos < out_cap) {
-                    const float4 *src = reinterpret_cast<const float4 *>(row_mat + (size_t)my_row[k] * 16);
-                    float4 *dst = reinterpret_cast<float4 *>(out_mats + (size_t)pos * 16);
-                    float4 a = src[0], b = src[1], c = src[2], d = src[3];
-                    dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
-                    out_ids[pos] = row_id[my_row[k]];
-                }
-            }
+        const uint32_t part = tid & 3u, grp = tid >> 2;                     // 64 lane groups
+        for (uint32_t t0 = 0; t0 < T; t0 += 64u * 8u) {
+            uint32_t sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7;
+#define LD_ITEM(u) { uint32_t t = t0 + u * 64u + grp; sr##u = t < T ? K.item_slot[t] : 0xFFFFFFFFu; rw##u = t < T ? __hip_atomic_load(&K.item_row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; }
+            LD_ITEM(0) LD_ITEM(1) LD_ITEM(2) LD_ITEM(3) LD_ITEM(4) LD_ITEM(5) LD_ITEM(6) LD_ITEM(7)
+#undef LD_ITEM
+            float4 v0, v1, v2, v3, v4, v5, v6, v7; uint32_t id0 = 0, id1 = 0, id2 = 0, id3 = 0, id4 = 0, id5 = 0, id6 = 0, id7 = 0;
+#define LD_MAT(u) { if (sr##u != 0xFFFFFFFFu) { v##u = reinterpret_cast<const float4 *>(A.row_mat + (size_t)rw##u * 16)[part]; if (part == 0) id##u = A.row_id[rw##u]; } }
+            LD_MAT(0) LD_MAT(1) LD_MAT(2) LD_MAT(3) LD_MAT(4) LD_MAT(5) LD_MAT(6) LD_MAT(7)
+#undef LD_MAT
+#define ST_MAT(u) { if (sr##u != 0xFFFFFFFFu) { uint32_t pos = s_hist[sr##u >> 16] + (sr##u & 0xFFFFu); if (pos < A.out_cap) { reinterpret_cast<float4 *>(A.out_mats + (size_t)pos * 16)[part] = v##u; if (part == 0) A.out_ids[pos] = id##u; } } }
+            ST_MAT(0) ST_MAT(1) ST_MAT(2) ST_MAT(3) ST_MAT(4) ST_MAT(5) ST_MAT(6) ST_MAT(7)
+#undef ST_MAT
         }
     }
-    __syncthreads();
+    STAMP(4);
     if (tid == 0) {
-        HostResult r; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
+        HostResult r = *A.hres; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = *s_gcarry; r.total = *s_carry; r.n_candidates = hdr->n_candidates;
         r.overflow = overflow ? 1u : 0u; r.n_entries = nsec; r.n_items = T;
-        *hres = r;
-        FrameHeader z = {}; *hdr_next = z; TickHeader tz = {}; *th = tz;     // next frame's counters (this frame's header stays readable)
+#ifdef RE_EXP_STAMPS
+        r.stamps[5] = wall_clock64();
+#endif
+        *A.hres = r;                                            // mapped pinned host memory
+        TickHeader tz = {}; *th = tz;
     }
+    for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's counters (this frame's header stays readable)
 }
 
 // K2c: scatter -- the instance pack (specify_type_ids! callback + MappedBuffer::write_data_serialized,
@@ -548,10 +628,10 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
                                               RowArrays R, const uint32_t *__restrict__ row_cell,
                                               const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
-                                              FrameParams P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
+                                              const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
                                               TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, TickHeader *h_th) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, P, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap);
+    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap);
     // the last workgroup to finish publishes the counters into mapped pinned host memory
     __shared__ uint32_t s_last;
     __threadfence();
