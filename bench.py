@@ -186,8 +186,12 @@ def cpu_baseline(a, atomic, n_total):
     ax = min(a.cpu_sample_axis, a.axis)
     first = (16384 // atomic - ax) // 2
     ents = synthetic.lattice_world(cells_per_axis=ax, first_cell=first, atomic=atomic, spinner_every=a.spinner_every)
-    threads = os.cpu_count() or 1
-    w = ro.World(16384, atomic, threads=threads)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    par = max(1, min(avail, 16))                   # a 1-GPU box gives this job a 16-core share; rayon would size its pool to the cores it may use
+    w = ro.World(16384, atomic, threads=1)
     w.register(to_oracle(ents))
     c = (first + ax / 2.0) * atomic
     cam = oracle_camera(Camera((c, c, c), (0.0, 0.0, -1.0), a.far))
@@ -196,14 +200,20 @@ def cpu_baseline(a, atomic, n_total):
         L.ro_frame_cull(h, C.byref(cam), 0, None)
         L.ro_frame_render(h, C.byref(cam), 0, 0, None, None, 0, None, None)
         L.ro_frame_tick(h, C.byref(cam), np.float32(0.016), 0, None, None)
-    for _ in range(3):
-        frame()
-    n, t0 = 0, time.perf_counter()
-    while True:
-        frame(); n += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or n >= 20000:
-            break
+    best = None
+    for threads in sorted({1, par}):               # the reference's par_chunks(25) sites with 1 thread and with the pool; the faster one is reported
+        L.ro_set_threads(h, threads)
+        for _ in range(3):
+            frame()
+        n, t0 = 0, time.perf_counter()
+        while True:
+            frame(); n += 1
+            el = time.perf_counter() - t0
+            if el > 6.0 or n >= 20000:
+                break
+        if best is None or el / n < best[0]:
+            best = (el / n, threads, n)
+    el, threads, n = best[0] * best[2], best[1], best[2]
     per_frame = el / n
     w.close()
     return {"value": n_total / per_frame, "unit": "entities/s", "cores": threads, "kind": "port",

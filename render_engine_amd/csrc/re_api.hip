@@ -568,7 +568,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
     PackArgs A{}; A.do_pack = small ? 1u : 0u; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
-    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.do_shared = c->nsh ? 1u : 0u;
+    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.do_shared = c->nsh ? 1u : 0u; A.group_begin = c->d_group_begin.p;
     // K1a: the streaming key scan (the dominant kernel).  hipExtLaunchKernelGGL ties the two events to this
     // dispatch's own begin/end timestamps.
     uint32_t scan_grid = (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64);
@@ -582,7 +582,11 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
                        item_sink(c), hdr, hdr_next, c->d_th.p, A, shared_arrays(c), c->d_params.p, lpw);
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
-    if (!small) {
+    if (small) {
+        uint32_t sgrid = std::min(256u, (std::max(c->pred_total, 1u) + 63u) / 64u * 2u + 4u);      // ~2x the predicted instances, 64 per workgroup per pass
+        hipLaunchKernelGGL(k_scatter_ranked, dim3(sgrid), dim3(256), 0, st, hdr, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_id.p, c->d_mat.p,
+                           out_ids, out_mats, out_cap);
+    } else {
         int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;
     }

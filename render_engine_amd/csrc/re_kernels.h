@@ -53,7 +53,7 @@ struct FrameHeader {
     unsigned long long cursor;              // low 32: entries, high 32: instances
     uint32_t n_vis_map, n_vis_vec, n_groups, total;
     uint32_t n_candidates, ticket;          // sections inside a candidate box (== hash probes of the reference); completed ticket shards
-    uint32_t pad1[8];
+    uint32_t ranked, pad1[7];               // ranked: ranks + group begins of this frame are ready for k_scatter_ranked
     uint32_t shard[TICKET_SHARDS * 16];     // finished-workgroup counters, one per 64-byte line (a single word saturates near 88 atomics/us)
 };
 struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; };
@@ -81,7 +81,7 @@ struct ItemSink { uint32_t *item_row, *item_slot; uint32_t item_cap; const uint3
 struct PackArgs {                           // what the fused small pack needs besides the item list
     uint32_t do_pack, nslots, out_cap, do_shared;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
-    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres;
+    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; uint32_t *group_begin;
 };
 __global__ void k_scan_keys(const uint64_t *cell_key, uint32_t ncells, PBoxTable B, uint32_t *wave_count, uint32_t *cand, FrameParams Pfull, FrameParams *P_dev);
 __global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const uint32_t *wave_count, const uint32_t *cand, const Aabb *cell_tight, const uint32_t *cell_begin,
@@ -92,6 +92,8 @@ __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint3
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
+__global__ void k_scatter_ranked(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
+                                 const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,

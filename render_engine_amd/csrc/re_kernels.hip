@@ -521,7 +521,7 @@ __device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHea
         uint32_t begin = *s_carry + woff + incl - v;
         uint32_t gidx = *s_gcarry + wcn + incn - nz;
         if (i < nslots) {
-            s_hist[i] = begin;
+            s_hist[i] = begin; A.group_begin[i] = begin;                // k_scatter_ranked reads the begins from HBM
             if (v) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
         }
         __syncthreads();
@@ -529,25 +529,6 @@ __device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHea
         __syncthreads();
     }
     STAMP(3);
-    // scatter: the instance pack (64-byte column-major matrix + entity id per instance).  4 lanes per
-    // instance (each moves one float4, so a wave instruction covers 16 whole 64-byte rows), 8 instances in
-    // flight per lane group: a single workgroup hides latency only through its own independent loads.
-    if (!overflow) {
-        const uint32_t part = tid & 3u, grp = tid >> 2;                     // 64 lane groups
-        for (uint32_t t0 = 0; t0 < T; t0 += 64u * 8u) {
-            uint32_t sr0, sr1, sr2, sr3, sr4, sr5, sr6, sr7, rw0, rw1, rw2, rw3, rw4, rw5, rw6, rw7;
-#define LD_ITEM(u) { uint32_t t = t0 + u * 64u + grp; sr##u = t < T ? K.item_slot[t] : 0xFFFFFFFFu; rw##u = t < T ? __hip_atomic_load(&K.item_row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; }
-            LD_ITEM(0) LD_ITEM(1) LD_ITEM(2) LD_ITEM(3) LD_ITEM(4) LD_ITEM(5) LD_ITEM(6) LD_ITEM(7)
-#undef LD_ITEM
-            float4 v0, v1, v2, v3, v4, v5, v6, v7; uint32_t id0 = 0, id1 = 0, id2 = 0, id3 = 0, id4 = 0, id5 = 0, id6 = 0, id7 = 0;
-#define LD_MAT(u) { if (sr##u != 0xFFFFFFFFu) { v##u = reinterpret_cast<const float4 *>(A.row_mat + (size_t)rw##u * 16)[part]; if (part == 0) id##u = A.row_id[rw##u]; } }
-            LD_MAT(0) LD_MAT(1) LD_MAT(2) LD_MAT(3) LD_MAT(4) LD_MAT(5) LD_MAT(6) LD_MAT(7)
-#undef LD_MAT
-#define ST_MAT(u) { if (sr##u != 0xFFFFFFFFu) { uint32_t pos = s_hist[sr##u >> 16] + (sr##u & 0xFFFFu); if (pos < A.out_cap) { reinterpret_cast<float4 *>(A.out_mats + (size_t)pos * 16)[part] = v##u; if (part == 0) A.out_ids[pos] = id##u; } } }
-            ST_MAT(0) ST_MAT(1) ST_MAT(2) ST_MAT(3) ST_MAT(4) ST_MAT(5) ST_MAT(6) ST_MAT(7)
-#undef ST_MAT
-        }
-    }
     STAMP(4);
     if (tid == 0) {
         HostResult r = *A.hres; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = *s_gcarry; r.total = *s_carry; r.n_candidates = hdr->n_candidates;
@@ -557,6 +538,7 @@ __device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHea
 #endif
         *A.hres = r;                                            // mapped pinned host memory
         TickHeader tz = {}; *th = tz;
+        hdr->ranked = overflow ? 0u : 1u;                       // k_scatter_ranked may run
     }
     for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's counters (this frame's header stays readable)
 }
@@ -604,6 +586,29 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, co
             }
         }
         __syncthreads();
+    }
+}
+
+// K2 (small), second half: the instance pack proper (specify_type_ids! callback + MappedBuffer::write_data_serialized,
+// prelude/layout_update_macros.rs:15-21, render_components/mapped_buffer.rs:166-189) for a frame whose
+// ranks and group begins were computed by the last workgroup of k_cull_sections.  Spread over many
+// workgroups on purpose: thousands of page-scattered 64-byte gathers are slow from a single CU.
+// 4 lanes per instance, one float4 each.
+__global__ __launch_bounds__(256) void k_scatter_ranked(const FrameHeader *hdr, const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_slot, uint32_t item_cap,
+                                                        const uint32_t *__restrict__ group_begin, const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
+                                                        uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap) {
+    if (!hdr->ranked) return;
+    uint32_t T = (uint32_t)(hdr->cursor >> 32); if (T > item_cap) T = item_cap;
+    const uint32_t part = threadIdx.x & 3u;
+    for (uint32_t t = blockIdx.x * 64u + (threadIdx.x >> 2); t < T; t += gridDim.x * 64u) {
+        uint32_t sr = item_slot[t];
+        if (sr == 0xFFFFFFFFu) continue;
+        uint32_t row = item_row[t];
+        uint32_t pos = group_begin[sr >> 16] + (sr & 0xFFFFu);
+        if (pos < out_cap) {
+            reinterpret_cast<float4 *>(out_mats + (size_t)pos * 16)[part] = reinterpret_cast<const float4 *>(row_mat + (size_t)row * 16)[part];
+            if (part == 0) out_ids[pos] = row_id[row];
+        }
     }
 }
 
