@@ -144,7 +144,7 @@ def main():
         k1_mean = float(np.mean(k1_us)) if len(k1_us) else float("nan")
         achieved = alg_bytes / (k1_mean * 1e-6) / 1e9 if k1_mean > 0 else None
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_k_cull_sections.json")
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_k_scan_keys.json")
         if os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")

@@ -1,0 +1,27 @@
+#!/bin/bash
+# usage (on the GPU box): tools/pmc_bench.sh <tag> ; collects FETCH_SIZE and WRITE_SIZE in two separate passes
+tag=$1
+root=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --output-format csv -d $root/gpurun_out/pmc_${tag}_$ctr -- python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $root/gpurun_out/pmc_${tag}_$ctr.log 2>&1
+done
+cd $root
+python - <<PY
+import csv, glob, json, collections
+out = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("gpurun_out/pmc_${tag}_%s/*/*counter_collection.csv" % ctr)
+    if not f:
+        print("no counter file for", ctr); continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r.get("Counter_Name") == ctr:
+            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        if "k_scan_keys" in k or "k_cull_sections" in k or "k_scatter_ranked" in k or "k_tick" in k:
+            v = v[len(v) // 3:]                      # steady state
+            out.setdefault(k, {})[ctr] = sum(v) / len(v)
+print(json.dumps(out, indent=1))
+json.dump(out, open("gpurun_out/pmc_${tag}.json", "w"), indent=1)
+PY
