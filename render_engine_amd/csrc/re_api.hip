@@ -56,7 +56,7 @@ struct re_ctx {
     DevBuf<uint32_t> d_dyn_row; DevBuf<float> d_dyn_vel, d_dyn_acc, d_dyn_rotvel, d_dyn_rotacc;
     DevBuf<uint64_t> d_row_key; DevBuf<uint8_t> d_row_nk; DevBuf<SharedRec> d_shrec; DevBuf<uint32_t> d_counter;
     std::vector<uint32_t> h_id, h_flags, h_dyn_row;      // host mirrors of the immutable id column / upload flags / dynamic-row list
-    bool has_rotvel = false;
+    bool has_rotvel = false; uint32_t n_dead = 0;         // n_dead: rows removed by out-of-bounds ticks (upper bound on uncounted reservations)
     bool ids_identity = false;                           // entity id == row index (dense ids): no lookup table needed
     std::vector<std::pair<uint32_t, uint32_t>> id_rows;  // otherwise (id, row) sorted by id
     bool row_of(uint32_t id, uint32_t *row) const {
@@ -417,7 +417,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     if (rc != RE_OK) return rc;
     // frame buffers
     c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
-    c->item_cap = std::max(2u * n, 64u);
+    c->item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
     c->list_cap = std::max(c->ndyn, 1u);
     HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
@@ -501,8 +501,9 @@ static void fill_visible(re_ctx *c, re_visible *out) {
     out->d_matrices = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
 }
 
-static ItemSink item_sink(re_ctx *c) {
-    ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.row_gclass = c->d_gclass.p; return K;
+static ItemSink item_sink(re_ctx *c, bool sharded) {
+    ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.row_gclass = c->d_gclass.p;
+    K.nshards = sharded ? CURSOR_SHARDS : 1u; K.seg_cap = c->item_cap / K.nshards; return K;
 }
 static SharedArrays shared_arrays(re_ctx *c) {
     SharedArrays S; S.n = c->nsh; S.cells = c->d_sh_cells.p; S.aabb = c->d_sh_aabb.p; S.begin = c->d_sh_begin.p; S.nact = c->d_sh_nact.p; S.nstat = c->d_sh_nstat.p;
@@ -510,16 +511,19 @@ static SharedArrays shared_arrays(re_ctx *c) {
 }
 
 // multi-kernel pack for large visible sets: count -> scan -> scatter
-static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next) {
+static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next, bool sharded) {
+    const uint32_t nshards = sharded ? CURSOR_SHARDS : 1u, seg_cap = c->item_cap / nshards;
     hipStream_t st = c->stream;
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     uint32_t grid = std::min(2048u, (c->item_cap + 255u) / 256u);
     size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
-    hipLaunchKernelGGL(k_emit_count, dim3(grid), dim3(256), lds, st, hdr, c->d_item_slot.p, c->item_cap, c->d_group_count.p, c->nslots);
+    // few workgroups for the count: every workgroup flushes its LDS histogram with one global atomic per non-empty group,
+    // and a handful of hot (model, LOD) groups saturate near 88 atomics/us per address
+    hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, c->d_item_slot.p, nshards, seg_cap, c->d_group_count.p, c->nslots);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
                        c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
+    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
                        c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap);
     HIPCHK(c, hipGetLastError());
     return RE_OK;
@@ -530,7 +534,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     c->cull_inflight = false;
     if (c->h_res->overflow) {
         // the single-workgroup pack declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
-        int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u));
+        int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u), false);   // the small path filled shard 0 only
         if (rc != RE_OK) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -539,6 +543,11 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         c->t_cull *= 1000.f; c->t_pack *= 1000.f;
     }
     c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
+    {   // every instance the cull reserved must have been counted into a group (dead rows excepted): otherwise a cursor segment overflowed
+        uint32_t counted = 0; for (uint32_t g = 0; g < c->h_res->n_groups && g < c->nslots; g++) counted += c->h_ranges[g].count;
+        if (counted != c->h_res->total) return c->fail(RE_E_STATE, "group table inconsistent (%u vs %u)", counted, c->h_res->total);
+        if (c->h_res->n_items > c->h_res->total + c->n_dead) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
+    }
     if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
     fill_visible(c, out);
     return RE_OK;
@@ -579,7 +588,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     uint32_t cull_grid = std::max(1u, (cull_waves + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
     hipLaunchKernelGGL(k_cull_sections, dim3(cull_grid), dim3(CULL_THREADS), small ? (size_t)std::max(c->nslots, 1u) * 4 : 0, st, c->d_cell_key.p, c->ncells,
                        c->d_wave_count.p, c->d_cand.p, c->d_cell_tight.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p,
-                       item_sink(c), hdr, hdr_next, c->d_th.p, A, shared_arrays(c), c->d_params.p, lpw);
+                       item_sink(c, !small), hdr, hdr_next, c->d_th.p, A, shared_arrays(c), c->d_params.p, lpw);
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
@@ -587,7 +596,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
         hipLaunchKernelGGL(k_scatter_ranked, dim3(sgrid), dim3(256), 0, st, hdr, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_id.p, c->d_mat.p,
                            out_ids, out_mats, out_cap);
     } else {
-        int rc = launch_pack_large(c, hdr, hdr_next);
+        int rc = launch_pack_large(c, hdr, hdr_next, true);
         if (rc != RE_OK) return rc;
     }
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[2], st));
@@ -600,7 +609,7 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tick_inflight = false;
     if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
-    if (c->ndyn) { c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
+    if (c->ndyn) { c->n_dead += c->h_th->n_oob; c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
     else c->last_tick = re_tick_result{ 0, 0, 0 };
     if (out) *out = c->last_tick;
     return RE_OK;

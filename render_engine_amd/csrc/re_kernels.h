@@ -49,8 +49,11 @@ struct FrameParams {
     LevelBox box[2][MAX_LEVELS];            // [0] logic box, [1] render box, per level
 };
 constexpr uint32_t TICKET_SHARDS = 64;
+constexpr uint32_t CURSOR_SHARDS = 8;
 struct FrameHeader {
-    unsigned long long cursor;              // low 32: entries, high 32: instances
+    unsigned long long cursors[CURSOR_SHARDS * 8];   // one per 64-byte line; low 32: emitting sections, high 32: instances.  Shard 0 alone
+                                            // in small frames; 8 shards (workgroup index mod 8) when the visible set is large, because a
+                                            // single word saturates near 88 atomics/us
     uint32_t n_vis_map, n_vis_vec, n_groups, total;
     uint32_t n_candidates, ticket;          // sections inside a candidate box (== hash probes of the reference); completed ticket shards
     uint32_t ranked, pad1[7];               // ranked: ranks + group begins of this frame are ready for k_scatter_ranked
@@ -77,7 +80,11 @@ __global__ void k_fold_shared(uint32_t nsh, const uint32_t *sh_begin, const uint
 __global__ void k_static_cache_cells(uint32_t ncells, const Aabb *cell_tight, uint8_t *cell_flags, FrameParams P);
 __global__ void k_clear_static_dirty(uint32_t ncells, uint8_t *cell_flags, uint32_t nsh, uint8_t *sh_dirty);
 __global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty, int32_t *sh_owner, uint8_t *sh_cached, FrameParams P);
-struct ItemSink { uint32_t *item_row, *item_slot; uint32_t item_cap; const uint32_t *rows, *row_gclass; };
+struct ItemSink {
+    uint32_t *item_row, *item_slot; uint32_t item_cap;
+    uint32_t nshards, seg_cap;              // instance list = nshards segments of seg_cap slots, one cursor each
+    const uint32_t *rows, *row_gclass;
+};
 struct PackArgs {                           // what the fused small pack needs besides the item list
     uint32_t do_pack, nslots, out_cap, do_shared;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
@@ -87,10 +94,10 @@ __global__ void k_scan_keys(const uint64_t *cell_key, uint32_t ncells, PBoxTable
 __global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const uint32_t *wave_count, const uint32_t *cand, const Aabb *cell_tight, const uint32_t *cell_begin,
                                 const uint32_t *cell_nlocal, const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, ItemSink K, FrameHeader *hdr,
                                 FrameHeader *hdr_next, TickHeader *th, PackArgs A, SharedArrays S, const FrameParams *P, uint32_t lists_per_wave);
-__global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t item_cap, uint32_t *group_count, uint32_t nslots);
+__global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres);
-__global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
+__global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
 __global__ void k_scatter_ranked(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
                                  const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);

@@ -137,41 +137,71 @@ __global__ __launch_bounds__(256) void k_static_cache_shared(uint32_t nsh, const
 // sum gives every lane its offset, then every lane expands its own rows (RenderFlow::add_entities,
 // render_flow.rs:872-933: ModelId + LOD -> group slot).  Sections with many rows are expanded by the
 // whole wave so one crowded section does not serialise behind a single lane.
-__device__ __forceinline__ void emit_sections(uint32_t rb, uint32_t cnt, uint32_t lodm, FrameHeader *hdr, const ItemSink &K) {
-    const uint32_t m = (lodm >> 8) & 3u, lod = lodm & 7u;
-    const uint32_t nemit = cnt * m;
-    uint64_t mask = __ballot(nemit > 0);
+// segments of the instance list (see FrameHeader::cursors)
+struct ShardMap { uint32_t n[CURSOR_SHARDS]; uint32_t total; };
+__device__ __forceinline__ ShardMap load_shard_map(const FrameHeader *hdr, uint32_t nshards, uint32_t seg_cap) {
+    ShardMap m; m.total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+        uint32_t v = k < nshards ? (uint32_t)(hdr->cursors[k * 8] >> 32) : 0u;
+        m.n[k] = v < seg_cap ? v : seg_cap; m.total += m.n[k];
+    }
+    return m;
+}
+__device__ __forceinline__ uint32_t shard_item_index(uint32_t t, const ShardMap &m, uint32_t seg_cap) {
+    uint32_t idx = t;
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { if (t < m.n[k]) { idx = k * seg_cap + t; break; } t -= m.n[k]; }
+    return idx;
+}
+
+constexpr uint32_t EMIT_MAX = WAVE_KEYS / 64u;                 // sections one lane can hold per call (one per 64-candidate round of a list)
+
+__device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t first, uint32_t stride, uint32_t n, uint32_t off, uint32_t lod, uint32_t seg_base, const ItemSink &K) {
+    for (uint32_t k = first; k < n; k += stride) {
+        uint32_t t = off + k;
+        if (t < K.seg_cap) {
+            uint32_t row = K.rows[rb + (k % cnt)];
+            uint32_t gc = K.row_gclass[row];
+            K.item_row[seg_base + t] = row; K.item_slot[seg_base + t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
+        }
+    }
+}
+
+// Every lane brings up to EMIT_MAX visible sections {row range, count, lod | multiplicity << 8}.  ONE 64-bit
+// atomic per call reserves their instances.
+__device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MAX], const uint32_t (&cnt)[EMIT_MAX], const uint32_t (&lodm)[EMIT_MAX],
+                                                    FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint) {
+    uint32_t mine = 0, nsec = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < EMIT_MAX; j++) { uint32_t n = cnt[j] * ((lodm[j] >> 8) & 3u); mine += n; nsec += n ? 1u : 0u; }
+    uint64_t mask = __ballot(mine > 0);
     if (!mask) return;
-    uint32_t incl = wave_incl_scan(nemit);
-    uint32_t tot = __shfl(incl, 63, 64);
+    uint32_t incl = wave_incl_scan(mine), incs = wave_incl_scan(nsec);
+    uint32_t tot = __shfl(incl, 63, 64), tots = __shfl(incs, 63, 64);
+    const uint32_t shard = K.nshards > 1u ? (shard_hint & (CURSOR_SHARDS - 1u)) : 0u;      // wave-uniform (list / section-block index)
     unsigned long long base = 0;
-    if (lane_id() == 0) base = atomicAdd(reinterpret_cast<unsigned long long *>(&hdr->cursor), (unsigned long long)__popcll(mask) | ((unsigned long long)tot << 32));
+    if (lane_id() == 0) base = atomicAdd(&hdr->cursors[shard * 8u], (unsigned long long)tots | ((unsigned long long)tot << 32));
     base = __shfl(base, 0, 64);
-    uint32_t off = (uint32_t)(base >> 32) + (incl - nemit);
+    uint32_t off = (uint32_t)(base >> 32) + (incl - mine);
+    const uint32_t seg_base = shard * K.seg_cap;
     const uint32_t WIDE = 32u;
-    if (nemit && nemit <= WIDE) {
-        for (uint32_t k = 0; k < nemit; k++) {
-            uint32_t t = off + k;
-            if (t < K.item_cap) {
-                uint32_t row = K.rows[rb + (k % cnt)];
-                uint32_t gc = K.row_gclass[row];
-                K.item_row[t] = row; K.item_slot[t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
-            }
+#pragma unroll
+    for (uint32_t j = 0; j < EMIT_MAX; j++) {
+        const uint32_t m = (lodm[j] >> 8) & 3u, lod = lodm[j] & 7u, n = cnt[j] * m;
+        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K);
+        uint64_t wide = __ballot(n > WIDE);
+        while (wide) {                                          // wave-cooperative expansion of crowded sections
+            int src = __ffsll((long long)wide) - 1; wide &= wide - 1;
+            expand_rows(__shfl(rb[j], src, 64), __shfl(cnt[j], src, 64), lane_id(), 64u, __shfl(n, src, 64), __shfl(off, src, 64), __shfl(lod, src, 64), seg_base, K);
         }
+        off += n;
     }
-    uint64_t wide = __ballot(nemit > WIDE);
-    while (wide) {                                              // wave-cooperative expansion of crowded sections
-        int src = __ffsll((long long)wide) - 1; wide &= wide - 1;
-        uint32_t w_rb = __shfl(rb, src, 64), w_cnt = __shfl(cnt, src, 64), w_n = __shfl(nemit, src, 64), w_off = __shfl(off, src, 64);
-        for (uint32_t k = lane_id(); k < w_n; k += 64u) {
-            uint32_t t = w_off + k;
-            if (t < K.item_cap) {
-                uint32_t row = K.rows[w_rb + (k % w_cnt)];
-                uint32_t gc = K.row_gclass[row];
-                K.item_row[t] = row; K.item_slot[t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
-            }
-        }
-    }
+}
+__device__ __forceinline__ void emit_sections(uint32_t rb0, uint32_t cnt0, uint32_t lodm0, FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint) {
+    uint32_t rb[EMIT_MAX] = {}, cnt[EMIT_MAX] = {}, lodm[EMIT_MAX] = {};
+    rb[0] = rb0; cnt[0] = cnt0; lodm[0] = lodm0;
+    emit_sections_multi(rb, cnt, lodm, hdr, K, shard_hint);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -309,9 +339,11 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
         const int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
         const uint32_t qn = __shfl(my_count, src, 64);
         const uint32_t *q = cand + (size_t)__shfl(my_list, src, 64) * WAVE_KEYS;
-        for (uint32_t i0 = 0; i0 < qn; i0 += 64u) {                         // dense lanes
-            uint32_t i = i0 + lane;
-            uint32_t rb = 0, cnt = 0, lod = 0;
+        uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
+#pragma unroll
+        for (uint32_t j = 0; j < EMIT_MAX; j++) {                           // dense lanes, <= EMIT_MAX rounds of 64 candidates
+            const uint32_t i = j * 64u + lane;
+            rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
             if (i < qn) {
                 uint32_t c = q[i];
                 uint64_t key = cell_key[c];
@@ -328,14 +360,14 @@ __global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *
                     bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
                     bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
                     uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c];
-                    rb = cell_begin[c] + (act ? 0u : nl);
-                    cnt = (act ? nl : 0u) + (sta ? ns : 0u);
+                    rbv[j] = cell_begin[c] + (act ? 0u : nl);
+                    cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
                     uint32_t m = P.emit_duplicates ? mult : 1u;
-                    lod = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8);
+                    lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8);
                 }
             }
-            emit_sections(rb, cnt, lod, hdr, K);
         }
+        emit_sections_multi(rbv, cntv, lodv, hdr, K, __shfl(my_list, src, 64));  // one reservation per candidate list
     }
     if (__ballot(cand_acc != 0)) {                                          // per-wave counters: one atomic each
         for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
@@ -401,8 +433,9 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
             }
         }
     }
-    emit_sections(rbA, cntA, lodA, hdr, K);                       // active members
-    emit_sections(rbS, cntS, lodS, hdr, K);                       // static members
+    const uint32_t hint = __builtin_amdgcn_readfirstlane(s) >> 6;
+    emit_sections(rbA, cntA, lodA, hdr, K, hint);                 // active members
+    emit_sections(rbS, cntS, lodS, hdr, K, hint + 1u);            // static members
 }
 
 
@@ -410,14 +443,15 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
 // ---------------------------------------------------------------------------------------------
 // K2a (large visible sets): per-group instance counts from the expanded item list.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit_count(const FrameHeader *hdr, const uint32_t *__restrict__ item_slot, uint32_t item_cap,
+__global__ __launch_bounds__(256) void k_emit_count(const FrameHeader *hdr, const uint32_t *__restrict__ item_slot, uint32_t nshards, uint32_t seg_cap,
                                                     uint32_t *__restrict__ group_count, uint32_t nslots) {
     extern __shared__ uint32_t s_hist[];
     const bool use_lds = nslots <= LDS_HIST_SLOTS;
     if (use_lds) { for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) s_hist[i] = 0; __syncthreads(); }
-    uint32_t T = (uint32_t)(hdr->cursor >> 32); if (T > item_cap) T = item_cap;
+    const ShardMap sm = load_shard_map(hdr, nshards, seg_cap);
+    const uint32_t T = sm.total;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        uint32_t slot = item_slot[t];
+        uint32_t slot = item_slot[shard_item_index(t, sm, seg_cap)];
         if (slot != 0xFFFFFFFFu) { if (use_lds) atomicAdd(&s_hist[slot], 1u); else atomicAdd(&group_count[slot], 1u); }
     }
     if (use_lds) {
@@ -461,9 +495,10 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
     }
     if (threadIdx.x == 0) {
         hdr->total = s_carry; hdr->n_groups = s_gcarry;
-        unsigned long long cur = hdr->cursor;
-        HostResult r; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
-        r.overflow = 0; r.n_entries = (uint32_t)cur; r.n_items = (uint32_t)(cur >> 32);
+        uint32_t nsec = 0, nitems = 0;
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * 8]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
+        HostResult r = *hres; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
+        r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         *hres = r;                                              // mapped pinned host memory
         TickHeader tz = {}; *th = tz;
     }
@@ -490,7 +525,7 @@ __device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHea
     if (tid == 0) { *s_carry = 0; *s_gcarry = 0; }
     __syncthreads();
     STAMP(1);
-    unsigned long long cur = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&hdr->cursor), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long cur = __hip_atomic_load(&hdr->cursors[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // small frames use shard 0 only
     const uint32_t nsec = (uint32_t)cur, T = (uint32_t)(cur >> 32);
     const bool overflow = T > PACK_SMALL_ITEMS || T > K.item_cap || nslots > LDS_HIST_SLOTS;
     if (!overflow) {
@@ -549,19 +584,20 @@ __device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHea
 // LDS histogram, one global atomic per (workgroup, group) reserves the slots; (B) 4 lanes per
 // instance each move one float4 of the 64-byte column-major matrix, so a wave instruction
 // reads/writes 16 whole 64-byte rows.
-__global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_slot, uint32_t item_cap,
+__global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_slot, uint32_t nshards, uint32_t seg_cap,
                                                       const uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill, uint32_t nslots,
                                                       const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
                                                       uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap) {
     extern __shared__ uint32_t s_hist[];                       // [nslots] local counts, then the reserved bases
     __shared__ uint32_t s_pos[256], s_row[256];
     const bool use_lds = nslots <= LDS_HIST_SLOTS;
-    uint32_t T = (uint32_t)(hdr->cursor >> 32); if (T > item_cap) T = item_cap;
+    const ShardMap sm = load_shard_map(hdr, nshards, seg_cap);
+    const uint32_t T = sm.total;
     const uint32_t tid = threadIdx.x;
     for (uint32_t t0 = blockIdx.x * 256u; t0 < T; t0 += gridDim.x * 256u) {   // uniform trip count per workgroup
         uint32_t t = t0 + tid;
         uint32_t slot = 0xFFFFFFFFu, row = 0, rank = 0, pos = 0xFFFFFFFFu;
-        if (t < T) { slot = item_slot[t]; row = item_row[t]; }
+        if (t < T) { uint32_t ii = shard_item_index(t, sm, seg_cap); slot = item_slot[ii]; row = item_row[ii]; }
         if (use_lds) {
             for (uint32_t i = tid; i < nslots; i += 256u) s_hist[i] = 0;
             __syncthreads();
@@ -598,7 +634,7 @@ __global__ __launch_bounds__(256) void k_scatter_ranked(const FrameHeader *hdr, 
                                                         const uint32_t *__restrict__ group_begin, const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
                                                         uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap) {
     if (!hdr->ranked) return;
-    uint32_t T = (uint32_t)(hdr->cursor >> 32); if (T > item_cap) T = item_cap;
+    uint32_t T = (uint32_t)(hdr->cursors[0] >> 32); if (T > item_cap) T = item_cap;
     const uint32_t part = threadIdx.x & 3u;
     for (uint32_t t = blockIdx.x * 64u + (threadIdx.x >> 2); t < T; t += gridDim.x * 64u) {
         uint32_t sr = item_slot[t];
@@ -638,8 +674,8 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap);
     // the last workgroup to finish publishes the counters into mapped pinned host memory
+    // (the counters are device-scope atomics, already at L2: no fence is needed before the ticket)
     __shared__ uint32_t s_last;
-    __threadfence();
     __syncthreads();
     if (threadIdx.x == 0) s_last = (atomicAdd(&th->ticket, 1u) == gridDim.x - 1u);
     __syncthreads();
