@@ -72,11 +72,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # RE_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (all ranks share device 0)
+    backend = os.environ.get("RE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import render_engine_amd as R
     from render_engine_amd import parallel

@@ -792,9 +792,13 @@ static void update_static_world_sections(ro_world *w) {
     }
 }
 
+static int cmp_shared_idx_world(const void *a, const void *b, void *arg);
+
 void ro_end_of_changes(ro_world *w) {
     u64set_normalize(&w->changed_cells);
     u32vec_normalize(&w->changed_shared);
+    /* deterministic stand-in for hash order: canonical id order (keys lexicographic, then count), independent of table slots */
+    if (w->changed_shared.n > 1) qsort_r(w->changed_shared.v, w->changed_shared.n, sizeof(uint32_t), cmp_shared_idx_world, (void *)w);
     update_static_world_sections(w);
     int too_many = w->total_combining > 500;
     for (uint32_t i = 0; i < w->changed_cells.n; i++) {

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <array>
+#include <set>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -39,6 +41,20 @@ struct GroupKeyHash { size_t operator()(const GroupKey &k) const { return (size_
 
 }  // namespace
 
+struct SharedIdPub { uint32_t nk; uint64_t keys[8];
+                     // canonical order: keys lexicographic (numeric), then count -- the order the oracle visits changed shared sections in
+                     bool operator<(const SharedIdPub &o) const { uint32_t m = nk < o.nk ? nk : o.nk; for (uint32_t i = 0; i < m; i++) if (keys[i] != o.keys[i]) return keys[i] < o.keys[i]; return nk < o.nk; }
+                     bool operator==(const SharedIdPub &o) const { return nk == o.nk && memcmp(keys, o.keys, sizeof keys) == 0; } };
+
+// State of the structure before an incremental re-bucket (apply_change semantics): unchanged world sections keep their tight AABB
+// (which may be stale: add_entity returns early when an entity stays in its section), static-section flag and render-cache bits.
+struct Carry {
+    std::vector<uint64_t> keys; std::vector<Aabb> tight; std::vector<uint8_t> flags;
+    std::vector<SharedIdPub> shids; std::vector<Aabb> sh_aabb; std::vector<int32_t> sh_owner_key_idx; std::vector<uint64_t> sh_owner_key; std::vector<uint8_t> sh_cached;
+    std::set<uint64_t> changed_cells, changed_static; std::vector<SharedIdPub> changed_shared; std::set<SharedIdPub> changed_shared_set;
+    bool too_many = false;
+};
+
 struct re_ctx {
     re_config cfg{};
     int device = 0;
@@ -56,6 +72,7 @@ struct re_ctx {
     DevBuf<uint32_t> d_dyn_row; DevBuf<float> d_dyn_vel, d_dyn_acc, d_dyn_rotvel, d_dyn_rotacc;
     DevBuf<uint64_t> d_row_key; DevBuf<uint8_t> d_row_nk; DevBuf<SharedRec> d_shrec; DevBuf<uint32_t> d_counter;
     std::vector<uint32_t> h_id, h_flags, h_dyn_row;      // host mirrors of the immutable id column / upload flags / dynamic-row list
+    uint32_t n_rebuilds = 0;
     bool has_rotvel = false; uint32_t n_dead = 0;         // n_dead: rows removed by out-of-bounds ticks (upper bound on uncounted reservations)
     bool ids_identity = false;                           // entity id == row index (dense ids): no lookup table needed
     std::vector<std::pair<uint32_t, uint32_t>> id_rows;  // otherwise (id, row) sorted by id
@@ -71,6 +88,10 @@ struct re_ctx {
     DevBuf<uint8_t> d_cell_flags;
     DevBuf<int32_t> d_sh_cells, d_sh_owner; DevBuf<Aabb> d_sh_aabb; DevBuf<uint32_t> d_sh_begin, d_sh_nact, d_sh_nstat; DevBuf<uint8_t> d_sh_cached, d_sh_dirty;
     std::vector<uint64_t> h_cell_key;
+    // host copies the incremental re-bucket needs: per-row section decision, and the shared-section ids in device order
+    std::vector<uint64_t> h_row_key; std::vector<uint8_t> h_row_nk; std::vector<uint32_t> h_row_cell, h_gclass;
+    std::unordered_map<uint32_t, std::array<uint64_t, 8>> h_row_shared_keys;
+    std::vector<SharedIdPub> h_shids; std::vector<uint32_t> h_sh_nact, h_sh_nstat;
     bool dirty_pending = false;
     // groups
     uint32_t ngclass = 0, nslots = 0;
@@ -162,11 +183,11 @@ static RowArrays row_arrays(re_ctx *c) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct SortRec { uint64_t key; uint64_t sub; uint32_t row; };   // sub = static << 32 | entity id
-struct SharedId { uint32_t nk; uint64_t keys[8]; bool operator<(const SharedId &o) const { if (nk != o.nk) return nk < o.nk; return memcmp(keys, o.keys, sizeof keys) < 0; } };
+using SharedId = SharedIdPub;
 }
 
 static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const std::vector<uint8_t> &row_nk, std::vector<SharedRec> &shrec,
-                          const std::vector<uint32_t> &flags) {
+                          const std::vector<uint32_t> &flags, const Carry *carry = nullptr) {
     const uint32_t n = c->n;
     uint64_t *acct = &c->dev_bytes;
     // --- unique rows sorted by (section key, static, entity id): CSR order == the oracle's iteration order
@@ -177,6 +198,11 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     // --- shared sections, indexed by first appearance in row order (== creation order of a fresh tree)
     std::sort(shrec.begin(), shrec.end(), [](const SharedRec &a, const SharedRec &b) { return a.row < b.row; });
     std::map<SharedId, uint32_t> shmap; std::vector<SharedId> shids; std::vector<std::vector<uint32_t>> sh_act, sh_sta;
+    if (carry) {                                                        // surviving shared sections keep their creation order
+        std::set<SharedId> alive;
+        for (const SharedRec &sr : shrec) { SharedId id; id.nk = sr.nk; memcpy(id.keys, sr.keys, sizeof id.keys); alive.insert(id); }
+        for (const SharedId &id : carry->shids) if (alive.count(id)) { shmap.emplace(id, (uint32_t)shids.size()); shids.push_back(id); sh_act.emplace_back(); sh_sta.emplace_back(); }
+    }
     for (const SharedRec &sr : shrec) {
         SharedId id; id.nk = sr.nk; memcpy(id.keys, sr.keys, sizeof id.keys);
         auto it = shmap.find(id); uint32_t s;
@@ -240,26 +266,43 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         for (uint32_t r : sh_act[s]) { rows.push_back(r); row_cell[r] = ROW_CELL_SHARED | s; }
         for (uint32_t r : sh_sta[s]) { rows.push_back(r); row_cell[r] = ROW_CELL_SHARED | s; }
     }
-    // --- update_static_world_sections (bounding_box_tree_v2.rs:1133-1213), every section and shared section changed
-    std::vector<uint8_t> cflags(ncells + 1, 0);
-    for (uint32_t ci = 0; ci < ncells; ci++) {
+    // --- update_static_world_sections (bounding_box_tree_v2.rs:1133-1213).  Fresh build: every section and shared section changed.
+    // Incremental (carry): only the changed sections are recomputed, everything else keeps its previous flag.
+    std::vector<uint8_t> cflags(ncells + 1, 0), refold(ncells + 1, 1); std::vector<Aabb> carried_tight(ncells + 1);
+    auto loop1 = [&](uint32_t ci) {
         bool st = false;
         if (nlocal[ci] == 0) {
             auto it = cell_link_idx.find(ci);
             if (it == cell_link_idx.end()) st = true;
             else for (uint32_t s : cell_links[it->second]) if (sh_nact[s] == 0) st = true;
         }
-        cflags[ci] = is_pad(keys[ci]) ? (uint8_t)(CF_PAD | CF_STATIC_SECTION) : (uint8_t)((st ? CF_STATIC_SECTION : 0) | CF_STATIC_DIRTY);
+        return st;
+    };
+    for (uint32_t ci = 0; ci < ncells; ci++) {
+        if (is_pad(keys[ci])) { cflags[ci] = (uint8_t)(CF_PAD | CF_STATIC_SECTION); continue; }
+        if (!carry) { cflags[ci] = (uint8_t)((loop1(ci) ? CF_STATIC_SECTION : 0) | CF_STATIC_DIRTY); continue; }
+        auto old = std::lower_bound(carry->keys.begin(), carry->keys.end(), keys[ci]);
+        bool existed = old != carry->keys.end() && *old == keys[ci];
+        bool changed = carry->changed_cells.count(keys[ci]) != 0;
+        uint8_t f = existed ? (uint8_t)(carry->flags[old - carry->keys.begin()] & (CF_STATIC_SECTION | CF_STATIC_CACHED | CF_STATIC_DIRTY)) : (uint8_t)0;
+        if (changed || !existed) f = (uint8_t)((f & ~CF_STATIC_SECTION) | (loop1(ci) ? CF_STATIC_SECTION : 0));
+        if (carry->changed_static.count(keys[ci])) f |= CF_STATIC_DIRTY;
+        cflags[ci] = f;
+        if (existed && !changed) { refold[ci] = 0; carried_tight[ci] = carry->tight[old - carry->keys.begin()]; }
     }
-    for (uint32_t s = 0; s < nsh; s++)
+    std::vector<uint32_t> sh_order(nsh); for (uint32_t s = 0; s < nsh; s++) sh_order[s] = s;
+    std::sort(sh_order.begin(), sh_order.end(), [&](uint32_t a, uint32_t b) { return shids[a] < shids[b]; });   // canonical id order
+    for (uint32_t s : sh_order) {
+        if (carry && !carry->changed_shared_set.count(shids[s])) continue;      // second loop: changed shared sections only
         for (uint32_t k = 0; k < shids[s].nk; k++) {
             uint32_t ci = (uint32_t)sh_cells[(size_t)s * 8 + k];
             if (sh_nact[s] == 0) { if (nlocal[ci] == 0) cflags[ci] |= CF_STATIC_SECTION; }
             else cflags[ci] &= ~CF_STATIC_SECTION;
         }
+    }
     // --- upload
     c->ncells = ncells; c->nsh = nsh; c->nrows_csr = (uint32_t)rows.size();
-    c->h_cell_key = keys;
+    c->h_cell_key = keys; c->h_row_cell = row_cell; c->h_shids = shids; c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat;
     std::vector<uint64_t> keys_padded(keys); keys_padded.resize((size_t)((ncells + 1) & ~1u) + 2, 0xFFFFFFFFFFFFFFFFull);
     HIPCHK(c, c->d_cell_key.alloc(keys_padded.size(), acct));
     HIPCHK(c, c->d_cell_tight.alloc(ncells, acct)); HIPCHK(c, c->d_cell_begin.alloc(ncells + 1, acct)); HIPCHK(c, c->d_cell_nlocal.alloc(ncells, acct));
@@ -284,22 +327,53 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, hipMemcpyAsync(c->d_sh_begin.p, sh_begin.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_sh_nact.p, sh_nact.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_sh_nstat.p, sh_nstat.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemsetAsync(c->d_sh_owner.p, 0xFF, (size_t)nsh * 4, st));
-        HIPCHK(c, hipMemsetAsync(c->d_sh_cached.p, 0, nsh, st));
-        HIPCHK(c, hipMemsetAsync(c->d_sh_dirty.p, 1, nsh, st));
+        std::vector<int32_t> owner(nsh, -1); std::vector<uint8_t> cached(nsh, 0), dirty(nsh, carry ? 0 : 1);
+        if (carry)
+            for (uint32_t s = 0; s < nsh; s++) {
+                auto it = std::find(carry->shids.begin(), carry->shids.end(), shids[s]);
+                if (it == carry->shids.end()) continue;
+                size_t o = it - carry->shids.begin();
+                cached[s] = carry->sh_cached[o];
+                if (carry->sh_owner_key_idx[o] >= 0) { auto kk = std::lower_bound(keys.begin(), keys.end(), carry->sh_owner_key[o]); if (kk != keys.end() && *kk == carry->sh_owner_key[o]) owner[s] = (int32_t)(kk - keys.begin()); }
+            }
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_owner.p, owner.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_cached.p, cached.data(), nsh, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_dirty.p, dirty.data(), nsh, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
     }
     // --- end_of_changes: tight AABBs.  total_world_aabb_combining of a fresh batch == number of unique adds (:710-744)
-    int too_many = recs.size() > 500;
-    if (ncells) hipLaunchKernelGGL(k_fold_tight, dim3((ncells + 255) / 256), dim3(256), 0, st, ncells, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p,
-                                   c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, too_many);
+    int too_many = carry ? (int)carry->too_many : (int)(recs.size() > 500);
+    DevBuf<uint8_t> d_refold; DevBuf<Aabb> d_carried;
+    if (ncells && !carry) hipLaunchKernelGGL(k_fold_tight, dim3((ncells + 255) / 256), dim3(256), 0, st, ncells, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p,
+                                             c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, too_many);
+    if (ncells && carry) {
+        HIPCHK(c, d_refold.alloc(ncells, nullptr)); HIPCHK(c, d_carried.alloc(ncells, nullptr));
+        HIPCHK(c, hipMemcpyAsync(d_refold.p, refold.data(), ncells, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(d_carried.p, carried_tight.data(), (size_t)ncells * sizeof(Aabb), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_fold_tight_masked, dim3((ncells + 255) / 256), dim3(256), 0, st, ncells, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p,
+                           c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, too_many, d_refold.p, d_carried.p);
+    }
     if (nsh) hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
+    if (nsh && carry) {                                                     // unchanged shared sections keep their AABB
+        std::vector<Aabb> sa(nsh);
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipMemcpy(sa.data(), c->d_sh_aabb.p, (size_t)nsh * sizeof(Aabb), hipMemcpyDeviceToHost));
+        for (uint32_t s2 = 0; s2 < nsh; s2++) {
+            if (carry->changed_shared_set.count(shids[s2])) continue;
+            auto it = std::find(carry->shids.begin(), carry->shids.end(), shids[s2]);
+            if (it != carry->shids.end()) sa[s2] = carry->sh_aabb[it - carry->shids.begin()];
+        }
+        HIPCHK(c, hipMemcpy(c->d_sh_aabb.p, sa.data(), (size_t)nsh * sizeof(Aabb), hipMemcpyHostToDevice));
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     c->nlists = std::max(1u, (((ncells + 1u) >> 1) + 64u * CULL_ITERS - 1u) / (64u * CULL_ITERS));
     HIPCHK(c, c->d_wave_count.alloc(c->nlists, acct)); HIPCHK(c, c->d_cand.alloc((size_t)c->nlists * WAVE_KEYS, acct));
     HIPCHK(c, hipMemsetAsync(c->d_wave_count.p, 0, (size_t)c->nlists * 4, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    c->dirty_pending = true; c->have_cull = false;
+    d_refold.release(nullptr); d_carried.release(nullptr);
+    if (!carry) { c->dirty_pending = true; c->have_cull = false; }
+    else if (!carry->changed_static.empty()) c->dirty_pending = true;
     return RE_OK;
 }
 
@@ -413,6 +487,8 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     for (uint32_t r = 0; r < n; r++) if (row_nk[r] == 0) rejected++;
     if (n_rejected) *n_rejected = rejected;
     c->d_shrec.release(acct);
+    c->h_row_key = row_key; c->h_row_nk = row_nk; c->h_gclass = gclass; c->h_row_shared_keys.clear();
+    for (const SharedRec &sr : shrec) { std::array<uint64_t, 8> a; memcpy(a.data(), sr.keys, sizeof sr.keys); c->h_row_shared_keys[sr.row] = a; }
     int rc = build_sections(c, row_key, row_nk, shrec, flags);
     if (rc != RE_OK) return rc;
     // frame buffers
@@ -484,6 +560,8 @@ static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     fill_level_boxes(P.box[1], c->maxlevel, wsl, rmax(cx - half, 0.0f), cx + half, rmax(cy - half, 0.0f), cy + half, rmax(cz - half, 0.0f), cz + half);
     fill_packed_boxes(c->PB.box[0], P.box[0], c->maxlevel); fill_packed_boxes(c->PB.box[1], P.box[1], c->maxlevel);
 }
+
+static int finish_tick(re_ctx *c, re_tick_result *out);
 
 static void fill_visible(re_ctx *c, re_visible *out) {
     const HostResult &h = *c->h_res;
@@ -559,6 +637,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     if (!c->h_res) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    if (c->tick_inflight && c->ndyn) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }   // movers of the previous tick may change the section table
     if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
@@ -605,11 +684,138 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     return finish_cull(c, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Incremental re-bucket after a tick: update_entity_in_tree -> BoundingBoxTree::add_entity (which removes the entity from
+// its previous section) for every mover whose section changed, then end_of_changes (helper_things/entity_change_helpers.rs:
+// 217-262, 325-351; world/bounding_box_tree_v2.rs:563-942, 1055-1213).  Order of the reference: translation-only movers, then
+// kinematic movers, each set in ascending EntityId (stand-in for hash order).  The sequential bookkeeping that decides
+// total_world_aabb_combining (> 500 => crowded changed sections fall back to their grid AABB) is replayed exactly on the
+// few affected sections; the key-sorted arrays are then rebuilt, carrying over everything the reference leaves untouched.
+// Host-assisted and O(N log N): correct first; a GPU-resident incremental update is the next step.
+// ------------------------------------------------------------------------------------------------
+static int rebucket(re_ctx *c, uint32_t n_movers) {
+    hipStream_t st = c->stream;
+    const uint32_t M = std::min(n_movers, c->list_cap);
+    if (n_movers > c->list_cap) return c->fail(RE_E_CAPACITY, "mover list overflow");
+    std::vector<uint32_t> movers(M);
+    HIPCHK(c, hipMemcpy(movers.data(), c->d_movers.p, (size_t)M * 4, hipMemcpyDeviceToHost));
+    std::sort(movers.begin(), movers.end(), [&](uint32_t a, uint32_t b) {
+        bool ta = (a >> 31) != 0, tb = (b >> 31) != 0;                 // translation-only first
+        if (ta != tb) return ta;
+        return c->h_id[a & 0x7FFFFFFFu] < c->h_id[b & 0x7FFFFFFFu];
+    });
+    DevBuf<uint32_t> d_list; DevBuf<uint8_t> d_nk; DevBuf<uint64_t> d_keys;
+    HIPCHK(c, d_list.alloc(M, nullptr)); HIPCHK(c, d_nk.alloc(M, nullptr)); HIPCHK(c, d_keys.alloc((size_t)M * 8, nullptr));
+    HIPCHK(c, hipMemcpyAsync(d_list.p, movers.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_assign_rows, dim3((M + 255) / 256), dim3(256), 0, st, M, d_list.p, row_arrays(c), c->cfg.outline_length, c->cfg.atomic_length, d_nk.p, d_keys.p);
+    std::vector<uint8_t> nk(M); std::vector<uint64_t> nkeys((size_t)M * 8);
+    HIPCHK(c, hipMemcpyAsync(nk.data(), d_nk.p, M, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(nkeys.data(), d_keys.p, (size_t)M * 64, hipMemcpyDeviceToHost, st));
+    // previous structure
+    Carry carry;
+    const uint32_t oc = c->ncells, os = c->nsh;
+    carry.keys = c->h_cell_key; carry.tight.resize(oc); carry.flags.resize(oc); carry.shids = c->h_shids; carry.sh_aabb.resize(os); carry.sh_cached.resize(os);
+    std::vector<int32_t> sh_owner(os); std::vector<uint32_t> o_nl(oc), o_ns(oc);
+    if (oc) {
+        HIPCHK(c, hipMemcpyAsync(carry.tight.data(), c->d_cell_tight.p, (size_t)oc * sizeof(Aabb), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(carry.flags.data(), c->d_cell_flags.p, oc, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(o_nl.data(), c->d_cell_nlocal.p, (size_t)oc * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(o_ns.data(), c->d_cell_nstatic.p, (size_t)oc * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (os) {
+        HIPCHK(c, hipMemcpyAsync(carry.sh_aabb.data(), c->d_sh_aabb.p, (size_t)os * sizeof(Aabb), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(carry.sh_cached.data(), c->d_sh_cached.p, os, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(sh_owner.data(), c->d_sh_owner.p, (size_t)os * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    d_list.release(nullptr); d_nk.release(nullptr); d_keys.release(nullptr);
+    carry.sh_owner_key_idx = sh_owner; carry.sh_owner_key.resize(os, 0);
+    for (uint32_t s = 0; s < os; s++) if (sh_owner[s] >= 0) carry.sh_owner_key[s] = c->h_cell_key[sh_owner[s]];
+    // ---- replay of remove_entity / add_entity on the affected sections (counts only)
+    struct CS { uint32_t nl, ns, links; bool exists; };
+    struct SS { uint32_t na, nst; bool exists; };
+    std::map<uint64_t, CS> cs; std::map<SharedIdPub, SS> ss;
+    std::map<uint64_t, uint32_t> link_count;                             // shared sections linking each section, from the previous structure
+    for (uint32_t s = 0; s < os; s++) for (uint32_t k = 0; k < c->h_shids[s].nk; k++) link_count[c->h_shids[s].keys[k]]++;
+    auto cell = [&](uint64_t key) -> CS & {
+        auto it = cs.find(key);
+        if (it != cs.end()) return it->second;
+        CS v{ 0, 0, 0, false };
+        auto o = std::lower_bound(carry.keys.begin(), carry.keys.end(), key);
+        if (o != carry.keys.end() && *o == key) { size_t i = o - carry.keys.begin(); v.nl = o_nl[i]; v.ns = o_ns[i]; v.exists = true; auto lc = link_count.find(key); v.links = lc == link_count.end() ? 0u : lc->second; }
+        return cs.emplace(key, v).first->second;
+    };
+    auto shared = [&](const SharedIdPub &id) -> SS & {
+        auto it = ss.find(id);
+        if (it != ss.end()) return it->second;
+        SS v{ 0, 0, false };
+        auto o = std::find(c->h_shids.begin(), c->h_shids.end(), id);
+        if (o != c->h_shids.end()) { size_t i = o - c->h_shids.begin(); v.na = c->h_sh_nact[i]; v.nst = c->h_sh_nstat[i]; v.exists = true; }
+        return ss.emplace(id, v).first->second;
+    };
+    auto mark_shared = [&](const SharedIdPub &id) { if (carry.changed_shared_set.insert(id).second) carry.changed_shared.push_back(id); };
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < M; i++) {
+        const uint32_t r = movers[i] & 0x7FFFFFFFu;
+        const bool was_static = (c->h_flags[r] & F_STATIC) != 0;
+        // remove_entity (:787-942)
+        if (c->h_row_nk[r] > 1) {
+            SharedIdPub id; id.nk = c->h_row_nk[r]; memcpy(id.keys, c->h_row_shared_keys[r].data(), sizeof id.keys);
+            SS &sh = shared(id);
+            if (was_static) { for (uint32_t k = 0; k < id.nk; k++) carry.changed_static.insert(id.keys[k]); if (sh.nst) sh.nst--; } else if (sh.na) sh.na--;
+            if (sh.na == 0 && sh.nst == 0) {
+                for (uint32_t k = 0; k < id.nk; k++) { CS &cl = cell(id.keys[k]); if (cl.links) cl.links--; if (cl.nl == 0 && cl.ns == 0 && cl.links == 0) cl.exists = false; }
+                sh.exists = false;
+            }
+            mark_shared(id);
+        } else if (c->h_row_nk[r] == 1) {
+            const uint64_t key = c->h_row_key[r];
+            CS &cl = cell(key);
+            if (was_static) { if (cl.ns) cl.ns--; carry.changed_static.insert(key); } else if (cl.nl) cl.nl--;
+            if (cl.nl == 0 && cl.ns == 0 && cl.links == 0) cl.exists = false;
+            else total += carry.changed_cells.count(key) ? 1u : cl.nl + cl.ns;
+            carry.changed_cells.insert(key);
+        }
+        // add_entity with is_static = false (:563-762)
+        if (nk[i] > 1) {
+            SharedIdPub id; id.nk = nk[i]; memcpy(id.keys, &nkeys[(size_t)i * 8], sizeof id.keys);
+            SS &sh = shared(id);
+            if (!sh.exists) { sh = SS{ 0, 0, true }; for (uint32_t k = 0; k < id.nk; k++) { CS &cl = cell(id.keys[k]); if (!cl.exists) cl = CS{ 0, 0, 0, true }; cl.links++; } }
+            sh.na++;
+            mark_shared(id);
+            std::array<uint64_t, 8> a; memcpy(a.data(), id.keys, sizeof id.keys); c->h_row_shared_keys[r] = a;
+            c->h_row_key[r] = id.keys[0];
+        } else if (nk[i] == 1) {
+            const uint64_t key = nkeys[(size_t)i * 8];
+            CS &cl = cell(key);
+            if (cl.exists) { cl.nl++; total += carry.changed_cells.count(key) ? 1u : cl.nl + cl.ns; }
+            else { cl = CS{ 1, 0, 0, true }; total += 1; }
+            carry.changed_cells.insert(key);
+            c->h_row_shared_keys.erase(r);
+            c->h_row_key[r] = key;
+        }
+        c->h_row_nk[r] = nk[i];
+        c->h_flags[r] &= ~F_STATIC;
+    }
+    carry.too_many = total > 500;
+    // ---- rebuild the key-sorted arrays from the patched per-row decisions
+    std::vector<SharedRec> shrec; shrec.reserve(c->h_row_shared_keys.size());
+    for (auto &kv : c->h_row_shared_keys) { SharedRec sr; sr.row = kv.first; sr.nk = c->h_row_nk[kv.first]; memcpy(sr.keys, kv.second.data(), sizeof sr.keys); shrec.push_back(sr); }
+    std::vector<uint32_t> flags(c->h_flags);
+    int rc = build_sections(c, c->h_row_key, c->h_row_nk, shrec, flags, &carry);
+    if (rc != RE_OK) return rc;
+    c->n_rebuilds++;
+    return RE_OK;
+}
+
 static int finish_tick(re_ctx *c, re_tick_result *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tick_inflight = false;
     if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
-    if (c->ndyn) { c->n_dead += c->h_th->n_oob; c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
+    if (c->ndyn) {
+        c->n_dead += c->h_th->n_oob; c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob;
+        if (c->h_th->n_rebucket) { uint32_t m = c->h_th->n_rebucket; c->h_th->n_rebucket = 0; int rc = rebucket(c, m); if (rc != RE_OK) return rc; }
+    }
     else c->last_tick = re_tick_result{ 0, 0, 0 };
     if (out) *out = c->last_tick;
     return RE_OK;

@@ -105,6 +105,9 @@ __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, c
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th);
+__global__ void k_assign_rows(uint32_t m, const uint32_t *rows, RowArrays R, uint32_t outline, uint32_t atomic, uint8_t *out_nk, uint64_t *out_keys);
+__global__ void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
+                                    const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many, const uint8_t *refold, const Aabb *carried);
 __global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
 
 }  // namespace re

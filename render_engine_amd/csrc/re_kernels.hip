@@ -811,8 +811,43 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
     }
     if (!same) {
         uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
-        if (slot < list_cap) mover_rows[slot] = r;
+        if (slot < list_cap) mover_rows[slot] = r | ((pos_set && !rot_set) ? 0x80000000u : 0u);   // bit 31: translation-only mover
     }
+}
+
+// section decision (add_entity with add_if_out_bounds = true: the box is clamped) for a list of rows, from their current StaticAABB;
+// also clears RE_F_STATIC: update_entity_in_tree re-adds movers with is_static = false (entity_change_helpers.rs:330)
+__global__ __launch_bounds__(256) void k_assign_rows(uint32_t m, const uint32_t *__restrict__ rows, RowArrays R, uint32_t outline, uint32_t atomic,
+                                                     uint8_t *__restrict__ out_nk, uint64_t *__restrict__ out_keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t r = rows[i] & 0x7FFFFFFFu;
+    Aabb bv = R.aabb[r];
+    normalize_aabb(&bv, (float)outline);
+    uint64_t keys[8];
+    int nk = assign_sections(bv, atomic, keys);
+    if (nk < 0) nk = 0;
+    out_nk[i] = (uint8_t)nk;
+    for (int k = 0; k < 8; k++) out_keys[(size_t)i * 8 + k] = k < nk ? keys[k] : 0ull;
+    R.flags[r] &= ~F_STATIC;
+}
+// end_of_changes restricted to the changed sections of an incremental update: unchanged sections keep their (possibly stale) AABB
+__global__ __launch_bounds__(256) void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
+                                                           const uint32_t *cell_nstatic, const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight,
+                                                           uint32_t atomic, int too_many, const uint8_t *refold, const Aabb *carried) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncells) return;
+    if (!refold[c]) { cell_tight[c] = carried[c]; return; }
+    uint64_t key = cell_key[c];
+    uint32_t n = cell_nlocal[c] + cell_nstatic[c];
+    uint32_t adj = 20u + key_level(key) * 5u; if (adj > 50u) adj = 50u;
+    Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (too_many && n > adj) u = key_to_aabb(key, atomic);
+    else {
+        uint32_t b = cell_begin[c];
+        for (uint32_t i = 0; i < n; i++) { Aabb e = ent_aabb[rows[b + i]]; u = (i == 0) ? e : combine_aabb(u, e); }
+    }
+    cell_tight[c] = u;
 }
 
 // gathers the visible sections of the last cull for re_debug_get_visible_sections

@@ -192,6 +192,29 @@ def test_async_frames_match_sync(R):
     p.close(); w.close()
 
 
+def test_movers_rebucket_parity(R):
+    """entities that leave their world section (unique <-> unique, unique <-> shared, new and emptied sections): the section table,
+    tight AABBs (stale ones included), static flags, visible set and matrices must follow the reference's apply_change semantics"""
+    ents = R.synthetic.mixed_world(3000, seed=21, spread=600.0)
+    ents["vel"] *= 12.0                                              # fast movers: many section changes per tick
+    p, w = build_pair(R, ents)
+    check_sections(p, w)
+    cams = [R.Camera((8192 + 25 * i, 8192 - 10 * i, 8600 - 30 * i), (0, 0, -1), 1500.0) for i in range(6)]
+    moved = 0
+    for cam in cams:
+        check_frame(R, p, w, cam, False)
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.05)
+        t = p.tick(0.05)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        moved += t["n_rebucket"]
+        check_sections(p, w)
+        s = p.stats()
+        assert s["n_shared_sections"] == w.L.ro_num_shared(w.h)
+    assert moved > 50
+    check_entities(R, p, w, ents[:500])
+    p.close(); w.close()
+
+
 def test_truncation_reports(R):
     ents = R.synthetic.lattice_world(cells_per_axis=24, first_cell=116)
     p = R.Pipeline(16384, 64, max_instances=100)
