@@ -212,6 +212,37 @@ int re_get_last_candidates(re_ctx *ctx, uint32_t *n_candidates);
 /* the HIP stream of the ctx (hipStream_t as void*) so callers can order their own work after it */
 void *re_get_stream(re_ctx *ctx);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Deferred lighting (BASELINE.json configs[4]): the second pass of RenderSystem::draw
+ * (render_system/render_system.rs:507-585) as a compute kernel -- the math of
+ * render_engine_assets/shaders/second_pass_frag.glsl:20-139, light uniform arrays as uploaded by
+ * render_system.rs:752-766 (cone "point" lights) and :814-830 (radius "spot" lights).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct re_lighting re_lighting;
+typedef struct { int32_t device; uint32_t width, height, max_spot_lights, max_point_lights; } re_lighting_config;
+typedef struct {
+    uint32_t n_spot, n_point;
+    const float *spot_pos, *spot_diffuse, *spot_specular;                 /* n_spot*3 */
+    const float *spot_ambient;                                            /* n_spot*4 (rgb, a) */
+    const float *spot_linear, *spot_quadratic, *spot_radius;              /* n_spot */
+    const float *point_pos, *point_dir, *point_diffuse, *point_specular;  /* n_point*3 */
+    const float *point_ambient;                                           /* n_point*4 */
+    const float *point_linear, *point_quadratic, *point_cutoff, *point_outer_cutoff;   /* n_point */
+    float camera_pos[3];
+    float no_light_source_cutoff, default_diffuse_factor;                 /* render_system_setup.rs:24-25 */
+    uint32_t any_light_source_visible;
+} re_lights;
+int         re_lighting_create(const re_lighting_config *cfg, re_lighting **out);
+void        re_lighting_destroy(re_lighting *l);
+const char *re_lighting_last_error(const re_lighting *l);
+/* G-buffer of the first pass (prelude/default_render_system.rs:104-107): gPosition / gNormal RGBA32F, gAlbedoSpec RGBA8; host pointers, copied.
+ * gLightPosition is not needed: the shadow value it feeds is discarded by the shader (second_pass_frag.glsl:105). */
+int re_lighting_upload_gbuffer(re_lighting *l, const float *g_position, const float *g_normal, const uint8_t *g_albedo_spec);
+int re_lighting_set_lights(re_lighting *l, const re_lights *lights);
+int re_lighting_run(re_lighting *l, float *kernel_microseconds /* nullable */);      /* FragColor RGBA32F stays in HBM */
+int re_lighting_read(re_lighting *l, float *out_rgba);                                 /* width*height*4 floats */
+int re_lighting_read_pixels(re_lighting *l, const uint32_t *pixel_index, uint32_t n, float *out_rgba);
+
 #ifdef __cplusplus
 }
 #endif

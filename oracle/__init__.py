@@ -40,6 +40,29 @@ class Camera(C.Structure):
                 ("n_lod", C.c_uint32), ("lod_min", C.c_float * 8), ("lod_max", C.c_float * 8)]
 
 
+class LightsC(C.Structure):
+    _fields_ = [("n_spot", C.c_uint32), ("n_point", C.c_uint32)] + \
+               [(n, C.POINTER(C.c_float)) for n in ("spot_pos", "spot_diffuse", "spot_specular", "spot_ambient", "spot_linear", "spot_quadratic", "spot_radius",
+                                                     "point_pos", "point_dir", "point_diffuse", "point_specular", "point_ambient", "point_linear", "point_quadratic",
+                                                     "point_cutoff", "point_outer_cutoff")] + \
+               [("camera_pos", C.c_float * 3), ("no_light_source_cutoff", C.c_float), ("default_diffuse_factor", C.c_float), ("any_light_source_visible", C.c_uint32)]
+
+
+def deferred_lighting(pos, nrm, alb, lights_struct, idx=None):
+    """CPU evaluation of second_pass_frag.glsl for all pixels, or only the pixel indices in idx."""
+    pos = np.ascontiguousarray(pos, np.float32); nrm = np.ascontiguousarray(nrm, np.float32); alb = np.ascontiguousarray(alb, np.uint8)
+    npix = pos.shape[0]
+    L = lib()
+    L.ro_deferred_lighting.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(LightsC), C.c_void_p, C.c_uint32, C.c_void_p]
+    if idx is None:
+        out = np.zeros((npix, 4), np.float32)
+        L.ro_deferred_lighting(npix, pos.ctypes.data, nrm.ctypes.data, alb.ctypes.data, C.byref(lights_struct), None, 0, out.ctypes.data)
+    else:
+        idx = np.ascontiguousarray(idx, np.uint32); out = np.zeros((len(idx), 4), np.float32)
+        L.ro_deferred_lighting(npix, pos.ctypes.data, nrm.ctypes.data, alb.ctypes.data, C.byref(lights_struct), idx.ctypes.data, len(idx), out.ctypes.data)
+    return out
+
+
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("re_oracle.c", "re_oracle.h")):

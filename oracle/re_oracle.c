@@ -1288,3 +1288,96 @@ uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt, uint32_t cap
     if (n_oob) *n_oob = noob;
     return napplied;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * config 5: deferred lighting -- second_pass_frag.glsl main() and helpers, evaluated per pixel
+ * in f32 over ALL lights in index order (no culling).
+ * ---------------------------------------------------------------------------------------- */
+static void v3_normalize(const float v[3], float o[3]) { float n = sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n; }
+static float v3_dot(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
+static float v3_len(const float a[3]) { return sqrtf(v3_dot(a, a)); }
+static float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+/* calculateSpecular (:124-130) */
+static void gl_specular(const float frag[3], const float ldir[3], const float spec[3], const float n[3], const float cam[3], float out[3]) {
+    float cd[3] = { cam[0] - frag[0], cam[1] - frag[1], cam[2] - frag[2] }, cdn[3], h[3], hn[3];
+    v3_normalize(cd, cdn);
+    h[0] = ldir[0] + cdn[0]; h[1] = ldir[1] + cdn[1]; h[2] = ldir[2] + cdn[2];
+    v3_normalize(h, hn);
+    float f = powf(fmaxf(v3_dot(n, hn), 0.0f), 64.0f);
+    out[0] = spec[0] * f; out[1] = spec[1] * f; out[2] = spec[2] * f;
+}
+/* calculateAttenuation (:132-136) */
+static float gl_attenuation(const float frag[3], float lin, float quad, const float lp[3]) {
+    float d[3] = { lp[0] - frag[0], lp[1] - frag[1], lp[2] - frag[2] };
+    float dist = v3_len(d);
+    return 1.0f / (1.0f + lin * dist + quad * dist * dist);
+}
+/* calculateSpotLights (:93-114); the shadow value is computed and discarded in the shader */
+static void gl_spot(const ro_lights *L, const float frag[3], const float n[3], const float od[3], float acc[3]) {
+    acc[0] = acc[1] = acc[2] = 0.0f;
+    for (uint32_t i = 0; i < L->n_spot; i++) {
+        const float *lp = L->spot_pos + 3 * i;
+        float d[3] = { lp[0] - frag[0], lp[1] - frag[1], lp[2] - frag[2] };
+        if (v3_len(d) > L->spot_radius[i]) continue;
+        float nd[3]; v3_normalize(d, nd);
+        float att = gl_attenuation(frag, L->spot_linear[i], L->spot_quadratic[i], lp);
+        const float *am = L->spot_ambient + 4 * i, *df = L->spot_diffuse + 3 * i, *sp = L->spot_specular + 3 * i;
+        float dc = fmaxf(v3_dot(n, nd), 0.0f), spec[3];
+        gl_specular(frag, nd, sp, n, L->camera_pos, spec);
+        for (int k = 0; k < 3; k++) {
+            acc[k] += (od[k] * am[k] * am[3]) * att;            /* calculateAmbient * attenuation */
+            acc[k] += (df[k] * od[k] * dc) * att;               /* calculateDiffuse * attenuation */
+            acc[k] += spec[k] * att;
+        }
+    }
+}
+/* calculatePointLights (:72-91): the cone term uses normalize(fragPosition) - lightPosition */
+static void gl_point(const ro_lights *L, const float frag[3], const float n[3], const float od[3], float acc[3]) {
+    acc[0] = acc[1] = acc[2] = 0.0f;
+    float fn[3]; v3_normalize(frag, fn);
+    for (uint32_t i = 0; i < L->n_point; i++) {
+        const float *lp = L->point_pos + 3 * i;
+        float dirn[3]; v3_normalize(L->point_dir + 3 * i, dirn);
+        float a[3] = { fn[0] - lp[0], fn[1] - lp[1], fn[2] - lp[2] };
+        float angle = v3_dot(a, dirn);
+        float eps = L->point_cutoff[i] - L->point_outer_cutoff[i];
+        float intensity = clampf((angle - L->point_outer_cutoff[i]) / eps, 0.0f, 1.0f);
+        float d[3] = { lp[0] - frag[0], lp[1] - frag[1], lp[2] - frag[2] }, nd[3];
+        v3_normalize(d, nd);
+        float att = gl_attenuation(frag, L->point_linear[i], L->point_quadratic[i], lp);
+        const float *am = L->point_ambient + 4 * i, *df = L->point_diffuse + 3 * i, *sp = L->point_specular + 3 * i;
+        float dc = fmaxf(v3_dot(n, nd), 0.0f), spec[3];
+        gl_specular(frag, nd, sp, n, L->camera_pos, spec);
+        for (int k = 0; k < 3; k++) {
+            acc[k] += (od[k] * am[k] * am[3]) * att;
+            acc[k] += (df[k] * od[k] * dc) * att * intensity;
+            acc[k] += spec[k] * att;
+        }
+    }
+}
+void ro_deferred_lighting(uint32_t npix, const float *gpos, const float *gnormal, const uint8_t *galbedo, const ro_lights *L,
+                          const uint32_t *idx, uint32_t n, float *out) {
+    uint32_t count = idx ? n : npix;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (long j = 0; j < (long)count; j++) {
+        uint32_t p = idx ? idx[j] : (uint32_t)j;
+        float od[3] = { galbedo[4 * p] / 255.0f, galbedo[4 * p + 1] / 255.0f, galbedo[4 * p + 2] / 255.0f };
+        float c[3];
+        if (!L->any_light_source_visible) {                      /* :30-34: ambient with vec4(1,1,1,defaultDiffuseFactor) */
+            for (int k = 0; k < 3; k++) c[k] = od[k] * 1.0f * L->default_diffuse_factor;
+        } else {
+            const float *frag = gpos + 4 * p, *nrm = gnormal + 4 * p;
+            float s1[3], pt[3], s2[3];
+            gl_spot(L, frag, nrm, od, s1); gl_point(L, frag, nrm, od, pt); gl_spot(L, frag, nrm, od, s2);   /* :42-44: the spot term twice */
+            for (int k = 0; k < 3; k++) {
+                float v = s1[k]; v += pt[k]; v += s2[k];
+                v += (float)(v < L->no_light_source_cutoff) * od[k] * L->default_diffuse_factor;
+                c[k] = clampf(v, 0.0f, 1.0f);
+            }
+        }
+        out[4 * j] = c[0]; out[4 * j + 1] = c[1]; out[4 * j + 2] = c[2]; out[4 * j + 3] = 1.0f;
+    }
+}

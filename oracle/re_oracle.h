@@ -167,6 +167,25 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
 uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt,
                        uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
 
+/* ---- config 5: deferred lighting, CPU evaluation of render_engine_assets/shaders/second_pass_frag.glsl:20-139 ----
+ * Light uniform arrays as RenderSystem uploads them (render_system/render_system.rs:752-766, 814-830). */
+typedef struct {
+    uint32_t n_spot, n_point;
+    const float *spot_pos;      /* n_spot*3 */
+    const float *spot_diffuse, *spot_specular;   /* n_spot*3 each */
+    const float *spot_ambient;  /* n_spot*4 (rgb, a) */
+    const float *spot_linear, *spot_quadratic, *spot_radius;   /* n_spot each */
+    const float *point_pos, *point_dir, *point_diffuse, *point_specular;   /* n_point*3 each */
+    const float *point_ambient; /* n_point*4 */
+    const float *point_linear, *point_quadratic, *point_cutoff, *point_outer_cutoff;   /* n_point each */
+    float camera_pos[3];
+    float no_light_source_cutoff, default_diffuse_factor;
+    uint32_t any_light_source_visible;
+} ro_lights;
+/* gpos/gnormal: RGBA32F (4 floats per pixel), galbedo: RGBA8; out: RGBA32F.  Only pixels listed in idx (n of them) when idx != NULL. */
+void ro_deferred_lighting(uint32_t npix, const float *gpos, const float *gnormal, const uint8_t *galbedo, const ro_lights *L,
+                          const uint32_t *idx, uint32_t n, float *out);
+
 #ifdef __cplusplus
 }
 #endif

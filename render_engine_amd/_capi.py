@@ -55,11 +55,25 @@ class Stats(C.Structure):
                 ("n_shared_sections", C.c_uint32), ("max_level", C.c_uint32), ("device_bytes", C.c_uint64)]
 
 
+class LightingConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("max_spot_lights", C.c_uint32), ("max_point_lights", C.c_uint32)]
+
+
+class Lights(C.Structure):
+    _fields_ = [("n_spot", C.c_uint32), ("n_point", C.c_uint32)] + \
+               [(n, _fp) for n in ("spot_pos", "spot_diffuse", "spot_specular", "spot_ambient", "spot_linear", "spot_quadratic", "spot_radius",
+                                   "point_pos", "point_dir", "point_diffuse", "point_specular", "point_ambient", "point_linear", "point_quadratic",
+                                   "point_cutoff", "point_outer_cutoff")] + \
+               [("camera_pos", C.c_float * 3), ("no_light_source_cutoff", C.c_float), ("default_diffuse_factor", C.c_float), ("any_light_source_visible", C.c_uint32)]
+
+
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
            "re_wait", "re_copy_visible", "re_set_output_buffers", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
-           "re_timing_begin", "re_timing_collect", "re_get_last_candidates"]
+           "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
+           "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
+           "re_lighting_run", "re_lighting_read", "re_lighting_read_pixels"]
 
 _lib = None
 
@@ -99,5 +113,13 @@ def load():
     L.re_timing_begin.restype = C.c_int; L.re_timing_begin.argtypes = [vp, C.c_uint32]
     L.re_timing_collect.restype = C.c_int; L.re_timing_collect.argtypes = [vp, vp, C.c_uint32, _u32p]
     L.re_get_last_candidates.restype = C.c_int; L.re_get_last_candidates.argtypes = [vp, _u32p]
+    L.re_lighting_create.restype = C.c_int; L.re_lighting_create.argtypes = [C.POINTER(LightingConfig), C.POINTER(vp)]
+    L.re_lighting_destroy.restype = None; L.re_lighting_destroy.argtypes = [vp]
+    L.re_lighting_last_error.restype = C.c_char_p; L.re_lighting_last_error.argtypes = [vp]
+    L.re_lighting_upload_gbuffer.restype = C.c_int; L.re_lighting_upload_gbuffer.argtypes = [vp, vp, vp, vp]
+    L.re_lighting_set_lights.restype = C.c_int; L.re_lighting_set_lights.argtypes = [vp, C.POINTER(Lights)]
+    L.re_lighting_run.restype = C.c_int; L.re_lighting_run.argtypes = [vp, _fp]
+    L.re_lighting_read.restype = C.c_int; L.re_lighting_read.argtypes = [vp, vp]
+    L.re_lighting_read_pixels.restype = C.c_int; L.re_lighting_read_pixels.argtypes = [vp, vp, C.c_uint32, vp]
     _lib = L
     return L

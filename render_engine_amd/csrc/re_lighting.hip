@@ -1,0 +1,262 @@
+// re_lighting.hip -- BASELINE.json configs[4]: the deferred-lighting second pass of render_engine
+// (render_engine_assets/shaders/second_pass_frag.glsl:20-139) as a HIP compute kernel for gfx950, plus its C ABI.
+//
+// Tiled deferred shading.  One 256-thread workgroup owns a 32x32-pixel tile (4 pixels per lane):
+//   1. tile AABB of the G-buffer positions (wave shuffles + LDS),
+//   2. exact-conservative culling of the radius ("spot") lights against the tile AABB, 256 lights per round, compacted
+//      into an LDS list in ascending light index (ballot + prefix: the per-pixel summation order is deterministic),
+//   3. every lane shades its 4 pixels over the list; the light record (64 B) is fetched with scalar loads
+//      (wave-uniform index), so the inner loop is pure f32 VALU -- the kernel is VALU-bound, not HBM-bound,
+//   4. cone ("point") lights cannot be culled (no radius in the shader) and are evaluated for every pixel,
+//   5. epilogue exactly as main(): (spot + point) + spot -- the spot term is added twice in the shader --, the
+//      default-diffuse floor, clamp.
+// gLightPosition is not read: the shadow value it feeds is computed and discarded by the shader (:105).
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "re_hip.h"
+
+namespace {
+
+constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 512;
+
+struct LightParams {
+    uint32_t width, height, n_spot, n_point;
+    float cam[3]; float cutoff, default_diffuse; uint32_t any_visible;
+};
+
+__device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
+__device__ __forceinline__ float dot3(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float3 sub3(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 norm3v(float3 v) { float n = sqrtf(dot3(v, v)); return f3(v.x / n, v.y / n, v.z / n); }
+__device__ __forceinline__ float pow64(float x) { x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; return x; }
+
+// one light's contribution to one pixel; A = (pos, radius|unused), B = (diffuse, linear), C = (specular, quadratic), D = ambient rgba
+__device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3 camdir, float4 A, float4 B, float4 C, float4 D, bool radius_cut, float intensity, float3 &acc) {
+    float3 d = sub3(f3(A.x, A.y, A.z), frag);
+    float dist = sqrtf(dot3(d, d));
+    if (radius_cut && dist > A.w) return;                                      // :97-100
+    float3 nd = f3(d.x / dist, d.y / dist, d.z / dist);
+    float att = 1.0f / (1.0f + B.w * dist + C.w * dist * dist);                // calculateAttenuation :132-136
+    float dc = fmaxf(dot3(nrm, nd), 0.0f);                                     // calculateDiffuse :118-122
+    float3 h = norm3v(f3(nd.x + camdir.x, nd.y + camdir.y, nd.z + camdir.z));  // calculateSpecular :124-130
+    float sf = pow64(fmaxf(dot3(nrm, h), 0.0f));
+    acc.x += (od.x * D.x * D.w) * att; acc.x += (B.x * od.x * dc) * att * intensity; acc.x += (C.x * sf) * att;
+    acc.y += (od.y * D.y * D.w) * att; acc.y += (B.y * od.y * dc) * att * intensity; acc.y += (C.y * sf) * att;
+    acc.z += (od.z * D.z * D.w) * att; acc.z += (B.z * od.z * dc) * att * intensity; acc.z += (C.z * sf) * att;
+}
+
+__global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P, const float4 *__restrict__ gpos, const float4 *__restrict__ gnormal, const uchar4 *__restrict__ galbedo,
+                                                                   const float4 *__restrict__ spot,     // 4 float4 per light: A, B, C, D
+                                                                   const float4 *__restrict__ point,    // 5 float4 per light: A(pos), B, C, D, E(dir.xyz normalised, -) + F(cutoff, outer, -, -) packed as 6
+                                                                   float4 *__restrict__ out) {
+    __shared__ float s_red[4][6];
+    __shared__ uint32_t s_list[LIST_CAP];
+    __shared__ uint32_t s_wcnt[4];
+    __shared__ uint32_t s_n;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t tx = blockIdx.x * TILE + (tid & 31u), ty0 = blockIdx.y * TILE + (tid >> 5);
+    float3 frag[4], nrm[4], od[4], camdir[4], acc[4]; bool live[4];
+    float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t y = ty0 + 8u * k;
+        live[k] = tx < P.width && y < P.height;
+        frag[k] = nrm[k] = od[k] = camdir[k] = f3(0.f, 0.f, 0.f); acc[k] = f3(0.f, 0.f, 0.f);
+        if (live[k]) {
+            size_t p = (size_t)y * P.width + tx;
+            float4 gp = gpos[p], gn = gnormal[p]; uchar4 ga = galbedo[p];
+            frag[k] = f3(gp.x, gp.y, gp.z); nrm[k] = f3(gn.x, gn.y, gn.z);
+            od[k] = f3(ga.x / 255.0f, ga.y / 255.0f, ga.z / 255.0f);
+            camdir[k] = norm3v(sub3(f3(P.cam[0], P.cam[1], P.cam[2]), frag[k]));
+            lo[0] = fminf(lo[0], gp.x); lo[1] = fminf(lo[1], gp.y); lo[2] = fminf(lo[2], gp.z);
+            hi[0] = fmaxf(hi[0], gp.x); hi[1] = fmaxf(hi[1], gp.y); hi[2] = fmaxf(hi[2], gp.z);
+        }
+    }
+    if (P.any_visible) {
+        // ---- tile AABB ----
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            for (int d = 32; d >= 1; d >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64)); }
+        if (lane == 0) for (int a = 0; a < 3; a++) { s_red[wid][a] = lo[a]; s_red[wid][3 + a] = hi[a]; }
+        if (tid == 0) s_n = 0;
+        __syncthreads();
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a])); hi[a] = fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a])); }
+        // ---- radius lights: cull 256 per round into the ordered LDS list, shade whenever the list could overflow ----
+        float3 spot_acc[4]; for (int k = 0; k < 4; k++) spot_acc[k] = f3(0.f, 0.f, 0.f);
+        for (uint32_t i0 = 0; i0 < P.n_spot; i0 += LT_THREADS) {
+            uint32_t li = i0 + tid; bool hit = false;
+            if (li < P.n_spot) {
+                float4 A = spot[(size_t)li * 4];
+                float dx = fmaxf(fmaxf(lo[0] - A.x, A.x - hi[0]), 0.0f), dy = fmaxf(fmaxf(lo[1] - A.y, A.y - hi[1]), 0.0f), dz = fmaxf(fmaxf(lo[2] - A.z, A.z - hi[2]), 0.0f);
+                float r = A.w * 1.00001f + 1e-3f;                                  // conservative: the exact per-pixel radius test follows
+                hit = ((dx * dx + dy * dy) + dz * dz) <= r * r;
+            }
+            uint64_t m = __ballot(hit);
+            if (lane == 0) s_wcnt[wid] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t base = s_n, tot = 0;
+            for (uint32_t w = 0; w < 4; w++) { if (w < wid) base += s_wcnt[w]; tot += s_wcnt[w]; }
+            if (hit) s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = li;
+            __syncthreads();
+            uint32_t n = s_n + tot;
+            const bool last = i0 + LT_THREADS >= P.n_spot;
+            if (n + LT_THREADS > LIST_CAP || last) {                            // uniform decision
+                for (uint32_t j = 0; j < n; j++) {
+                    uint32_t l = __builtin_amdgcn_readfirstlane(s_list[j]);
+                    float4 A = spot[(size_t)l * 4], B = spot[(size_t)l * 4 + 1], C = spot[(size_t)l * 4 + 2], D = spot[(size_t)l * 4 + 3];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (live[k]) shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, true, 1.0f, spot_acc[k]);
+                }
+                n = 0;
+            }
+            __syncthreads();
+            if (tid == 0) s_n = n;
+            __syncthreads();
+        }
+        // ---- cone lights (calculatePointLights :72-91): no radius, every pixel evaluates every light ----
+        float3 point_acc[4]; for (int k = 0; k < 4; k++) point_acc[k] = f3(0.f, 0.f, 0.f);
+        for (uint32_t l = 0; l < P.n_point; l++) {
+            float4 A = point[(size_t)l * 6], B = point[(size_t)l * 6 + 1], C = point[(size_t)l * 6 + 2], D = point[(size_t)l * 6 + 3], E = point[(size_t)l * 6 + 4], F = point[(size_t)l * 6 + 5];
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (live[k]) {
+                float3 fn = norm3v(frag[k]);
+                float angle = dot3(sub3(fn, f3(A.x, A.y, A.z)), f3(E.x, E.y, E.z));
+                float intensity = fminf(fmaxf((angle - F.y) / (F.x - F.y), 0.0f), 1.0f);
+                shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, false, intensity, point_acc[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // main() :42-44: lightColour = spot; lightColour += point; lightColour += spot
+            acc[k].x = (spot_acc[k].x + point_acc[k].x) + spot_acc[k].x; acc[k].y = (spot_acc[k].y + point_acc[k].y) + spot_acc[k].y; acc[k].z = (spot_acc[k].z + point_acc[k].z) + spot_acc[k].z;
+            acc[k].x += (acc[k].x < P.cutoff ? 1.0f : 0.0f) * od[k].x * P.default_diffuse;
+            acc[k].y += (acc[k].y < P.cutoff ? 1.0f : 0.0f) * od[k].y * P.default_diffuse;
+            acc[k].z += (acc[k].z < P.cutoff ? 1.0f : 0.0f) * od[k].z * P.default_diffuse;
+            acc[k].x = fminf(fmaxf(acc[k].x, 0.0f), 1.0f); acc[k].y = fminf(fmaxf(acc[k].y, 0.0f), 1.0f); acc[k].z = fminf(fmaxf(acc[k].z, 0.0f), 1.0f);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc[k] = f3(od[k].x * 1.0f * P.default_diffuse, od[k].y * 1.0f * P.default_diffuse, od[k].z * 1.0f * P.default_diffuse);   // :30-34
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (live[k]) out[(size_t)(ty0 + 8u * k) * P.width + tx] = make_float4(acc[k].x, acc[k].y, acc[k].z, 1.0f);
+}
+
+__global__ void k_gather_pixels(const float4 *img, const uint32_t *idx, uint32_t n, float4 *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = img[idx[i]];
+}
+
+}  // namespace
+
+struct re_lighting {
+    re_lighting_config cfg{};
+    hipStream_t stream = nullptr;
+    std::string err;
+    float4 *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr, *d_spot = nullptr, *d_point = nullptr; uchar4 *d_alb = nullptr;
+    LightParams P{};
+    int fail(int code, const char *fmt, ...) { char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); err = buf; return code; }
+};
+static thread_local std::string g_lt_error;
+#define LCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (ctx)->fail(RE_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+extern "C" const char *re_lighting_last_error(const re_lighting *l) { return l ? l->err.c_str() : g_lt_error.c_str(); }
+
+extern "C" int re_lighting_create(const re_lighting_config *cfg, re_lighting **out) {
+    if (!cfg || !out || !cfg->width || !cfg->height) { g_lt_error = "re_lighting_create: bad argument"; return RE_E_ARG; }
+    int ndev = 0; hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) { g_lt_error = std::string("re_lighting_create: no HIP device (") + hipGetErrorString(e) + "); no CPU path"; return RE_E_HIP; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_lt_error = "re_lighting_create: device ordinal out of range"; return RE_E_ARG; }
+    re_lighting *l = new re_lighting(); l->cfg = *cfg;
+    size_t np = (size_t)cfg->width * cfg->height;
+    if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&l->d_pos, np * 16) != hipSuccess || hipMalloc(&l->d_nrm, np * 16) != hipSuccess || hipMalloc(&l->d_out, np * 16) != hipSuccess || hipMalloc(&l->d_alb, np * 4) != hipSuccess ||
+        hipMalloc(&l->d_spot, (size_t)(cfg->max_spot_lights + 1) * 64) != hipSuccess || hipMalloc(&l->d_point, (size_t)(cfg->max_point_lights + 1) * 96) != hipSuccess) {
+        g_lt_error = "re_lighting_create: device allocation failed"; delete l; return RE_E_HIP;
+    }
+    l->P.width = cfg->width; l->P.height = cfg->height;
+    *out = l; return RE_OK;
+}
+extern "C" void re_lighting_destroy(re_lighting *l) {
+    if (!l) return;
+    (void)hipSetDevice(l->cfg.device);
+    if (l->stream) (void)hipStreamSynchronize(l->stream);
+    (void)hipFree(l->d_pos); (void)hipFree(l->d_nrm); (void)hipFree(l->d_out); (void)hipFree(l->d_alb); (void)hipFree(l->d_spot); (void)hipFree(l->d_point);
+    if (l->stream) (void)hipStreamDestroy(l->stream);
+    delete l;
+}
+extern "C" int re_lighting_upload_gbuffer(re_lighting *l, const float *g_position, const float *g_normal, const uint8_t *g_albedo_spec) {
+    if (!l || !g_position || !g_normal || !g_albedo_spec) return RE_E_ARG;
+    LCHK(l, hipSetDevice(l->cfg.device));
+    size_t np = (size_t)l->cfg.width * l->cfg.height;
+    LCHK(l, hipMemcpyAsync(l->d_pos, g_position, np * 16, hipMemcpyHostToDevice, l->stream));
+    LCHK(l, hipMemcpyAsync(l->d_nrm, g_normal, np * 16, hipMemcpyHostToDevice, l->stream));
+    LCHK(l, hipMemcpyAsync(l->d_alb, g_albedo_spec, np * 4, hipMemcpyHostToDevice, l->stream));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    return RE_OK;
+}
+extern "C" int re_lighting_set_lights(re_lighting *l, const re_lights *L) {
+    if (!l || !L) return RE_E_ARG;
+    if (L->n_spot > l->cfg.max_spot_lights || L->n_point > l->cfg.max_point_lights) return l->fail(RE_E_CAPACITY, "more lights than configured");
+    LCHK(l, hipSetDevice(l->cfg.device));
+    std::vector<float> s((size_t)L->n_spot * 16), p((size_t)L->n_point * 24);
+    for (uint32_t i = 0; i < L->n_spot; i++) {
+        float *o = &s[(size_t)i * 16];
+        o[0] = L->spot_pos[3 * i]; o[1] = L->spot_pos[3 * i + 1]; o[2] = L->spot_pos[3 * i + 2]; o[3] = L->spot_radius[i];
+        o[4] = L->spot_diffuse[3 * i]; o[5] = L->spot_diffuse[3 * i + 1]; o[6] = L->spot_diffuse[3 * i + 2]; o[7] = L->spot_linear[i];
+        o[8] = L->spot_specular[3 * i]; o[9] = L->spot_specular[3 * i + 1]; o[10] = L->spot_specular[3 * i + 2]; o[11] = L->spot_quadratic[i];
+        o[12] = L->spot_ambient[4 * i]; o[13] = L->spot_ambient[4 * i + 1]; o[14] = L->spot_ambient[4 * i + 2]; o[15] = L->spot_ambient[4 * i + 3];
+    }
+    for (uint32_t i = 0; i < L->n_point; i++) {
+        float *o = &p[(size_t)i * 24];
+        o[0] = L->point_pos[3 * i]; o[1] = L->point_pos[3 * i + 1]; o[2] = L->point_pos[3 * i + 2]; o[3] = 0.f;
+        o[4] = L->point_diffuse[3 * i]; o[5] = L->point_diffuse[3 * i + 1]; o[6] = L->point_diffuse[3 * i + 2]; o[7] = L->point_linear[i];
+        o[8] = L->point_specular[3 * i]; o[9] = L->point_specular[3 * i + 1]; o[10] = L->point_specular[3 * i + 2]; o[11] = L->point_quadratic[i];
+        o[12] = L->point_ambient[4 * i]; o[13] = L->point_ambient[4 * i + 1]; o[14] = L->point_ambient[4 * i + 2]; o[15] = L->point_ambient[4 * i + 3];
+        const float *d = L->point_dir + 3 * i; float n = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);     // normalize(pointLightDirection[i])
+        o[16] = d[0] / n; o[17] = d[1] / n; o[18] = d[2] / n; o[19] = 0.f;
+        o[20] = L->point_cutoff[i]; o[21] = L->point_outer_cutoff[i]; o[22] = o[23] = 0.f;
+    }
+    if (L->n_spot) LCHK(l, hipMemcpyAsync(l->d_spot, s.data(), s.size() * 4, hipMemcpyHostToDevice, l->stream));
+    if (L->n_point) LCHK(l, hipMemcpyAsync(l->d_point, p.data(), p.size() * 4, hipMemcpyHostToDevice, l->stream));
+    LCHK(l, hipStreamSynchronize(l->stream));
+    l->P.n_spot = L->n_spot; l->P.n_point = L->n_point;
+    for (int k = 0; k < 3; k++) l->P.cam[k] = L->camera_pos[k];
+    l->P.cutoff = L->no_light_source_cutoff; l->P.default_diffuse = L->default_diffuse_factor; l->P.any_visible = L->any_light_source_visible;
+    return RE_OK;
+}
+extern "C" int re_lighting_run(re_lighting *l, float *kernel_us) {
+    if (!l) return RE_E_ARG;
+    LCHK(l, hipSetDevice(l->cfg.device));
+    hipEvent_t a = nullptr, b = nullptr;
+    if (kernel_us) { LCHK(l, hipEventCreate(&a)); LCHK(l, hipEventCreate(&b)); }
+    dim3 grid((l->cfg.width + TILE - 1) / TILE, (l->cfg.height + TILE - 1) / TILE);
+    hipExtLaunchKernelGGL(k_deferred_lighting, grid, dim3(LT_THREADS), 0, l->stream, a, b, 0, l->P, l->d_pos, l->d_nrm, l->d_alb, l->d_spot, l->d_point, l->d_out);
+    LCHK(l, hipGetLastError());
+    LCHK(l, hipStreamSynchronize(l->stream));
+    if (kernel_us) { float ms = 0; LCHK(l, hipEventElapsedTime(&ms, a, b)); *kernel_us = ms * 1000.f; (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+    return RE_OK;
+}
+extern "C" int re_lighting_read(re_lighting *l, float *out_rgba) {
+    if (!l || !out_rgba) return RE_E_ARG;
+    LCHK(l, hipSetDevice(l->cfg.device));
+    LCHK(l, hipMemcpy(out_rgba, l->d_out, (size_t)l->cfg.width * l->cfg.height * 16, hipMemcpyDeviceToHost));
+    return RE_OK;
+}
+extern "C" int re_lighting_read_pixels(re_lighting *l, const uint32_t *idx, uint32_t n, float *out_rgba) {
+    if (!l || !idx || !out_rgba) return RE_E_ARG;
+    LCHK(l, hipSetDevice(l->cfg.device));
+    uint32_t *d_idx = nullptr; float4 *d_o = nullptr;
+    LCHK(l, hipMalloc(&d_idx, (size_t)n * 4 + 4)); LCHK(l, hipMalloc(&d_o, (size_t)n * 16 + 16));
+    LCHK(l, hipMemcpy(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_gather_pixels, dim3((n + 255) / 256), dim3(256), 0, l->stream, l->d_out, d_idx, n, d_o);
+    LCHK(l, hipStreamSynchronize(l->stream));
+    LCHK(l, hipMemcpy(out_rgba, d_o, (size_t)n * 16, hipMemcpyDeviceToHost));
+    (void)hipFree(d_idx); (void)hipFree(d_o);
+    return RE_OK;
+}
