@@ -99,7 +99,7 @@ struct re_ctx {
     // frame
     uint32_t frame = 0; bool have_cull = false;
     FrameParams P{}; PBoxTable PB{}; DevBuf<FrameParams> d_params;
-    DevBuf<uint32_t> d_wave_count, d_cand; uint32_t nlists = 0, pred_candidates = 0;
+    uint32_t nlists = 0, pred_candidates = 0;             // nlists: 512-key chunks == waves of k_scan_cull
     uint32_t item_cap = 0, out_cap = 0, list_cap = 0;
     DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
     uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0;
@@ -154,7 +154,7 @@ static void free_world(re_ctx *c) {
     c->d_sh_begin.release(a); c->d_sh_nact.release(a); c->d_sh_nstat.release(a); c->d_sh_cached.release(a); c->d_sh_dirty.release(a);
     c->d_gc_model.release(a); c->d_gc_rs.release(a); c->d_gc_sort.release(a); c->d_group_count.release(a); c->d_group_begin.release(a); c->d_group_fill.release(a);
     c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
-    c->d_hdr.release(a); c->d_th.release(a); c->d_wave_count.release(a); c->d_cand.release(a); c->d_params.release(a); c->d_movers.release(a); c->d_oob.release(a);
+    c->d_hdr.release(a); c->d_th.release(a); c->d_params.release(a); c->d_movers.release(a); c->d_oob.release(a);
     if (c->h_res) { (void)hipHostFree(c->h_res); c->h_res = nullptr; }
     if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
     if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
@@ -368,8 +368,6 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     c->nlists = std::max(1u, (((ncells + 1u) >> 1) + 64u * CULL_ITERS - 1u) / (64u * CULL_ITERS));
-    HIPCHK(c, c->d_wave_count.alloc(c->nlists, acct)); HIPCHK(c, c->d_cand.alloc((size_t)c->nlists * WAVE_KEYS, acct));
-    HIPCHK(c, hipMemsetAsync(c->d_wave_count.p, 0, (size_t)c->nlists * 4, st));
     HIPCHK(c, hipStreamSynchronize(st));
     d_refold.release(nullptr); d_carried.release(nullptr);
     if (!carry) { c->dirty_pending = true; c->have_cull = false; }
@@ -579,9 +577,9 @@ static void fill_visible(re_ctx *c, re_visible *out) {
     out->d_matrices = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
 }
 
-static ItemSink item_sink(re_ctx *c, bool sharded) {
+static ItemSink item_sink(re_ctx *c) {
     ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.row_gclass = c->d_gclass.p;
-    K.nshards = sharded ? CURSOR_SHARDS : 1u; K.seg_cap = c->item_cap / K.nshards; return K;
+    K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; return K;
 }
 static SharedArrays shared_arrays(re_ctx *c) {
     SharedArrays S; S.n = c->nsh; S.cells = c->d_sh_cells.p; S.aabb = c->d_sh_aabb.p; S.begin = c->d_sh_begin.p; S.nact = c->d_sh_nact.p; S.nstat = c->d_sh_nstat.p;
@@ -589,8 +587,8 @@ static SharedArrays shared_arrays(re_ctx *c) {
 }
 
 // multi-kernel pack for large visible sets: count -> scan -> scatter
-static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next, bool sharded) {
-    const uint32_t nshards = sharded ? CURSOR_SHARDS : 1u, seg_cap = c->item_cap / nshards;
+static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next) {
+    const uint32_t nshards = CURSOR_SHARDS, seg_cap = c->item_cap / nshards;
     hipStream_t st = c->stream;
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
@@ -611,8 +609,8 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cull_inflight = false;
     if (c->h_res->overflow) {
-        // the single-workgroup pack declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
-        int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u), false);   // the small path filled shard 0 only
+        // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
+        int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u));
         if (rc != RE_OK) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -655,29 +653,26 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
-    PackArgs A{}; A.do_pack = small ? 1u : 0u; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
-    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.do_shared = c->nsh ? 1u : 0u; A.group_begin = c->d_group_begin.p;
-    // K1a: the streaming key scan (the dominant kernel).  hipExtLaunchKernelGGL ties the two events to this
-    // dispatch's own begin/end timestamps.
-    uint32_t scan_grid = (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64);
-    hipExtLaunchKernelGGL(k_scan_keys, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, c->d_cell_key.p, c->ncells, c->PB, c->d_wave_count.p, c->d_cand.p, P, c->d_params.p);
-    // K1b: one wave per 64 candidate lists when few sections are candidates (the usual case), one wave per list otherwise
-    uint32_t lpw = c->pred_candidates <= 65536u ? 64u : 1u;
-    uint32_t cull_waves = (c->nlists + lpw - 1) / lpw;
-    uint32_t cull_grid = std::max(1u, (cull_waves + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
-    hipLaunchKernelGGL(k_cull_sections, dim3(cull_grid), dim3(CULL_THREADS), small ? (size_t)std::max(c->nslots, 1u) * 4 : 0, st, c->d_cell_key.p, c->ncells,
-                       c->d_wave_count.p, c->d_cand.p, c->d_cell_tight.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_flags.p, c->d_cell_stamp.p,
-                       item_sink(c, !small), hdr, hdr_next, c->d_th.p, A, shared_arrays(c), c->d_params.p, lpw);
+    PackArgs A{}; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
+    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres;
+    // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
+    // timing events to this dispatch's own begin/end timestamps.
+    uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
+    ScanCullArgs SA; SA.cell_key = c->d_cell_key.p; SA.ncells = c->ncells; SA.pad = 0; SA.B = c->PB; SA.P = P; SA.P_dev = c->d_params.p;
+    SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p;
+    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c);
+    hipExtLaunchKernelGGL(k_scan_cull, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, SA);
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
-        uint32_t sgrid = std::min(256u, (std::max(c->pred_total, 1u) + 63u) / 64u * 2u + 4u);      // ~2x the predicted instances, 64 per workgroup per pass
-        hipLaunchKernelGGL(k_scatter_ranked, dim3(sgrid), dim3(256), 0, st, hdr, c->d_item_row.p, c->d_item_slot.p, c->item_cap, c->d_group_begin.p, c->d_id.p, c->d_mat.p,
-                           out_ids, out_mats, out_cap);
+        // a few workgroups, ~256 predicted instances each; every workgroup counts all instances, so more workgroups only help the matrix moves
+        uint32_t pgrid = std::min(64u, std::max(c->pred_total, 1u) / 128u + 1u);
+        hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c));
     } else {
-        int rc = launch_pack_large(c, hdr, hdr_next, true);
+        int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;
     }
+    HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[2], st));
     c->have_cull = true; c->cull_inflight = true; c->th_clean = true;
     if (flags & RE_CULL_ASYNC) return RE_OK;
@@ -1001,23 +996,6 @@ extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32
     c->k1_timing = false; c->k1_used = 0;
     return RE_OK;
 }
-// development aid: launches the key-scan kernel alone, back to back, and returns the per-launch device times
-extern "C" int re_debug_bench_cull(re_ctx *c, uint32_t reps, float *us) {
-    if (!c || !c->have_cull || !us) return RE_E_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    HIPCHK(c, hipStreamSynchronize(st));
-    hipEvent_t a, b; HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&b));
-    uint32_t scan_grid = (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64);
-    for (uint32_t i = 0; i < reps; i++) {
-        hipExtLaunchKernelGGL(k_scan_keys, dim3(scan_grid), dim3(CULL_THREADS), 0, st, a, b, 0, c->d_cell_key.p, c->ncells, c->PB, c->d_wave_count.p, c->d_cand.p, c->P, c->d_params.p);
-        HIPCHK(c, hipStreamSynchronize(st));
-        float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, a, b)); us[i] = ms * 1000.f;
-    }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    return RE_OK;
-}
-
 extern "C" int re_debug_get_stamps(re_ctx *c, unsigned long long *out8) { if (!c || !c->h_res || !out8) return RE_E_ARG; memcpy(out8, c->h_res->stamps, 64); return RE_OK; }
 
 extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {

@@ -21,9 +21,7 @@ constexpr uint32_t ROW_CELL_NONE = 0xFFFFFFFFu, ROW_CELL_SHARED = 0x80000000u;
 constexpr int MAX_LEVELS = 16;
 constexpr int CULL_THREADS = 256;
 constexpr int CULL_ITERS = 4;               // 16-byte key loads in flight per lane
-constexpr int CULL_CHUNK = CULL_THREADS * CULL_ITERS * 2;   // 4096 sections per workgroup of k_cull_sections (LDS queue of 16 KiB)
-constexpr uint32_t LDS_HIST_SLOTS = 4096;   // must stay < 2^15 (slot<<16|rank packing)
-constexpr uint32_t LDS_HIST_SLOTS_UNUSED = 0;  // group slots (gclass*8+lod) that fit the LDS histograms
+constexpr uint32_t LDS_HIST_SLOTS = 4096;   // group slots (gclass*8+lod) whose two histograms fit the LDS of k_pack_small
 
 struct RowArrays {                          // one row per entity, in upload order
     uint32_t *id, *gclass, *flags;
@@ -38,7 +36,7 @@ struct LevelBox { uint32_t bx, by, bz, nx, ny, nz; float level_length; uint32_t 
 // inside  <=>  pk_min_u16(pk_sub_u16(word, sub), min) == pk_sub_u16(word, sub) for both words
 struct PBox { uint32_t sub_hi, sub_lo, min_hi, min_lo; };
 struct PBoxTable { PBox box[2][16]; };
-constexpr uint32_t WAVE_KEYS = 64u * 4u * 2u;   // keys one wave of k_cull_sections owns (64 lanes x CULL_ITERS x 2); level runs are padded to it
+constexpr uint32_t WAVE_KEYS = 64u * 4u * 2u;   // keys one wave of k_scan_cull owns (64 lanes x CULL_ITERS x 2); level runs are padded to it
 
 struct FrameParams {
     float planes[24];
@@ -48,24 +46,22 @@ struct FrameParams {
     uint32_t max_level, frame, emit_duplicates, pad;
     LevelBox box[2][MAX_LEVELS];            // [0] logic box, [1] render box, per level
 };
-constexpr uint32_t TICKET_SHARDS = 64;
+constexpr uint32_t COUNTER_SHARDS = 64;
 constexpr uint32_t CURSOR_SHARDS = 8;
 struct FrameHeader {
-    unsigned long long cursors[CURSOR_SHARDS * 8];   // one per 64-byte line; low 32: emitting sections, high 32: instances.  Shard 0 alone
-                                            // in small frames; 8 shards (workgroup index mod 8) when the visible set is large, because a
-                                            // single word saturates near 88 atomics/us
-    uint32_t n_vis_map, n_vis_vec, n_groups, total;
-    uint32_t n_candidates, ticket;          // sections inside a candidate box (== hash probes of the reference); completed ticket shards
-    uint32_t ranked, pad1[7];               // ranked: ranks + group begins of this frame are ready for k_scatter_ranked
-    uint32_t shard[TICKET_SHARDS * 16];     // finished-workgroup counters, one per 64-byte line (a single word saturates near 88 atomics/us)
+    unsigned long long cursors[CURSOR_SHARDS * 8];   // one per 64-byte line; low 32: emitting sections, high 32: instances.  Sharded by
+                                            // wave index mod 8, because a single word saturates near 88 atomics/us
+    uint32_t counters[COUNTER_SHARDS * 16]; // one shard per 64-byte line: [0] sections inside a candidate box (== hash probes of the
+                                            // reference), [1] visible sections (map), [2] visible sections (vec, with duplicates)
 };
+struct FrameCounts { uint32_t n_candidates, n_vis_map, n_vis_vec; };
 struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; };
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
     unsigned long long stamps[8];           // development builds (-DRE_EXP_STAMPS): 100 MHz wall-clock stamps of the pack phases
 };
-constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances the last workgroup of k_cull_sections packs itself (rank fits 14 bits)
+constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances k_pack_small takes (every workgroup counts all of them); more go through the count/scan/scatter path
 struct SharedArrays {                       // shared world sections (bounding_box_tree_v2.rs:113-155, 253-316)
     uint32_t n;
     const int32_t *cells; const Aabb *aabb; const uint32_t *begin, *nact, *nstat; const int32_t *owner; const uint8_t *cached;
@@ -85,22 +81,25 @@ struct ItemSink {
     uint32_t nshards, seg_cap;              // instance list = nshards segments of seg_cap slots, one cursor each
     const uint32_t *rows, *row_gclass;
 };
-struct PackArgs {                           // what the fused small pack needs besides the item list
-    uint32_t do_pack, nslots, out_cap, do_shared;
+struct PackArgs {                           // what k_pack_small needs besides the item list
+    uint32_t nslots, out_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
-    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; uint32_t *group_begin;
+    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres;
 };
-__global__ void k_scan_keys(const uint64_t *cell_key, uint32_t ncells, PBoxTable B, uint32_t *wave_count, uint32_t *cand, FrameParams Pfull, FrameParams *P_dev);
-__global__ void k_cull_sections(const uint64_t *cell_key, uint32_t ncells, const uint32_t *wave_count, const uint32_t *cand, const Aabb *cell_tight, const uint32_t *cell_begin,
-                                const uint32_t *cell_nlocal, const uint32_t *cell_nstatic, const uint8_t *cell_flags, uint32_t *cell_stamp, ItemSink K, FrameHeader *hdr,
-                                FrameHeader *hdr_next, TickHeader *th, PackArgs A, SharedArrays S, const FrameParams *P, uint32_t lists_per_wave);
+struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull, as one struct (the kernel addresses its tail explicitly)
+    const uint64_t *cell_key; uint32_t ncells, pad;
+    PBoxTable B;                            // -- everything above is read by every wave, everything below by candidate waves only --
+    FrameParams P; FrameParams *P_dev;
+    const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic; const uint8_t *cell_flags; uint32_t *cell_stamp;
+    ItemSink K; FrameHeader *hdr; SharedArrays S;
+};
+__global__ void k_scan_cull(ScanCullArgs A);
+__global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K);
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
-__global__ void k_scatter_ranked(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t item_cap, const uint32_t *group_begin,
-                                 const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,

@@ -214,10 +214,12 @@ __device__ __forceinline__ void emit_sections(uint32_t rb0, uint32_t cnt0, uint3
 // index lies inside the box of its level, so the query is ONE streaming pass over the 8-byte keys
 // (the only per-section bytes read for non-candidates).
 //
-// Two launches: k_scan_keys (K1a, the HBM-bound stream over all keys) and k_cull_sections (K1b, the
-// exact predicates on the few candidates).  Keeping K1a free of everything phase 2 needs (1.7 KB of frame
-// parameters, a dozen pointers, ~50 VGPRs) is worth more than the launch boundary: its waves start
-// loading keys after one scalar load instead of six.
+// ONE launch (k_scan_cull).  Every wave streams 512 keys and runs the packed 16-bit box tests; the few
+// waves that hold a candidate (about 1 in 20 at the reference's draw distance) continue in place with
+// the exact predicates and the instance expansion, while the rest of the grid keeps streaming around
+// them.  Nothing is handed over through HBM between the two phases and no launch boundary, completion
+// ticket or fence sits between them; the dependent-load chain of the candidate waves (about four memory
+// round trips) hides under the stream.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub_u16(uint32_t a, uint32_t b) { u16x2 r = __builtin_bit_cast(u16x2, a) - __builtin_bit_cast(u16x2, b); return __builtin_bit_cast(uint32_t, r); }
@@ -230,13 +232,10 @@ __device__ __forceinline__ bool in_box(uint32_t x, uint32_t y, uint32_t z, const
     return ((x - b.bx) & 0xFFFFu) < b.nx && ((y - b.by) & 0xFFFFu) < b.ny && ((z - b.bz) & 0xFFFFu) < b.nz;
 }
 
-// Visibility of one world section from its key alone: 0 = not visible, 1 = in one of the two query results,
-// 2 = in both (the section then appears twice in visible_sections_vec).  *candidate: inside a candidate box.
-__device__ __forceinline__ uint32_t section_multiplicity(uint64_t key, const FrameParams &P, bool *candidate) {
-    uint32_t lv = key_level(key);
-    if (lv >= P.max_level) { if (candidate) *candidate = false; return 0u; }
+// Visibility of one world section of level-box pair (a = logic, b = render): 0 = not visible, 1 = in one of the two
+// query results, 2 = in both (the section then appears twice in visible_sections_vec).  *candidate: inside a candidate box.
+__device__ __forceinline__ uint32_t section_multiplicity_boxes(uint64_t key, const LevelBox &a, const LevelBox &b, const FrameParams &P, bool *candidate) {
     uint32_t x = key_x(key), y = key_y(key), z = key_z(key);
-    LevelBox a = P.box[0][lv], b = P.box[1][lv];
     bool inl = in_box(x, y, z, a), inr = in_box(x, y, z, b);
     if (candidate) *candidate = inl | inr;
     // candidate AABB as visible_world_flow.rs:73-82: base = (base_unique + i) as f32 * level_length
@@ -254,156 +253,129 @@ __device__ __forceinline__ uint32_t section_multiplicity(uint64_t key, const Fra
     }
     return (visl && visr) ? 2u : ((visl || visr) ? 1u : 0u);
 }
+__device__ __forceinline__ uint32_t section_multiplicity(uint64_t key, const FrameParams &P, bool *candidate) {
+    uint32_t lv = key_level(key);
+    if (lv >= P.max_level) { if (candidate) *candidate = false; return 0u; }
+    LevelBox a = P.box[0][lv], b = P.box[1][lv];
+    return section_multiplicity_boxes(key, a, b, P, candidate);
+}
 
-__device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_hist, uint32_t *s_tmp);
 __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
                                                     const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P);
 
-// K1a: the streaming pass.  Lean on purpose (two pointers + 512 B of packed boxes): every wave issues its
-// CULL_ITERS x 16-byte key loads immediately, runs the packed 16-bit box tests (~12 VALU per key) against
-// the two boxes of its level held in SGPRs, and writes its candidate list (section indices) and the list
-// length to HBM.  No atomics, no LDS, no barrier.  Level runs are padded to whole wave chunks on the host,
-// so the level of the first key is the level of every real key of the wave; keys of any other level fail
-// the packed test by themselves.
-__global__ __launch_bounds__(CULL_THREADS) void k_scan_keys(const uint64_t *__restrict__ cell_key, uint32_t ncells, PBoxTable B,
-                                                            uint32_t *__restrict__ wave_count, uint32_t *__restrict__ cand, FrameParams Pfull, FrameParams *P_dev) {
-    if (blockIdx.x == gridDim.x - 1u) {
-        // the last workgroup (it owns the short tail of the key array) stages the frame parameters from kernarg memory
-        // (host-resident) into device memory, where K1b and the tick read them at L2 latency
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&Pfull); uint32_t *dst = reinterpret_cast<uint32_t *>(P_dev);
-        for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
-    }
-    const uint32_t lane = lane_id(), wave = blockIdx.x * (CULL_THREADS / 64) + (threadIdx.x >> 6);
+// The streaming part is lean on purpose: every wave issues its CULL_ITERS x 16-byte key loads immediately and runs the
+// packed tests (~12 VALU per key) against the two boxes of its level held in SGPRs.  Level runs are padded to whole
+// wave chunks on the host, so the level of the first key is the level of every real key of the wave; keys of any other
+// level fail the packed test by themselves.  Frame parameters live in the kernel-argument segment and are read with
+// scalar loads by candidate waves only.
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(ScanCullArgs A) {
+    __shared__ uint32_t s_cand[CULL_THREADS / 64][WAVE_KEYS];               // per-wave compaction of candidate section indices (no barrier: wave-private)
+    const uint64_t *__restrict__ cell_key = A.cell_key; const uint32_t ncells = A.ncells;
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = blockIdx.x * (CULL_THREADS / 64) + wid;
     const uint32_t npairs = (ncells + 1u) >> 1;                              // key array is padded to an even count with never-candidate keys
     const uint32_t wave_pair0 = wave * (64u * CULL_ITERS);
-    if (wave_pair0 >= npairs) return;                                       // wave-uniform
-    const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);
-    ulonglong2 kk[CULL_ITERS];
+    if (wave_pair0 < npairs) {                                              // wave-uniform
+        const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);
+        ulonglong2 kk[CULL_ITERS];
 #pragma unroll
-    for (uint32_t it = 0; it < CULL_ITERS; it++) {
-        uint32_t pair = wave_pair0 + it * 64u + lane;
-        kk[it] = kp[pair < npairs ? pair : npairs - 1u];
-    }
-    const uint32_t lv0 = __builtin_amdgcn_readfirstlane(key_level(kk[0].x)) & (MAX_LEVELS - 1);
-    const PBox a0 = B.box[0][lv0], b0 = B.box[1][lv0];                       // uniform index: scalar loads into SGPRs
-    uint64_t m[CULL_ITERS * 2]; uint64_t any = 0;
-#pragma unroll
-    for (uint32_t it = 0; it < CULL_ITERS; it++) {
-        const bool valid = (wave_pair0 + it * 64u + lane) < npairs;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            uint64_t key = h ? kk[it].y : kk[it].x;
-            uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-            bool c = valid && (pk_in_box(hi, lo, a0) || pk_in_box(hi, lo, b0));
-            m[it * 2 + h] = __ballot(c); any |= m[it * 2 + h];
+        for (uint32_t it = 0; it < CULL_ITERS; it++) {
+            uint32_t pair = wave_pair0 + it * 64u + lane;
+            kk[it] = kp[pair < npairs ? pair : npairs - 1u];
         }
-    }
-    uint32_t qn = 0;
-    if (any) {                                                              // wave-uniform (scalar) branch
-        uint32_t *q = cand + (size_t)wave * WAVE_KEYS;
+        const uint32_t lv0 = __builtin_amdgcn_readfirstlane(key_level(kk[0].x)) & (MAX_LEVELS - 1);
+        const PBox a0 = A.B.box[0][lv0], b0 = A.B.box[1][lv0];               // uniform index: scalar loads into SGPRs
+        uint64_t m[CULL_ITERS * 2]; uint64_t any = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < CULL_ITERS * 2; k++) {
-            if ((m[k] >> lane) & 1ull) q[qn + mbcnt(m[k])] = (wave_pair0 + (k >> 1) * 64u + lane) * 2u + (k & 1u);
-            qn += (uint32_t)__popcll(m[k]);
-        }
-    }
-    if (lane == 0) wave_count[wave] = qn;
-}
-
-// K1b: exact predicates on the candidate lists of K1a, instance expansion, the shared world sections, and
-// -- with do_pack -- the instance pack in the last workgroup to finish.  lists_per_wave = 64 when few
-// sections are candidates (lane j looks at list wave + j*nwaves, interleaved so clustered non-empty
-// lists spread over the waves), 1 when the candidate set is large (one wave per list).
-__global__ __launch_bounds__(CULL_THREADS) void k_cull_sections(const uint64_t *__restrict__ cell_key, uint32_t ncells,
-                                                                const uint32_t *__restrict__ wave_count, const uint32_t *__restrict__ cand,
-                                                                const Aabb *__restrict__ cell_tight, const uint32_t *__restrict__ cell_begin,
-                                                                const uint32_t *__restrict__ cell_nlocal, const uint32_t *__restrict__ cell_nstatic,
-                                                                const uint8_t *__restrict__ cell_flags, uint32_t *__restrict__ cell_stamp,
-                                                                ItemSink K, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, SharedArrays S,
-                                                                const FrameParams *__restrict__ Pp, uint32_t lists_per_wave) {
-    __shared__ uint32_t s_tmp[32];
-    extern __shared__ uint32_t s_dyn[];                                     // pack histogram (only when do_pack)
-    const FrameParams &P = *Pp;
-    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = blockIdx.x * (CULL_THREADS / 64) + (tid >> 6);
-    const uint32_t nlists = (((ncells + 1u) >> 1) + 64u * CULL_ITERS - 1u) / (64u * CULL_ITERS);
-    const uint32_t nwaves = gridDim.x * (CULL_THREADS / 64);
-    bool wrote = false;
-#ifdef RE_EXP_STAMPS
-    if (blockIdx.x == 0 && tid == 0) A.hres->stamps[6] = wall_clock64();
-#endif
-    uint32_t my_list = wave + lane * nwaves;
-    uint32_t my_count = (lane < lists_per_wave && my_list < nlists) ? wave_count[my_list] : 0u;
-    uint64_t todo = __ballot(my_count != 0);
-    uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0;
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1; todo &= todo - 1;
-        const uint32_t qn = __shfl(my_count, src, 64);
-        const uint32_t *q = cand + (size_t)__shfl(my_list, src, 64) * WAVE_KEYS;
-        uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
+        for (uint32_t it = 0; it < CULL_ITERS; it++) {
+            const bool valid = (wave_pair0 + it * 64u + lane) < npairs;
 #pragma unroll
-        for (uint32_t j = 0; j < EMIT_MAX; j++) {                           // dense lanes, <= EMIT_MAX rounds of 64 candidates
-            const uint32_t i = j * 64u + lane;
-            rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-            if (i < qn) {
-                uint32_t c = q[i];
-                uint64_t key = cell_key[c];
-                uint8_t f = cell_flags[c];
-                bool is_cand = false;
-                uint32_t mult = (f & CF_PAD) ? 0u : section_multiplicity(key, P, &is_cand);
-                cand_acc += is_cand ? 1u : 0u;
-                if (mult) {
-                    cell_stamp[c] = (P.frame << 2) | mult;
-                    wrote = true;
-                    vis_map_acc += 1; vis_vec_acc += mult;
-                    Aabb t = cell_tight[c];
-                    float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
-                    bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
-                    bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
-                    uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c];
-                    rbv[j] = cell_begin[c] + (act ? 0u : nl);
-                    cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
-                    uint32_t m = P.emit_duplicates ? mult : 1u;
-                    lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8);
-                }
+            for (int h = 0; h < 2; h++) {
+                uint64_t key = h ? kk[it].y : kk[it].x;
+                uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+                bool c = valid && (pk_in_box(hi, lo, a0) || pk_in_box(hi, lo, b0));
+                m[it * 2 + h] = __ballot(c); any |= m[it * 2 + h];
             }
         }
-        emit_sections_multi(rbv, cntv, lodv, hdr, K, __shfl(my_list, src, 64));  // one reservation per candidate list
-    }
-    if (__ballot(cand_acc != 0)) {                                          // per-wave counters: one atomic each
-        for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
-        if (lane == 0) {
-            if (cand_acc) atomicAdd(&hdr->n_candidates, cand_acc);
-            if (vis_map_acc) { atomicAdd(&hdr->n_vis_map, vis_map_acc); atomicAdd(&hdr->n_vis_vec, vis_vec_acc); }
+        if (any) {                                                          // wave-uniform (scalar) branch: ~5% of the waves
+            // Candidate waves read the rest of the kernel-argument segment through a pointer the compiler cannot see through, so that
+            // none of those scalar loads is hoisted in front of the key loads of the other 95%.
+            typedef __attribute__((address_space(4))) const char *kernarg_ptr;
+            kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            const ScanCullArgs &R = *(const ScanCullArgs *)ka;
+            const FrameParams &P = R.P;
+            const ItemSink K = R.K; FrameHeader *hdr = R.hdr;
+            const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic;
+            const uint8_t *__restrict__ cell_flags = R.cell_flags; uint32_t *__restrict__ cell_stamp = R.cell_stamp;
+            if (lv0 < P.max_level) {
+            uint32_t *q = s_cand[wid];
+            uint32_t qn = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < CULL_ITERS * 2; k++) {
+                if ((m[k] >> lane) & 1ull) q[qn + mbcnt(m[k])] = (wave_pair0 + (k >> 1) * 64u + lane) * 2u + (k & 1u);
+                qn += (uint32_t)__popcll(m[k]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const LevelBox la = P.box[0][lv0], lb = P.box[1][lv0];          // scalar loads from the kernel-argument segment
+            uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0;
+            uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
+#pragma unroll
+            for (uint32_t j = 0; j < EMIT_MAX; j++) {                       // dense lanes, <= EMIT_MAX rounds of 64 candidates
+                const uint32_t i = j * 64u + lane;
+                rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
+                if (j * 64u < qn) {                                         // wave-uniform
+                    const bool on = i < qn;
+                    const uint32_t c = q[on ? i : 0u];
+                    // everything indexed by the section is requested together (one memory round trip), before visibility is known
+                    const uint64_t key = cell_key[c];
+                    const uint8_t f = cell_flags[c];
+                    const Aabb t = cell_tight[c];
+                    const uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c], cb = cell_begin[c];
+                    bool is_cand = false;
+                    uint32_t mult = (!on || (f & CF_PAD)) ? 0u : section_multiplicity_boxes(key, la, lb, P, &is_cand);
+                    cand_acc += (on && is_cand) ? 1u : 0u;
+                    if (mult) {
+                        cell_stamp[c] = (P.frame << 2) | mult;
+                        vis_map_acc += 1; vis_vec_acc += mult;
+                        float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
+                        bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
+                        bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
+                        rbv[j] = cb + (act ? 0u : nl);
+                        cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
+                        uint32_t mm = P.emit_duplicates ? mult : 1u;
+                        lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
+                    }
+                }
+            }
+            emit_sections_multi(rbv, cntv, lodv, hdr, K, wave);             // one reservation per wave
+            for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
+            if (lane == 0) {                                                // sharded frame counters: fire-and-forget atomics, <= 3 per candidate wave
+                uint32_t *cnt = hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u;
+                if (cand_acc) atomicAdd(cnt + 0, cand_acc);
+                if (vis_map_acc) { atomicAdd(cnt + 1, vis_map_acc); atomicAdd(cnt + 2, vis_vec_acc); }
+            }
+            }
         }
     }
-    // shared world sections: their visibility follows from the keys of the sections linking them, so any
-    // workgroup can process them concurrently with the candidate lists
-    if (A.do_shared)
-        for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < S.n; s0 += gridDim.x * CULL_THREADS) {
-            if (s0 + tid < S.n) wrote = true;
-            cull_shared_section(s0 + tid, S, cell_key, cell_flags, cell_tight, K, hdr, P);
+    // shared world sections: their visibility follows from the keys of the sections linking them, so the first
+    // workgroups process them next to their share of the stream.  The last workgroup (it owns the short tail of the
+    // key array) stages the frame parameters into device memory for the tick.
+    {
+        typedef __attribute__((address_space(4))) const char *kernarg_ptr;
+        kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        const ScanCullArgs &R = *(const ScanCullArgs *)ka;
+        const uint32_t nsh = R.S.n;
+        if (blockIdx.x * CULL_THREADS < nsh) {
+            const SharedArrays S = R.S; const ItemSink K = R.K;
+            for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < nsh; s0 += gridDim.x * CULL_THREADS)
+                cull_shared_section(s0 + threadIdx.x, S, cell_key, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
         }
-    if (!A.do_pack) return;
-    // ---- the last workgroup to finish packs the frame (small visible sets) ----
-    __shared__ uint32_t s_last;
-    if (__ballot(wrote)) __threadfence();                                   // release this wave's stamps / instances before the ticket
-    __syncthreads();
-    if (tid == 0) {
-        // sharded completion ticket: the workgroup that completes its shard bumps the top counter
-        uint32_t k = blockIdx.x % TICKET_SHARDS;
-        uint32_t in_shard = (gridDim.x - 1u - k) / TICKET_SHARDS + 1u;
-        uint32_t nshards = gridDim.x < TICKET_SHARDS ? gridDim.x : TICKET_SHARDS;
-        uint32_t last = 0;
-        if (atomicAdd(&hdr->shard[k * 16u], 1u) == in_shard - 1u) last = (atomicAdd(&hdr->ticket, 1u) == nshards - 1u) ? 1u : 0u;
-        s_last = last;
+        if (blockIdx.x == gridDim.x - 1u) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
+            for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
+        }
     }
-    __syncthreads();
-    if (!s_last) return;
-#ifdef RE_EXP_STAMPS
-    if (tid == 0) A.hres->stamps[7] = wall_clock64();
-#endif
-    __threadfence();                                                        // acquire: every other workgroup's writes
-    pack_small_body(hdr, hdr_next, th, A, K, s_dyn, s_tmp);
 }
 
 // Shared world sections (render_flow.rs:808-866): emitted once per frame when some linking unique
@@ -460,6 +432,7 @@ __global__ __launch_bounds__(256) void k_emit_count(const FrameHeader *hdr, cons
     }
 }
 
+__device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr);
 // K2b: exclusive scan of the group counts -> InstanceRange table (upload_instance_data_to_render_system,
 // render_flow.rs:964-983).  One workgroup; also resets the per-frame counters.
 __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
@@ -493,89 +466,17 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         if (threadIdx.x == 1023) { s_carry = begin + v; s_gcarry = gidx + nz; }
         __syncthreads();
     }
+    FrameCounts fc = {};
+    if (wid == 0) fc = load_frame_counts(hdr);
     if (threadIdx.x == 0) {
-        hdr->total = s_carry; hdr->n_groups = s_gcarry;
         uint32_t nsec = 0, nitems = 0;
         for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * 8]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
-        HostResult r = *hres; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = hdr->n_candidates;
+        HostResult r = *hres; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = fc.n_candidates;
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         *hres = r;                                              // mapped pinned host memory
         TickHeader tz = {}; *th = tz;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
-}
-
-// K2 (small): the whole pack in ONE workgroup when the visible set is small (the common case at the
-// reference's draw distance: ~10^3 instances).  Replaces k_cull_shared + k_emit_count + k_group_scan
-// + k_emit_scatter + every result copy: at these sizes each launch boundary costs more than the work.
-// Runs in the last workgroup of k_cull_sections.  An LDS atomic per instance yields both the group
-// histogram and the instance's rank inside its group.
-__device__ void pack_small_body(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_hist, uint32_t *s_tmp) {
-    const uint32_t NT = CULL_THREADS;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    uint32_t *s_wsum = s_tmp, *s_wcnt = s_tmp + 8, *s_carry = s_tmp + 16, *s_gcarry = s_tmp + 17;
-#ifdef RE_EXP_STAMPS
-#define STAMP(i) do { if (tid == 0) A.hres->stamps[i] = wall_clock64(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-    const uint32_t nslots = A.nslots;
-    STAMP(0);
-    for (uint32_t i = tid; i < nslots; i += NT) s_hist[i] = 0;
-    if (tid == 0) { *s_carry = 0; *s_gcarry = 0; }
-    __syncthreads();
-    STAMP(1);
-    unsigned long long cur = __hip_atomic_load(&hdr->cursors[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // small frames use shard 0 only
-    const uint32_t nsec = (uint32_t)cur, T = (uint32_t)(cur >> 32);
-    const bool overflow = T > PACK_SMALL_ITEMS || T > K.item_cap || nslots > LDS_HIST_SLOTS;
-    if (!overflow) {
-        // ranks: 8 independent slot loads in flight per lane
-        for (uint32_t t0 = 0; t0 < T; t0 += NT * 8u) {
-            uint32_t sl[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { uint32_t t = t0 + u * NT + tid; sl[u] = t < T ? __hip_atomic_load(&K.item_slot[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu; }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) {
-                uint32_t t = t0 + u * NT + tid;
-                if (sl[u] != 0xFFFFFFFFu) { uint32_t rank = atomicAdd(&s_hist[sl[u]], 1u); K.item_slot[t] = (sl[u] << 16) | rank; }   // slot < 2^15, rank < 2^14
-            }
-        }
-    }
-    __syncthreads();
-    STAMP(2);
-    // exclusive scan of the group counts -> InstanceRange table (render_flow.rs:964-983)
-    for (uint32_t base = 0; base < nslots && !overflow; base += NT) {
-        uint32_t i = base + tid;
-        uint32_t v = i < nslots ? s_hist[i] : 0u;
-        uint32_t nz = v ? 1u : 0u;
-        uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
-        if (lane == 63) { s_wsum[wid] = incl; s_wcnt[wid] = incn; }
-        __syncthreads();
-        uint32_t woff = 0, wcn = 0;
-        for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
-        uint32_t begin = *s_carry + woff + incl - v;
-        uint32_t gidx = *s_gcarry + wcn + incn - nz;
-        if (i < nslots) {
-            s_hist[i] = begin; A.group_begin[i] = begin;                // k_scatter_ranked reads the begins from HBM
-            if (v) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
-        }
-        __syncthreads();
-        if (tid == NT - 1) { *s_carry = begin + v; *s_gcarry = gidx + nz; }
-        __syncthreads();
-    }
-    STAMP(3);
-    STAMP(4);
-    if (tid == 0) {
-        HostResult r = *A.hres; r.n_vis_map = hdr->n_vis_map; r.n_vis_vec = hdr->n_vis_vec; r.n_groups = *s_gcarry; r.total = *s_carry; r.n_candidates = hdr->n_candidates;
-        r.overflow = overflow ? 1u : 0u; r.n_entries = nsec; r.n_items = T;
-#ifdef RE_EXP_STAMPS
-        r.stamps[5] = wall_clock64();
-#endif
-        *A.hres = r;                                            // mapped pinned host memory
-        TickHeader tz = {}; *th = tz;
-        hdr->ranked = overflow ? 0u : 1u;                       // k_scatter_ranked may run
-    }
-    for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's counters (this frame's header stays readable)
 }
 
 // K2c: scatter -- the instance pack (specify_type_ids! callback + MappedBuffer::write_data_serialized,
@@ -625,26 +526,112 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, co
     }
 }
 
-// K2 (small), second half: the instance pack proper (specify_type_ids! callback + MappedBuffer::write_data_serialized,
-// prelude/layout_update_macros.rs:15-21, render_components/mapped_buffer.rs:166-189) for a frame whose
-// ranks and group begins were computed by the last workgroup of k_cull_sections.  Spread over many
-// workgroups on purpose: thousands of page-scattered 64-byte gathers are slow from a single CU.
-// 4 lanes per instance, one float4 each.
-__global__ __launch_bounds__(256) void k_scatter_ranked(const FrameHeader *hdr, const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_slot, uint32_t item_cap,
-                                                        const uint32_t *__restrict__ group_begin, const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
-                                                        uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap) {
-    if (!hdr->ranked) return;
-    uint32_t T = (uint32_t)(hdr->cursors[0] >> 32); if (T > item_cap) T = item_cap;
-    const uint32_t part = threadIdx.x & 3u;
-    for (uint32_t t = blockIdx.x * 64u + (threadIdx.x >> 2); t < T; t += gridDim.x * 64u) {
-        uint32_t sr = item_slot[t];
-        if (sr == 0xFFFFFFFFu) continue;
-        uint32_t row = item_row[t];
-        uint32_t pos = group_begin[sr >> 16] + (sr & 0xFFFFu);
-        if (pos < out_cap) {
-            reinterpret_cast<float4 *>(out_mats + (size_t)pos * 16)[part] = reinterpret_cast<const float4 *>(row_mat + (size_t)row * 16)[part];
-            if (part == 0) out_ids[pos] = row_id[row];
+// K2 (small visible sets, the common case at the reference's draw distance: ~10^3 instances): the whole pack in ONE
+// launch of a few workgroups with no communication between them.  == specify_type_ids! callback +
+// MappedBuffer::write_data_serialized + the InstanceRange table (prelude/layout_update_macros.rs:15-21,
+// render_components/mapped_buffer.rs:166-189, flows/render_flow.rs:964-983).
+// Every workgroup reads the slot of every instance (a few KB, L2 hits) into two LDS histograms -- all instances
+// (-> group begins, by a scan) and the instances before its own chunk (-> where its chunk starts inside each group)
+// -- then ranks its own chunk with LDS atomics and moves the matrices, 4 lanes per instance, one float4 each.
+// The redundant counting costs less than any cross-workgroup hand-over would (a ticket, a fence, or a launch).
+// Workgroup 0 also writes the group table and the frame counters to mapped host memory and clears the next frame's header.
+__device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr) {          // whole wave; result valid in every lane
+    const uint32_t lane = lane_id();
+    const uint32_t *cnt = hdr->counters + (lane & (COUNTER_SHARDS - 1u)) * 16u;
+    uint32_t a = lane < COUNTER_SHARDS ? cnt[0] : 0u, b = lane < COUNTER_SHARDS ? cnt[1] : 0u, c = lane < COUNTER_SHARDS ? cnt[2] : 0u;
+    for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); c += __shfl_xor(c, d, 64); }
+    FrameCounts r; r.n_candidates = a; r.n_vis_map = b; r.n_vis_vec = c; return r;
+}
+__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K) {
+    extern __shared__ uint32_t s_dyn[];                       // [nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill
+    __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
+    __shared__ uint32_t s_pos[256], s_row[256];
+    const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const uint32_t nslots = A.nslots;
+    uint32_t *s_tot = s_dyn, *s_fill = s_dyn + nslots;
+    // raw cursors: a segment that ran over its capacity dropped instances -> the host re-runs the frame through the large path
+    uint32_t raw_items = 0, raw_sec = 0; bool seg_over = false;
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+        unsigned long long cur = k < K.nshards ? hdr->cursors[k * 8] : 0ull;
+        raw_sec += (uint32_t)cur; raw_items += (uint32_t)(cur >> 32); seg_over |= (uint32_t)(cur >> 32) > K.seg_cap;
+    }
+    const ShardMap sm = load_shard_map(hdr, K.nshards, K.seg_cap);
+    const uint32_t T = sm.total;
+    const bool overflow = seg_over || T > PACK_SMALL_ITEMS || nslots > LDS_HIST_SLOTS;
+    uint32_t per = ((T + gridDim.x - 1u) / gridDim.x + 63u) & ~63u;       // contiguous chunk of this workgroup
+    const uint32_t lo = blockIdx.x * per, hi = lo + per < T ? lo + per : T;
+    if (blockIdx.x != 0 && (overflow || lo >= T)) return;
+    if (!overflow) {
+        for (uint32_t i = tid; i < 2u * nslots; i += NT) s_dyn[i] = 0;
+        if (tid == 0) { s_carry = 0; s_gcarry = 0; }
+        __syncthreads();
+        for (uint32_t t0 = 0; t0 < T; t0 += NT * 8u) {                     // 8 independent slot loads in flight per lane
+            uint32_t sl[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) { uint32_t t = t0 + u * NT + tid; sl[u] = t < T ? K.item_slot[shard_item_index(t, sm, K.seg_cap)] : 0xFFFFFFFFu; }
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                uint32_t t = t0 + u * NT + tid;
+                if (sl[u] != 0xFFFFFFFFu) { atomicAdd(&s_tot[sl[u]], 1u); if (t < lo) atomicAdd(&s_fill[sl[u]], 1u); }
+            }
         }
+        __syncthreads();
+        // exclusive scan of the group counts -> group begins (+ the InstanceRange table, workgroup 0)
+        for (uint32_t base = 0; base < nslots; base += NT) {
+            uint32_t i = base + tid;
+            uint32_t v = i < nslots ? s_tot[i] : 0u;
+            uint32_t nz = v ? 1u : 0u;
+            uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
+            if (lane == 63) { s_wsum[wid] = incl; s_wcnt[wid] = incn; }
+            __syncthreads();
+            uint32_t woff = 0, wcn = 0;
+            for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
+            uint32_t begin = s_carry + woff + incl - v;
+            uint32_t gidx = s_gcarry + wcn + incn - nz;
+            if (i < nslots) {
+                s_tot[i] = begin;
+                if (v && blockIdx.x == 0) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
+            }
+            __syncthreads();
+            if (tid == NT - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
+            __syncthreads();
+        }
+    }
+    if (blockIdx.x == 0) {
+        if (wid == 0) {
+            FrameCounts fc = load_frame_counts(hdr);
+            if (lane == 0) {
+                HostResult r = *A.hres; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;
+                r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
+                r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
+                *A.hres = r;                                        // mapped pinned host memory
+                if (!overflow) { TickHeader tz = {}; *th = tz; }
+            }
+        }
+        // next frame's cursors / counters (this frame's header stays readable); on overflow the large path does it
+        if (!overflow) for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
+    }
+    if (overflow) return;
+    // ---- this workgroup's chunk: rank inside the group, then move the matrices ----
+    const uint32_t part = tid & 3u;
+    for (uint32_t t0 = lo; t0 < hi; t0 += NT) {                            // uniform trip count
+        uint32_t t = t0 + tid, pos = 0xFFFFFFFFu, row = 0;
+        if (t < hi) {
+            uint32_t ii = shard_item_index(t, sm, K.seg_cap);
+            uint32_t slot = K.item_slot[ii]; row = K.item_row[ii];
+            if (slot != 0xFFFFFFFFu) pos = s_tot[slot] + atomicAdd(&s_fill[slot], 1u);
+        }
+        s_pos[tid] = pos; s_row[tid] = row;
+        if (pos < A.out_cap) A.out_ids[pos] = A.row_id[row];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) {
+            uint32_t li = q * 64u + (tid >> 2);
+            uint32_t pp = s_pos[li];
+            if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
+        }
+        __syncthreads();
     }
 }
 
