@@ -14,7 +14,10 @@ SOURCES = ["re_kernels.hip", "re_api.hip", "re_lighting.hip"]
 HEADERS = ["re_kernels.h", "re_math.h", os.path.join(INCLUDE, "re_hip.h")]
 # -ffp-contract=off: the visible set must be bit-exact with the reference's Rust arithmetic (no FMA contraction)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
-         "-fgpu-rdc", "-Wall", "-Wno-unused-result"]
+         "-fgpu-rdc", "-Wall", "-Wno-unused-result",
+         # gfx950 hands the first kernel-argument dwords to each wave in SGPRs at launch: k_scan_cull's key pointer and count
+         # arrive without a scalar-load round trip in front of the key loads
+         "-mllvm", "-amdgpu-kernarg-preload-count=12"]
 
 
 def needs_build():

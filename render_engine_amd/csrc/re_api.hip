@@ -99,6 +99,9 @@ struct re_ctx {
     // frame
     uint32_t frame = 0; bool have_cull = false;
     FrameParams P{}; PBoxTable PB{}; DevBuf<FrameParams> d_params;
+#ifdef RE_EXP_STAMPS
+    DevBuf<unsigned long long> d_timeline;
+#endif
     uint32_t nlists = 0, pred_candidates = 0;             // nlists: 512-key chunks == waves of k_scan_cull
     uint32_t item_cap = 0, out_cap = 0, list_cap = 0;
     DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
@@ -540,6 +543,39 @@ static void fill_packed_boxes(PBox *out, const LevelBox *in, uint32_t maxlevel) 
     }
 }
 
+// Key chunks (2048 keys = one workgroup of k_scan_cull) that can hold candidates: per level, the x-slab [bx, bx+nx) of the union of
+// the two candidate boxes is one contiguous run of the key-sorted section array.  At most 4 disjoint ascending spans (see ScanSpans).
+static ScanSpans candidate_spans(re_ctx *c, uint32_t nchunks) {
+    ScanSpans SP{}; const FrameParams &P = c->P;
+    const uint32_t per = (uint32_t)(CULL_THREADS / 64) * WAVE_KEYS;
+    std::vector<std::pair<uint32_t, uint32_t>> sp;                            // [first chunk, end chunk)
+    const std::vector<uint64_t> &K = c->h_cell_key;
+    for (uint32_t l = 0; l < P.max_level && l < (uint32_t)MAX_LEVELS; l++) {
+        uint32_t x0 = 0xFFFFFFFFu, x1 = 0;
+        for (int w = 0; w < 2; w++) {
+            const LevelBox &b = P.box[w][l];
+            if (!b.nx || !b.ny || !b.nz) continue;
+            if (b.bx + b.nx > 0xFFFFu) { x0 = 0; x1 = 0xFFFFu; continue; }      // wrapped box: the whole level run
+            x0 = std::min(x0, b.bx); x1 = std::max(x1, b.bx + b.nx);
+        }
+        if (x0 >= x1) continue;
+        uint64_t k0 = ((uint64_t)l << 48) | ((uint64_t)x0 << 32), k1 = ((uint64_t)l << 48) | ((uint64_t)x1 << 32);
+        size_t i0 = std::lower_bound(K.begin(), K.end(), k0) - K.begin(), i1 = std::lower_bound(K.begin(), K.end(), k1) - K.begin();
+        if (i0 >= i1) continue;
+        sp.push_back({ (uint32_t)(i0 / per), std::min(nchunks, (uint32_t)((i1 + per - 1) / per)) });
+    }
+    std::sort(sp.begin(), sp.end());
+    std::vector<std::pair<uint32_t, uint32_t>> m;
+    for (auto &s : sp) { if (!m.empty() && s.first <= m.back().second) m.back().second = std::max(m.back().second, s.second); else m.push_back(s); }
+    while (m.size() > 4) {                                                    // merge the two closest spans
+        size_t best = 0; for (size_t i = 1; i + 1 < m.size(); i++) if (m[i + 1].first - m[i].second < m[best + 1].first - m[best].second) best = i;
+        m[best].second = m[best + 1].second; m.erase(m.begin() + best + 1);
+    }
+    SP.n = (uint32_t)m.size();
+    for (size_t i = 0; i < m.size(); i++) { SP.start[i] = m[i].first; SP.count[i] = m[i].second - m[i].first; }
+    return SP;
+}
+
 static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     FrameParams &P = c->P;
     make_planes(cam->projection_view, P.planes);
@@ -658,15 +694,22 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
-    ScanCullArgs SA; SA.cell_key = c->d_cell_key.p; SA.ncells = c->ncells; SA.pad = 0; SA.B = c->PB; SA.P = P; SA.P_dev = c->d_params.p;
+    ScanCullArgs SA; SA.B = c->PB; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p;
     SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c);
-    hipExtLaunchKernelGGL(k_scan_cull, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, SA);
+    static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
+#ifdef RE_EXP_STAMPS
+    if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 4, nullptr));
+    SA.timeline = c->d_timeline.p;
+#endif
+    const ScanSpans SP = candidate_spans(c, scan_grid);
+    hipExtLaunchKernelGGL(k_scan_cull, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const uint64_t *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+                          SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], SA);
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
-        // a few workgroups, ~256 predicted instances each; every workgroup counts all instances, so more workgroups only help the matrix moves
-        uint32_t pgrid = std::min(64u, std::max(c->pred_total, 1u) / 128u + 1u);
+        // one workgroup per 64 predicted instances (+25%): every workgroup counts all instances, the matrix gathers want many CUs
+        uint32_t pgrid = std::min(256u, (c->pred_total + c->pred_total / 4u) / 64u + 2u);
         hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c));
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next);
@@ -996,6 +1039,14 @@ extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32
     c->k1_timing = false; c->k1_used = 0;
     return RE_OK;
 }
+#ifdef RE_EXP_STAMPS
+extern "C" int re_debug_get_timeline(re_ctx *c, unsigned long long *out, uint32_t nwaves) {
+    if (!c || !out || !c->d_timeline.p) return RE_E_ARG;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, c->d_timeline.p, (size_t)std::min(nwaves, c->nlists) * 32, hipMemcpyDeviceToHost));
+    return RE_OK;
+}
+#endif
 extern "C" int re_debug_get_stamps(re_ctx *c, unsigned long long *out8) { if (!c || !c->h_res || !out8) return RE_E_ARG; memcpy(out8, c->h_res->stamps, 64); return RE_OK; }
 
 extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {

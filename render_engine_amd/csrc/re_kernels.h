@@ -86,14 +86,22 @@ struct PackArgs {                           // what k_pack_small needs besides t
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
     const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres;
 };
-struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull, as one struct (the kernel addresses its tail explicitly)
-    const uint64_t *cell_key; uint32_t ncells, pad;
-    PBoxTable B;                            // -- everything above is read by every wave, everything below by candidate waves only --
+struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull after its two leading scalars (the kernel addresses it explicitly)
+    PBoxTable B;                            // read by every wave; everything below by candidate waves only
     FrameParams P; FrameParams *P_dev;
     const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic; const uint8_t *cell_flags; uint32_t *cell_stamp;
     ItemSink K; FrameHeader *hdr; SharedArrays S;
+#ifdef RE_EXP_STAMPS
+    unsigned long long *timeline;           // development builds: [wave] = {start, keys arrived, end} 100 MHz stamps
+#endif
 };
-__global__ void k_scan_cull(ScanCullArgs A);
+// Workgroup order of k_scan_cull: up to 4 disjoint, ascending spans of key chunks (one chunk = the 2048 keys of a workgroup) run first,
+// the other chunks follow in key order.  The host puts the x-slabs of the candidate boxes there, so the few long-running
+// candidate waves start at once and finish under the stream instead of after it.
+struct ScanSpans { uint32_t n, start[4], count[4]; };
+constexpr uint32_t SCAN_CULL_ARGS_OFFSET = 48;   // cell_key (8 bytes) + ncells (4) + the 9 span scalars (36), already a multiple of the 8-byte alignment of ScanCullArgs
+__global__ void k_scan_cull(const uint64_t *cell_key, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
+                            uint32_t s3, uint32_t c3, ScanCullArgs A);   // nsp..c3 = ScanSpans as scalars: they arrive preloaded in SGPRs
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K);
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,

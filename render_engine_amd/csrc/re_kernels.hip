@@ -268,10 +268,27 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
 // wave chunks on the host, so the level of the first key is the level of every real key of the wave; keys of any other
 // level fail the packed test by themselves.  Frame parameters live in the kernel-argument segment and are read with
 // scalar loads by candidate waves only.
-__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(ScanCullArgs A) {
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__restrict__ cell_key, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                                            uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, ScanCullArgs A) {
     __shared__ uint32_t s_cand[CULL_THREADS / 64][WAVE_KEYS];               // per-wave compaction of candidate section indices (no barrier: wave-private)
-    const uint64_t *__restrict__ cell_key = A.cell_key; const uint32_t ncells = A.ncells;
-    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = blockIdx.x * (CULL_THREADS / 64) + wid;
+#ifdef RE_EXP_STAMPS
+    const unsigned long long tl_start = wall_clock64(); unsigned long long tl_keys = tl_start; uint32_t tl_cand = 0;
+#endif
+    // workgroup -> key chunk: the candidate spans first (see ScanSpans); all scalar
+    uint32_t chunk = blockIdx.x;
+    {
+        const uint32_t st[4] = { s0, s1, s2, s3 }, ct[4] = { c0, c1, c2, c3 };
+        uint32_t acc = 0; bool in_span = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++)
+            if (i < nsp && !in_span) { if (chunk < acc + ct[i]) { chunk = st[i] + (chunk - acc); in_span = true; } else acc += ct[i]; }
+        if (!in_span) {
+            chunk -= acc;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) if (i < nsp && chunk >= st[i]) chunk += ct[i];
+        }
+    }
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = chunk * (CULL_THREADS / 64) + wid;
     const uint32_t npairs = (ncells + 1u) >> 1;                              // key array is padded to an even count with never-candidate keys
     const uint32_t wave_pair0 = wave * (64u * CULL_ITERS);
     if (wave_pair0 < npairs) {                                              // wave-uniform
@@ -296,13 +313,16 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(ScanCullArgs A) {
                 m[it * 2 + h] = __ballot(c); any |= m[it * 2 + h];
             }
         }
+#ifdef RE_EXP_STAMPS
+        tl_keys = wall_clock64(); tl_cand = any ? 1u : 0u;
+#endif
         if (any) {                                                          // wave-uniform (scalar) branch: ~5% of the waves
             // Candidate waves read the rest of the kernel-argument segment through a pointer the compiler cannot see through, so that
             // none of those scalar loads is hoisted in front of the key loads of the other 95%.
             typedef __attribute__((address_space(4))) const char *kernarg_ptr;
             kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
-            const ScanCullArgs &R = *(const ScanCullArgs *)ka;
+            const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
             const FrameParams &P = R.P;
             const ItemSink K = R.K; FrameHeader *hdr = R.hdr;
             const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic;
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(ScanCullArgs A) {
         typedef __attribute__((address_space(4))) const char *kernarg_ptr;
         kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(ka));
-        const ScanCullArgs &R = *(const ScanCullArgs *)ka;
+        const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
         const uint32_t nsh = R.S.n;
         if (blockIdx.x * CULL_THREADS < nsh) {
             const SharedArrays S = R.S; const ItemSink K = R.K;
@@ -375,6 +395,9 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(ScanCullArgs A) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
             for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
         }
+#ifdef RE_EXP_STAMPS
+        if (R.timeline && lane == 0) { unsigned long long *t = R.timeline + (size_t)wave * 4u; t[0] = tl_start; t[1] = tl_keys; t[2] = wall_clock64(); t[3] = tl_cand; }
+#endif
     }
 }
 
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
     if (threadIdx.x == 0) {
         uint32_t nsec = 0, nitems = 0;
         for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * 8]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
-        HostResult r = *hres; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = fc.n_candidates;
+        HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = fc.n_candidates;
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         *hres = r;                                              // mapped pinned host memory
         TickHeader tz = {}; *th = tz;
@@ -545,7 +568,7 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K) {
     extern __shared__ uint32_t s_dyn[];                       // [nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
-    __shared__ uint32_t s_pos[256], s_row[256];
+    __shared__ uint32_t s_pos[64], s_row[64];
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t nslots = A.nslots;
     uint32_t *s_tot = s_dyn, *s_fill = s_dyn + nslots;
@@ -559,17 +582,31 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     const ShardMap sm = load_shard_map(hdr, K.nshards, K.seg_cap);
     const uint32_t T = sm.total;
     const bool overflow = seg_over || T > PACK_SMALL_ITEMS || nslots > LDS_HIST_SLOTS;
-    uint32_t per = ((T + gridDim.x - 1u) / gridDim.x + 63u) & ~63u;       // contiguous chunk of this workgroup
+    const uint32_t per = ((T + gridDim.x - 1u) / gridDim.x + 63u) & ~63u;             // contiguous chunk of this workgroup
     const uint32_t lo = blockIdx.x * per, hi = lo + per < T ? lo + per : T;
     if (blockIdx.x != 0 && (overflow || lo >= T)) return;
+    // The first pass (64 instances) of this workgroup's own chunk is requested up front, so its page-scattered gathers travel while the
+    // histograms are built.  Chunks are small on purpose: a CU resolves the address translations of scattered rows one after another,
+    // so the gathers want many CUs, while the redundant slot counting is contiguous and cheap.
+    const uint32_t part = tid & 3u, li = tid >> 2;
+    uint32_t my_slot = 0xFFFFFFFFu, my_row = 0, my_id = 0; float4 pre = {0.f, 0.f, 0.f, 0.f};
     if (!overflow) {
+        // all independent requests first: this lane's own item, and the first 8 x 256 slots of the histogram pass
+        if (tid < 64u && lo + tid < hi) { uint32_t ii = shard_item_index(lo + tid, sm, K.seg_cap); my_slot = K.item_slot[ii]; my_row = K.item_row[ii]; }
+        uint32_t sl[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) { uint32_t t = u * NT + tid; sl[u] = t < T ? K.item_slot[shard_item_index(t, sm, K.seg_cap)] : 0xFFFFFFFFu; }
         for (uint32_t i = tid; i < 2u * nslots; i += NT) s_dyn[i] = 0;
         if (tid == 0) { s_carry = 0; s_gcarry = 0; }
+        if (tid < 64u) s_row[tid] = my_row;
         __syncthreads();
+        if (tid < 64u && lo + tid < hi) my_id = A.row_id[my_row];
+        if (lo + li < hi) pre = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
         for (uint32_t t0 = 0; t0 < T; t0 += NT * 8u) {                     // 8 independent slot loads in flight per lane
-            uint32_t sl[8];
+            if (t0) {
 #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) { uint32_t t = t0 + u * NT + tid; sl[u] = t < T ? K.item_slot[shard_item_index(t, sm, K.seg_cap)] : 0xFFFFFFFFu; }
+                for (uint32_t u = 0; u < 8; u++) { uint32_t t = t0 + u * NT + tid; sl[u] = t < T ? K.item_slot[shard_item_index(t, sm, K.seg_cap)] : 0xFFFFFFFFu; }
+            }
 #pragma unroll
             for (uint32_t u = 0; u < 8; u++) {
                 uint32_t t = t0 + u * NT + tid;
@@ -602,7 +639,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
         if (wid == 0) {
             FrameCounts fc = load_frame_counts(hdr);
             if (lane == 0) {
-                HostResult r = *A.hres; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;
+                HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;   // (never read the mapped host struct: a PCIe round trip)
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
                 r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
                 *A.hres = r;                                        // mapped pinned host memory
@@ -613,25 +650,20 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
         if (!overflow) for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
     }
     if (overflow) return;
-    // ---- this workgroup's chunk: rank inside the group, then move the matrices ----
-    const uint32_t part = tid & 3u;
-    for (uint32_t t0 = lo; t0 < hi; t0 += NT) {                            // uniform trip count
-        uint32_t t = t0 + tid, pos = 0xFFFFFFFFu, row = 0;
-        if (t < hi) {
-            uint32_t ii = shard_item_index(t, sm, K.seg_cap);
-            uint32_t slot = K.item_slot[ii]; row = K.item_row[ii];
+    // ---- this workgroup's chunk: rank inside the group, then move the matrices (4 lanes per instance, one float4 each) ----
+    for (uint32_t t0 = lo; t0 < hi; t0 += 64u) {                           // uniform trip count
+        const bool first = t0 == lo;
+        __syncthreads();                                                   // previous pass done with s_pos / s_row
+        if (tid < 64u) {
+            uint32_t t = t0 + tid, pos = 0xFFFFFFFFu, row = my_row, slot = my_slot;
+            if (!first) { slot = 0xFFFFFFFFu; if (t < hi) { uint32_t ii = shard_item_index(t, sm, K.seg_cap); slot = K.item_slot[ii]; row = K.item_row[ii]; } }
             if (slot != 0xFFFFFFFFu) pos = s_tot[slot] + atomicAdd(&s_fill[slot], 1u);
-        }
-        s_pos[tid] = pos; s_row[tid] = row;
-        if (pos < A.out_cap) A.out_ids[pos] = A.row_id[row];
-        __syncthreads();
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            uint32_t li = q * 64u + (tid >> 2);
-            uint32_t pp = s_pos[li];
-            if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
+            s_pos[tid] = pos; s_row[tid] = row;
+            if (pos < A.out_cap) A.out_ids[pos] = first ? my_id : A.row_id[row];
         }
         __syncthreads();
+        uint32_t pp = s_pos[li];
+        if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = first ? pre : reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
     }
 }
 
