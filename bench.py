@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+TIMING_EVERY = 8
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 PER_GPU_AXIS = 216             # 216^3 = 10,077,696 sections/entities per GPU
 
@@ -121,7 +122,7 @@ def main():
     for _ in range(a.warmup):
         step(False)
     fence()
-    p.timing_begin(a.steps)
+    p.timing_begin(a.steps, every=TIMING_EVERY)     # HIP events on every 8th launch of the dominant kernel: timed dispatches cost queue time
     t_start = time.perf_counter()
     for _ in range(a.steps):
         step(False)
@@ -144,15 +145,19 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        # roofline of the dominant kernel (k_scan_keys): algorithmic bytes per launch, see DESIGN.md
+        # roofline of the dominant kernel (k_scan_cull): algorithmic bytes per launch, see DESIGN.md "Roofline accounting":
+        # 8 B key per section + 37 B per candidate section (flags, tight AABB, counts, begin) + 4 B stamp per visible section
+        # + 16 B per visible instance (row index and group class read, instance-list entry written)
         C_sections = stats["n_sections"]
         n_entries = vis["n_visible_sections"]
-        alg_bytes = 8 * C_sections + 41 * n_cand + 20 * n_entries
+        alg_bytes = 8 * C_sections + 37 * n_cand + 4 * n_entries + 16 * vis["total"]
         k1_mean = float(np.mean(k1_us)) if len(k1_us) else float("nan")
         achieved = alg_bytes / (k1_mean * 1e-6) / 1e9 if k1_mean > 0 else None
         traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_k_scan_keys.json")
-        if os.path.exists(prof):
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_k_scan_cull.json")
+        # the committed PMC measurement is of the default workload on one GPU; other workloads report null
+        default_workload = world == 1 and a.axis == 216 and a.far == 1000.0 and not a.spinner_every and not a.force_large_pack
+        if default_workload and os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
             except Exception:
@@ -170,8 +175,8 @@ def main():
                        "sharding": "none" if world == 1 else "contiguous section-key ranges, RCCL all-gather of packed visible buffers"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_scan_keys", "algorithmic_bytes_per_launch": alg_bytes,
-                         "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us))},
+                         "kernel": "k_scan_cull", "algorithmic_bytes_per_launch": alg_bytes,
+                         "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY},
             "frame_latency_ms_sync": float(np.median(lat) * 1e3),
             "kernel_us_last_frame": tm, "setup_s": t_setup,
         }

@@ -203,9 +203,10 @@ int re_debug_get_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, float 
 int re_debug_get_visible_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n);
 /* device time of the kernels of the last cull_pack / tick, microseconds (hipEvent on the ctx stream) */
 int re_get_timings(re_ctx *ctx, float *cull_us, float *pack_us, float *tick_us);
-/* per-launch HIP-event timing of the dominant kernel (the section-key scan) over a timed region:
- * re_timing_begin(ctx, max_launches); ...frames...; re_timing_collect(ctx, us, cap, &n) (synchronises) */
-int re_timing_begin(re_ctx *ctx, uint32_t max_launches);
+/* per-launch HIP-event timing of the dominant kernel (the section-key scan + cull) over a timed region, sampling every
+ * `every`-th launch (0 or 1 = all): re_timing_begin(ctx, max_launches, every); ...frames...;
+ * re_timing_collect(ctx, us, cap, &n) (synchronises) */
+int re_timing_begin(re_ctx *ctx, uint32_t max_launches, uint32_t every);
 int re_timing_collect(re_ctx *ctx, float *microseconds, uint32_t capacity, uint32_t *n);
 /* number of world sections inside a candidate box in the last cull (== hash probes the reference would make) */
 int re_get_last_candidates(re_ctx *ctx, uint32_t *n_candidates);

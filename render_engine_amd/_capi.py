@@ -110,7 +110,7 @@ def load():
     L.re_debug_get_visible_sections.restype = C.c_int; L.re_debug_get_visible_sections.argtypes = [vp, C.c_uint32, vp, vp, _u32p]
     L.re_get_timings.restype = C.c_int; L.re_get_timings.argtypes = [vp, _fp, _fp, _fp]
     L.re_get_stream.restype = vp; L.re_get_stream.argtypes = [vp]
-    L.re_timing_begin.restype = C.c_int; L.re_timing_begin.argtypes = [vp, C.c_uint32]
+    L.re_timing_begin.restype = C.c_int; L.re_timing_begin.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.re_timing_collect.restype = C.c_int; L.re_timing_collect.argtypes = [vp, vp, C.c_uint32, _u32p]
     L.re_get_last_candidates.restype = C.c_int; L.re_get_last_candidates.argtypes = [vp, _u32p]
     L.re_lighting_create.restype = C.c_int; L.re_lighting_create.argtypes = [C.POINTER(LightingConfig), C.POINTER(vp)]

@@ -114,7 +114,7 @@ struct re_ctx {
     bool cull_inflight = false, tick_inflight = false;
     re_tick_result last_tick{};
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
-    std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0; bool k1_timing = false;   // per-launch timing of k_cull_sections
+    std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0; bool k1_timing = false;   // per-launch timing of k_scan_cull
 
     int fail(int code, const char *fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -685,7 +685,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
         // the changed-static set is consumed by every render until the frame ends (re_tick clears it)
     }
     hipEvent_t k1a = nullptr, k1b = nullptr;
-    if (c->k1_timing && c->k1_used + 2 <= c->k1_events.size()) { k1a = c->k1_events[c->k1_used]; k1b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
+    if (c->k1_timing && (c->k1_seen++ % c->k1_every) == 0 && c->k1_used + 2 <= c->k1_events.size()) { k1a = c->k1_events[c->k1_used]; k1b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
@@ -1020,13 +1020,14 @@ extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *
 
 extern "C" void *re_get_stream(re_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-// per-launch HIP-event timing of the dominant kernel (k_cull_sections) over a timed region:
-// re_timing_begin(ctx, max_launches) ... frames ... re_timing_collect(ctx, us[], cap, &n)
-extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches) {
+// per-launch HIP-event timing of the dominant kernel (k_scan_cull) over a timed region, every `every`-th launch (timed dispatches
+// carry completion signals that cost a few microseconds of queue time each, so a throughput run samples):
+// re_timing_begin(ctx, max_launches, every) ... frames ... re_timing_collect(ctx, us[], cap, &n)
+extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches, uint32_t every) {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     while (c->k1_events.size() < (size_t)max_launches * 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->k1_events.push_back(e); }
-    c->k1_used = 0; c->k1_timing = max_launches > 0;
+    c->k1_used = 0; c->k1_timing = max_launches > 0; c->k1_every = std::max(every, 1u); c->k1_seen = 0;
     return RE_OK;
 }
 extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) {

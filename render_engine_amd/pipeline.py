@@ -252,8 +252,8 @@ class Pipeline:
         self._check(self._L.re_get_timings(self._h, C.byref(a), C.byref(b), C.byref(c)), "re_get_timings")
         return dict(cull=a.value, pack=b.value, tick=c.value)
 
-    def timing_begin(self, max_launches):
-        self._check(self._L.re_timing_begin(self._h, max_launches), "re_timing_begin")
+    def timing_begin(self, max_launches, every=1):
+        self._check(self._L.re_timing_begin(self._h, max_launches, every), "re_timing_begin")
 
     def timing_collect(self, cap=65536):
         us = np.zeros(cap, np.float32); n = C.c_uint32()
