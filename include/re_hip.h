@@ -57,6 +57,8 @@ extern "C" {
 #define RE_F_OOB_LOGIC   0x100u  /* entity type has OutOfBoundsLogic => add_if_out_bounds (entity_change_helpers.rs:264-274) */
 #define RE_F_HAS_MOVED   0x200u  /* HasMoved marker, maintained by re_tick */
 #define RE_F_HAS_ROTATED 0x400u  /* HasRotated marker, maintained by re_tick */
+#define RE_F_USER        0x800u  /* the user entity (flows/pipeline.rs:125-151): TransformationMatrix stays identity, StaticAABB = OriginalAABB
+                                   * translated by Position; added to the tree as a non-static entity */
 
 typedef struct re_ctx re_ctx;
 

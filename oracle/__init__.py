@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libre_oracle.so")
 # flags (mirror re_oracle.h)
 F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
-F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED = 0x100, 0x200, 0x400
+F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
 
 AABB_DT = np.dtype([("xmin", "f4"), ("xmax", "f4"), ("ymin", "f4"), ("ymax", "f4"), ("zmin", "f4"), ("zmax", "f4")])
 ENTITY_DT = np.dtype([
@@ -133,6 +133,11 @@ def _fp(a):
 
 def aabb(t):
     return Aabb(*[float(x) for x in t])
+
+
+def combine_aabb(a, b):
+    """StaticAABB::combine_aabb (world/bounding_volumes/aabb.rs + world/dimension/range.rs:38-61), epsilon-biased union."""
+    return np.array(lib().ro_combine_aabb(aabb(a), aabb(b)).tup(), dtype=np.float32)
 
 
 def unpack_key(k):

@@ -869,8 +869,17 @@ int ro_register_entities(ro_world *w, uint32_t n, const ro_entity_desc *d) {
         if (e->flags & RO_F_HAS_ROTVEL) { normalize3(d[i].rotvel_axis, e->rotvel); e->rotvel[3] = d[i].rotvel; }
         if (e->flags & RO_F_HAS_ROTACC) { normalize3(d[i].rotacc_axis, e->rotacc); e->rotacc[3] = d[i].rotacc; }
         if (e->flags & RO_F_ALWAYS_EXEC) u32vec_push(&w->always_exec, d[i].id);
+        if (e->flags & RO_F_USER) {
+            /* Pipeline::register_user_entity (flows/pipeline.rs:125-144): OriginalAABB.translate(camera_pos) (aabb.rs translate: each
+             * bound += offset) and an identity TransformationMatrix that nothing recomputes; added non-static (pipeline.rs:151) */
+            memset(e->mat, 0, sizeof e->mat); e->mat[0] = e->mat[5] = e->mat[10] = e->mat[15] = 1.0f;
+            e->aabb = e->original;
+            e->aabb.xmin += e->pos[0]; e->aabb.xmax += e->pos[0]; e->aabb.ymin += e->pos[1]; e->aabb.ymax += e->pos[1];
+            e->aabb.zmin += e->pos[2]; e->aabb.zmax += e->pos[2];
+        } else {
         ro_trs_matrix(e->pos, (e->flags & RO_F_HAS_ROT) != 0, e->rot, e->rot[3], (e->flags & RO_F_HAS_SCALE) != 0, e->scale, e->mat);
         e->aabb = ro_apply_transformation(e->original, e->mat);
+        }
         /* apply_choices: add_entity(id, &transformed, false, is_static, light) (:71) */
         if (ro_tree_add(w, d[i].id, e->aabb, 0, (e->flags & RO_F_STATIC) != 0) != 0) rejected++;
     }

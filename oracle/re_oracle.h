@@ -52,6 +52,7 @@ typedef struct { float xmin, xmax, ymin, ymax, zmin, zmax; } ro_aabb;
 #define RO_F_ALWAYS_EXEC 0x080u  /* AlwaysExecuteLogic written */
 #define RO_F_OOB_LOGIC   0x100u  /* entity type has OutOfBoundsLogic (add_if_out_bounds) */
 #define RO_F_HAS_MOVED   0x200u  /* HasMoved marker (output) */
+#define RO_F_USER        0x800u  /* the user entity (flows/pipeline.rs:125-144): identity TransformationMatrix, StaticAABB = OriginalAABB translated */
 #define RO_F_HAS_ROTATED 0x400u  /* HasRotated marker (output) */
 
 /* One entity as EntityTransformationBuilder would be filled (exports/entity_transformer.rs:12-29) */

@@ -8,7 +8,7 @@ from . import build as _build
 RE_OK = 0
 F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
-F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED = 0x100, 0x200, 0x400
+F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
 CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK = 0x1, 0x2, 0x4
 TICK_ALL_DYNAMIC, TICK_ASYNC = 0x1, 0x2
 (C_POSITION, C_ROTATION, C_SCALE, C_VELOCITY, C_ACCELERATION, C_ROTATION_VEL, C_ROTATION_ACC,

@@ -10,7 +10,7 @@ namespace re {
 // entity flag bits (== RE_F_* of include/re_hip.h) + internal
 constexpr uint32_t F_STATIC = 0x001, F_HAS_VEL = 0x002, F_HAS_ACC = 0x004, F_HAS_ROT = 0x008, F_HAS_ROTVEL = 0x010,
                    F_HAS_ROTACC = 0x020, F_HAS_SCALE = 0x040, F_ALWAYS_EXEC = 0x080, F_OOB_LOGIC = 0x100,
-                   F_HAS_MOVED = 0x200, F_HAS_ROTATED = 0x400, F_DEAD = 0x80000000u;
+                   F_HAS_MOVED = 0x200, F_HAS_ROTATED = 0x400, F_USER = 0x800, F_DEAD = 0x80000000u;
 // world-section flag bits
 constexpr uint8_t CF_STATIC_SECTION = 1;   // member of static_world_sections (bounding_box_tree_v2.rs:1133-1213)
 constexpr uint8_t CF_STATIC_CACHED = 2;    // its static entities are in the render cache (render_flow.rs:549-594)

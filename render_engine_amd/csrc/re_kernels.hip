@@ -38,12 +38,18 @@ __global__ __launch_bounds__(256) void k_transform_assign(RowArrays R, uint32_t 
     float axis[3] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2] }; float angle = R.rot[r * 4 + 3];
     float scl[3] = { R.scale[r * 3 + 0], R.scale[r * 3 + 1], R.scale[r * 3 + 2] };
     float m[16];
-    trs_matrix(pos, (fl & F_HAS_ROT) != 0, axis, angle, (fl & F_HAS_SCALE) != 0, scl, m);
+    Aabb orig = R.orig[r], a;
+    if (fl & F_USER) {
+        // the user entity (Pipeline::register_user_entity, flows/pipeline.rs:125-144): identity matrix, OriginalAABB.translate(position)
+        for (int k = 0; k < 16; k++) m[k] = (k % 5 == 0) ? 1.0f : 0.0f;
+        a = orig; a.xmin += pos[0]; a.xmax += pos[0]; a.ymin += pos[1]; a.ymax += pos[1]; a.zmin += pos[2]; a.zmax += pos[2];
+    } else {
+        trs_matrix(pos, (fl & F_HAS_ROT) != 0, axis, angle, (fl & F_HAS_SCALE) != 0, scl, m);
+        a = apply_transformation(orig, m);
+    }
     float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
     mo[0] = make_float4(m[0], m[1], m[2], m[3]); mo[1] = make_float4(m[4], m[5], m[6], m[7]);
     mo[2] = make_float4(m[8], m[9], m[10], m[11]); mo[3] = make_float4(m[12], m[13], m[14], m[15]);
-    Aabb orig = R.orig[r];
-    Aabb a = apply_transformation(orig, m);
     R.aabb[r] = a;
     Aabb bv = a;
     bool oob = normalize_aabb(&bv, (float)outline);

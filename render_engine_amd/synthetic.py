@@ -151,3 +151,56 @@ def mixed_world(n, seed=1234, centre=(8192.0, 8192.0, 8192.0), spread=900.0, ato
     e["vel"][u(41) < 0.1] = 0                                   # zero-velocity branch
     e["flags"] = flags
     return e
+
+
+SEED_SCENE = 0x5EED0004
+SAMPLE_SCENE_CAMERA = dict(position=(1000.0, 1000.0, 1150.0), direction=(0.0, 0.0, -1.0), far=1000.0)     # main.rs:24-33
+SAMPLE_SCENE_WORLD = dict(outline_length=16384, atomic_length=64)   # threads/render_thread.rs:127, exports/load_models.rs:52 (release build)
+SAMPLE_SCENE_MODEL_INDEX = {"yellowStar": 0, "blueStar": 1, "asteroid": 2, "wormhole": 3, "mine_producer": 4, "_user": 6}   # registration order; 5 = skyBox
+
+
+def sample_scene(models, seed=SEED_SCENE, asteroids_per_sun=20):
+    """configs[0]: the reference's own sample scene (`space_logic`), 45 entities.
+
+    `models` maps model name -> OriginalAABB (6 floats), see tests/golden/sample_scene_models.json.
+    Placement follows the reference's upload functions: stars solar_system/sun.rs:93-159, asteroids
+    asteroid.rs:84-171 (its thread_rng draws replaced by the counter-based RNG, one stream per draw),
+    wormhole wormhole.rs:62-73, mine producer mine_producer.rs:67-79, the user entity flows/pipeline.rs:125-151
+    with the +-5 box of main.rs:35-41 at the camera position.  Entity ids in creation order: the user entity is
+    created by ECS::new (objects/ecs.rs:141), then the instances in registration order (main.rs:59-63).
+    All entities are non-static (EntityTransformationBuilder::new(.., false, ..)); stars sit in sortable bucket 1
+    (write_sortable_component, sun.rs:123).  Lights are not modelled (out of the path)."""
+    n = 1 + 2 + 2 * asteroids_per_sun + 2
+    e = np.zeros(n, ENTITY_DT)
+    e["id"] = np.arange(n, dtype=np.uint32)
+    e["scale"][:] = 1.0
+    deg = np.float32(np.pi / 180.0)
+    ROT = _capi.F_HAS_ROT | _capi.F_HAS_ROTVEL | _capi.F_HAS_SCALE
+
+    def put(i, model, pos, flags, scale=None, rot=None, rotvel=None, sortable=0):
+        e["model_index"][i] = SAMPLE_SCENE_MODEL_INDEX[model]; e["sortable"][i] = sortable
+        e["original"][i] = np.asarray(models[model], np.float32); e["pos"][i] = np.asarray(pos, np.float32); e["flags"][i] = flags
+        if scale is not None: e["scale"][i] = np.float32(scale)
+        if rot is not None: e["rot_axis"][i] = rot[0]; e["rot_angle"][i] = np.float32(rot[1])
+        if rotvel is not None: e["rotvel_axis"][i] = rotvel[0]; e["rotvel"][i] = np.float32(rotvel[1])
+
+    # user entity: OriginalAABB +-5, Position = camera, Velocity = Acceleration = 0 (pipeline.rs:125-144)
+    put(0, "_user", SAMPLE_SCENE_CAMERA["position"], _capi.F_USER | _capi.F_HAS_VEL | _capi.F_HAS_ACC)
+    # Rotation::default() = axis (1,0,0), angle 0 (movement_components.rs:41-47)
+    put(1, "yellowStar", (950.0, 1000.0, 965.0), ROT, 10.0, ((1, 0, 0), 0.0), ((0, 1, 0), np.float32(-40.0) * deg), sortable=1)
+    put(2, "blueStar", (1050.0, 1000.0, 965.0), ROT, 15.0, ((1, 0, 0), 0.0), ((0, 1, 0), np.float32(50.0) * deg), sortable=1)
+    k = 3
+    for sun in (1, 2):
+        for j in range(asteroids_per_sun):
+            i = np.uint64(k)
+            xz = np.float32(360.0) * uniform(seed, i, 0); radius = np.float32(30.0) + np.float32(20.0) * uniform(seed, i, 1)
+            y = np.float32(1000.0) + (np.float32(40.0) * uniform(seed, i, 2) - np.float32(20.0))
+            rate = (np.float32(40.0) * uniform(seed, i, 3) - np.float32(20.0)) * deg
+            x = np.float32(np.cos(xz * deg)) * radius + e["pos"][sun][0]                # calculate_position, asteroid.rs:173-179
+            z = np.float32(np.sin(xz * deg)) * radius + e["pos"][sun][2]
+            put(k, "asteroid", (x, y, z), ROT, 2.0, ((0, 1, 0), np.float32(0.1) * deg), ((0, 1, 0), rate))
+            k += 1
+    put(k, "wormhole", (970.0, 1000.0, 1000.0), _capi.F_HAS_SCALE, 5.0); k += 1
+    put(k, "mine_producer", (980.0, 1000.0, 1000.0), ROT, 5.0, ((1, 0, 0), 0.0), ((1, 0, 0), np.float32(30.0) * deg)); k += 1
+    assert k == n
+    return e
