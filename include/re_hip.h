@@ -185,6 +185,26 @@ int re_copy_visible(re_ctx *ctx, uint32_t *entity_ids_host, float *matrices_host
  * NULLs restore the internal buffers. */
 int re_set_output_buffers(re_ctx *ctx, uint32_t *d_entity_ids, float *d_matrices, uint32_t capacity_instances);
 
+/* Change requests returned by user logic (LogicFunction / CollisionFunction -> Vec<EntityChangeInformation>,
+ * objects/entity_change_request.rs) == apply_change (helper_things/entity_change_helpers.rs:32-189) for the kinds that touch
+ * this path.  Processed in list order with the reference's rules: the last write of a component wins; Position alone takes
+ * the translation-only path (matrix column 3 + translated OriginalAABB), Rotation / Scale force the full TRS recompute; an
+ * entity whose section is unchanged is left where it is; a deleted entity ignores later requests; an entity that leaves the
+ * world is kept when RE_F_OOB_LOGIC, otherwise removed and reported (re_get_out_of_bounds).  Velocity-type components can be
+ * written for entities uploaded with Velocity or VelocityRotation.  The call belongs to the frame's logic phase (after
+ * re_cull_pack): like Pipeline::execute it clears the changed-static-section set afterwards (pipeline.rs:271).
+ * The reference's static render cache is a snapshot the logic phase never refreshes: an entity made static by a change is
+ * therefore not drawn until it wakes up again (modelled), and a static entity of the snapshot that is woken, deleted or
+ * rewritten keeps being drawn with its old bytes (needs ghost instances: RE_E_UNSUPPORTED for now). */
+#define RE_CHANGE_MODIFY       0u  /* ModifyRequest: component = RE_C_POSITION .. RE_C_ROTATION_ACC, value = the new component */
+#define RE_CHANGE_DELETE       1u  /* DeleteRequest (:156-172) */
+#define RE_CHANGE_MAKE_STATIC  2u  /* MakeObjectStatic (:112-122) */
+#define RE_CHANGE_WAKE_UP      3u  /* WakeUpRequest (:123-133) */
+typedef struct re_change { uint32_t kind, entity_id, component, reserved; float value[4]; } re_change;
+/* out: n_changed = entities whose matrix/AABB were recomputed, n_rebucket = of those, entities that changed section,
+ * n_out_of_bounds = entities removed because they left the world */
+int re_apply_changes(re_ctx *ctx, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out /*nullable*/);
+
 /* ECS read-back for user logic (LogicFunction reads components through &ECS, exports/logic_components.rs:15-18) */
 int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst);
 /* entity ids rejected by the last re_tick (update_entity_in_tree, entity_change_helpers.rs:325-351) */

@@ -28,6 +28,10 @@ ENTITY_DT = np.dtype([
 GROUP_DT = np.dtype([("model_index", "u4"), ("render_system", "u4"), ("sortable", "u4"), ("begin", "u4"), ("count", "u4")])
 
 
+CHANGE_DT = np.dtype([("kind", "u4"), ("entity_id", "u4"), ("component", "u4"), ("pad", "u4"), ("value", "f4", (4,))])
+CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP = 0, 1, 2, 3
+
+
 class Aabb(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")]
 
@@ -123,6 +127,8 @@ def lib():
     L.ro_frame_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, u32p]
     L.ro_frame_tick.restype = C.c_uint32
     L.ro_frame_tick.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_float, C.c_uint32, C.c_void_p, u32p]
+    L.ro_apply_changes.restype = C.c_uint32
+    L.ro_apply_changes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p]
     _lib = L
     return L
 
@@ -296,6 +302,13 @@ class World:
         ids = np.zeros(cap, np.uint32); mats = np.zeros((cap, 16), np.float32)
         total = self.L.ro_frame_render(self.h, C.byref(cam), int(emit_duplicates), cap, ids.ctypes.data, mats.ctypes.data, gcap, groups.ctypes.data, C.byref(ng))
         return dict(total=total, ids=ids[:min(total, cap)], mats=mats[:min(total, cap)], groups=groups[:ng.value].copy())
+
+    def apply_changes(self, changes, end_of_frame=True, cap=4096):
+        """changes: structured array CHANGE_DT (kind, entity_id, component, pad, value[4]); returns (n entities re-placed, oob ids)"""
+        ch = np.ascontiguousarray(changes, dtype=CHANGE_DT)
+        oob = np.zeros(cap, np.uint32); noob = C.c_uint32()
+        n = self.L.ro_apply_changes(self.h, ch.ctypes.data, len(ch), 1 if end_of_frame else 0, cap, oob.ctypes.data, C.byref(noob))
+        return n, oob[:min(noob.value, cap)].copy()
 
     def tick(self, cam, dt, cap=4096):
         oob = np.zeros(cap, np.uint32); noob = C.c_uint32()

@@ -517,7 +517,7 @@ typedef struct {
 } shared_t;
 
 /* cached static rendering data of one unique world section (render_flow.rs:549-594) */
-typedef struct { uint32_t id, model_index, render_system, sortable; } cache_ent_t;
+typedef struct { uint32_t id, model_index, render_system, sortable; float mat[16]; } cache_ent_t;   /* the WrittenInformation bytes: a snapshot */
 typedef struct { uint64_t key; cache_ent_t *e; uint32_t n, cap; } cache_t;
 
 typedef struct { uint32_t *v; uint32_t n, cap; } u32vec;
@@ -1046,11 +1046,11 @@ uint32_t ro_frame_cull(ro_world *w, const ro_camera *cam, uint32_t cap, uint64_t
 /* ------------------------------------------------------------------------------------------
  * RenderFlow: static cache, active sort, append, upload (flows/render_flow.rs:401-410)
  * ---------------------------------------------------------------------------------------- */
-typedef struct { uint32_t model_index, render_system, sortable, id; } inst_t;
+typedef struct { uint32_t model_index, render_system, sortable, id; float mat[16]; } inst_t;
 typedef struct { inst_t *v; size_t n, cap; } instvec;
-static void iv_push(instvec *iv, uint32_t m, uint32_t rs, uint32_t so, uint32_t id) {
+static void iv_push(instvec *iv, uint32_t m, uint32_t rs, uint32_t so, uint32_t id, const float *mat) {
     if (iv->n == iv->cap) { iv->cap = iv->cap ? iv->cap * 2 : 1024; iv->v = (inst_t *)realloc(iv->v, iv->cap * sizeof(inst_t)); }
-    inst_t *t = &iv->v[iv->n++]; t->model_index = m; t->render_system = rs; t->sortable = so; t->id = id;
+    inst_t *t = &iv->v[iv->n++]; t->model_index = m; t->render_system = rs; t->sortable = so; t->id = id; memcpy(t->mat, mat, sizeof t->mat);
 }
 static int cmp_inst(const void *a, const void *b) {
     const inst_t *x = (const inst_t *)a, *y = (const inst_t *)b;
@@ -1072,15 +1072,15 @@ static cache_t *cache_for(ro_world *w, uint64_t key, int create) {
 }
 static void cache_push(cache_t *c, const ent_t *e, uint32_t id) {
     if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 2; c->e = (cache_ent_t *)realloc(c->e, c->cap * sizeof(cache_ent_t)); }
-    cache_ent_t *t = &c->e[c->n++]; t->id = id; t->model_index = e->model_index; t->render_system = e->render_system; t->sortable = e->sortable;
+    cache_ent_t *t = &c->e[c->n++]; t->id = id; t->model_index = e->model_index; t->render_system = e->render_system; t->sortable = e->sortable; memcpy(t->mat, e->mat, sizeof t->mat);
 }
 
 /* sort_world_section_static_entities (render_flow.rs:549-594): rebuild the cached static data of
  * every unique section whose static membership changed.  The distance test of
  * sort_unique_world_sections (:749-754) runs with the camera of THIS frame; a section that fails
- * it is cached empty until its static set changes again.  The cache stores entity ids; the
- * reference stores the 64 matrix bytes, which are equal as long as a cached static entity's
- * TransformationMatrix is not rewritten (apply_change re-adds movers as non-static). */
+ * it is cached empty until its static set changes again.  The cache is a SNAPSHOT (ids, model ids and the 64
+ * matrix bytes): changes the logic phase makes to static entities never reach it, because changed_static_unique is
+ * cleared before the next render (pipeline.rs:271). */
 static void rebuild_static_cache(ro_world *w, const ro_camera *cam) {
     if (w->changed_static_unique.n == 0) return;
     u64set_normalize(&w->changed_static_unique);
@@ -1121,7 +1121,7 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
         float d = ci >= 0 ? ro_distance_to_aabb(w->cells[ci].aabb, cam->pos) : 0.0f;
         if (d > cam->far_draw) continue;                             /* :489 */
         for (uint32_t k = 0; k < c->n; k++)
-            iv_push(&iv, ro_lod_adjusted_model_index(c->e[k].model_index, d, cam->n_lod, cam->lod_min, cam->lod_max), c->e[k].render_system, c->e[k].sortable, c->e[k].id);
+            iv_push(&iv, ro_lod_adjusted_model_index(c->e[k].model_index, d, cam->n_lod, cam->lod_min, cam->lod_max), c->e[k].render_system, c->e[k].sortable, c->e[k].id, c->e[k].mat);
     }
     /* sort_world_section_active_entities (:603-653) */
     uint32_t pass = ++w->pass_id;
@@ -1134,7 +1134,7 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
             for (uint32_t k = 0; k < cell->local.n; k++) {
                 const ent_t *e = &w->ents[cell->local.v[k]];
                 if (!e->alive) continue;
-                iv_push(&iv, ro_lod_adjusted_model_index(e->model_index, d, cam->n_lod, cam->lod_min, cam->lod_max), e->render_system, e->sortable, cell->local.v[k]);
+                iv_push(&iv, ro_lod_adjusted_model_index(e->model_index, d, cam->n_lod, cam->lod_min, cam->lod_max), e->render_system, e->sortable, cell->local.v[k], e->mat);
             }
         for (uint32_t s = 0; s < cell->shared.n; s++) {
             shared_t *sh = &w->shared[cell->shared.v[s]];
@@ -1145,7 +1145,7 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
                 for (uint32_t k = 0; k < sh->ents.n; k++) {
                     const ent_t *e = &w->ents[sh->ents.v[k]];
                     if (!e->alive) continue;
-                    iv_push(&iv, ro_lod_adjusted_model_index(e->model_index, d2, cam->n_lod, cam->lod_min, cam->lod_max), e->render_system, e->sortable, sh->ents.v[k]);
+                    iv_push(&iv, ro_lod_adjusted_model_index(e->model_index, d2, cam->n_lod, cam->lod_min, cam->lod_max), e->render_system, e->sortable, sh->ents.v[k], e->mat);
                 }
         }
     }
@@ -1163,7 +1163,7 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
         if (ng - 1 < gcap) groups[ng - 1].count++;
         if (total < cap) {
             if (ids) ids[total] = t->id;
-            if (mats) memcpy(mats + (size_t)total * 16, w->ents[t->id].mat, 16 * sizeof(float));   /* specify_type_ids!: the 64 raw bytes of TransformationMatrix */
+            if (mats) memcpy(mats + (size_t)total * 16, t->mat, 16 * sizeof(float));   /* specify_type_ids!: the 64 raw bytes of TransformationMatrix */
         }
         total++;
     }
@@ -1226,6 +1226,31 @@ static void apply_kinematics_one(const ro_world *w, uint32_t id, float dt, chang
     }
 }
 
+/* update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + update_entity_in_tree (:325-351): translation-only
+ * entities first, then the kinematic ones, each set in ascending EntityId (stand-in for hash order).  Returns the number of
+ * entities that left the world without OutOfBoundsLogic (deleted, :336-349); their ids go to oob_ids[have..]. */
+static uint32_t update_aabb_after_kinematic_change(ro_world *w, const u32set *only_translation_p, const u32set *kinematics_p, uint32_t *oob_ids, uint32_t cap, uint32_t have) {
+    const u32set only_translation = *only_translation_p, kinematics = *kinematics_p;
+    uint32_t noob = have;
+    for (uint32_t i = 0; i < only_translation.n; i++) {
+        uint32_t id = only_translation.v[i]; ent_t *e = &w->ents[id];
+        ro_aabb a = e->original;                                      /* OriginalAABB translated: rotation and scale ignored (:223-224) */
+        a.xmin += e->pos[0]; a.xmax += e->pos[0]; a.ymin += e->pos[1]; a.ymax += e->pos[1]; a.zmin += e->pos[2]; a.zmax += e->pos[2];
+        e->mat[12] = e->pos[0]; e->mat[13] = e->pos[1]; e->mat[14] = e->pos[2];   /* column 3 xyz overwritten (:228-233) */
+        e->aabb = a;
+        /* update_entity_in_tree (:325-351) */
+        if (ro_tree_add(w, id, a, (e->flags & RO_F_OOB_LOGIC) != 0, 0) != 0) { if (noob < cap && oob_ids) oob_ids[noob] = id; noob++; w->ents[id].alive = 0; }
+    }
+    for (uint32_t i = 0; i < kinematics.n; i++) {
+        uint32_t id = kinematics.v[i]; ent_t *e = &w->ents[id];
+        /* Rotation/Scale default when absent (:245-246); all three factors are always applied (:248-250) */
+        ro_trs_matrix(e->pos, 1, e->rot, e->rot[3], 1, e->scale, e->mat);
+        e->aabb = ro_apply_transformation(e->original, e->mat);
+        if (ro_tree_add(w, id, e->aabb, (e->flags & RO_F_OOB_LOGIC) != 0, 0) != 0) { if (noob < cap && oob_ids) oob_ids[noob] = id; noob++; w->ents[id].alive = 0; }
+    }
+    return noob - have;
+}
+
 uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob) {
     (void)cam;
     changevec cv = { 0 };
@@ -1273,27 +1298,67 @@ uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt, uint32_t cap
         if (c->pos_set) { if (!u32set_has(&kinematics, c->id)) u32set_add(&only_translation, c->id); }
         if (c->rot_set) { u32set_add(&kinematics, c->id); u32set_del(&only_translation, c->id); }
     }
-    /* update_aabb_after_kinematic_change (:217-262) */
-    for (uint32_t i = 0; i < only_translation.n; i++) {
-        uint32_t id = only_translation.v[i]; ent_t *e = &w->ents[id];
-        ro_aabb a = e->original;                                      /* OriginalAABB translated: rotation and scale ignored (:223-224) */
-        a.xmin += e->pos[0]; a.xmax += e->pos[0]; a.ymin += e->pos[1]; a.ymax += e->pos[1]; a.zmin += e->pos[2]; a.zmax += e->pos[2];
-        e->mat[12] = e->pos[0]; e->mat[13] = e->pos[1]; e->mat[14] = e->pos[2];   /* column 3 xyz overwritten (:228-233) */
-        e->aabb = a;
-        /* update_entity_in_tree (:325-351) */
-        if (ro_tree_add(w, id, a, (e->flags & RO_F_OOB_LOGIC) != 0, 0) != 0) { if (noob < cap && oob_ids) oob_ids[noob] = id; noob++; w->ents[id].alive = 0; }
-    }
-    for (uint32_t i = 0; i < kinematics.n; i++) {
-        uint32_t id = kinematics.v[i]; ent_t *e = &w->ents[id];
-        /* Rotation/Scale default when absent (:245-246); all three factors are always applied (:248-250) */
-        ro_trs_matrix(e->pos, 1, e->rot, e->rot[3], 1, e->scale, e->mat);
-        e->aabb = ro_apply_transformation(e->original, e->mat);
-        if (ro_tree_add(w, id, e->aabb, (e->flags & RO_F_OOB_LOGIC) != 0, 0) != 0) { if (noob < cap && oob_ids) oob_ids[noob] = id; noob++; w->ents[id].alive = 0; }
-    }
+    noob += update_aabb_after_kinematic_change(w, &only_translation, &kinematics, oob_ids, cap, noob);
     uint32_t napplied = only_translation.n + kinematics.n;
     u32set_free(&only_translation); u32set_free(&kinematics); free(cv.v);
     ro_end_of_changes(w);                                            /* entity_change_helpers.rs:188 */
     u64set_clear(&w->changed_static_unique);                         /* Pipeline::execute -> clear_changed_static_unique (pipeline.rs:271) */
+    if (n_oob) *n_oob = noob;
+    return napplied;
+}
+
+/* apply_change (helper_things/entity_change_helpers.rs:32-189) for the change kinds that touch this path, in list order:
+ * ModifyRequest of one component (apply_entity_change_requests :276-323; a request of several components is the same as its
+ * components one after another: the classification only accumulates), DeleteRequest (:156-172), MakeObjectStatic (:112-122),
+ * WakeUpRequest (:123-133); then update_aabb_after_kinematic_change and end_of_changes (:186-188).
+ * end_of_frame != 0 additionally clears changed_static_unique like Pipeline::execute does after the logic flow (pipeline.rs:271).
+ * Deviation: a DeleteRequest also drops the entity from the translation-only set (the reference would unwrap a removed
+ * component there and panic). */
+uint32_t ro_apply_changes(ro_world *w, const ro_change *ch, uint32_t n, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob) {
+    u32set only_translation = { 0 }, kinematics = { 0 }, deleted = { 0 };
+    for (uint32_t i = 0; i < n; i++) {
+        const ro_change *c = &ch[i];
+        if (c->entity_id >= w->ents_cap || !w->ents[c->entity_id].alive) continue;
+        ent_t *e = &w->ents[c->entity_id];
+        const uint32_t id = c->entity_id;
+        switch (c->kind) {
+        case RO_CHANGE_MODIFY: {
+            if (u32set_has(&deleted, id)) break;
+            int pos = 0, rot = 0, scl = 0;
+            switch (c->component) {
+            case 0: memcpy(e->pos, c->value, 12); pos = 1; break;
+            case 1: normalize3(c->value, e->rot); e->rot[3] = c->value[3]; e->flags |= RO_F_HAS_ROT; rot = 1; break;
+            case 2: memcpy(e->scale, c->value, 12); e->flags |= RO_F_HAS_SCALE; scl = 1; break;
+            case 3: memcpy(e->vel, c->value, 12); e->flags |= RO_F_HAS_VEL; break;
+            case 4: memcpy(e->acc, c->value, 12); e->flags |= RO_F_HAS_ACC; break;
+            case 5: normalize3(c->value, e->rotvel); e->rotvel[3] = c->value[3]; e->flags |= RO_F_HAS_ROTVEL; break;
+            case 6: normalize3(c->value, e->rotacc); e->rotacc[3] = c->value[3]; e->flags |= RO_F_HAS_ROTACC; break;
+            default: break;
+            }
+            if (pos && !rot && !scl) { if (!u32set_has(&kinematics, id)) u32set_add(&only_translation, id); }
+            else if (pos || rot || scl) { u32set_add(&kinematics, id); u32set_del(&only_translation, id); }
+            break;
+        }
+        case RO_CHANGE_DELETE:
+            ro_tree_remove(w, id);
+            u32set_del(&kinematics, id); u32set_del(&only_translation, id); u32set_add(&deleted, id);
+            e->alive = 0;
+            break;
+        case RO_CHANGE_MAKE_STATIC: case RO_CHANGE_WAKE_UP: {
+            const int st = c->kind == RO_CHANGE_MAKE_STATIC;
+            ro_tree_remove(w, id);
+            e = &w->ents[id];
+            if (ro_tree_add(w, id, e->aabb, (e->flags & RO_F_OOB_LOGIC) != 0, st) == 0) { e = &w->ents[id]; if (st) e->flags |= RO_F_STATIC; else e->flags &= ~RO_F_STATIC; }
+            break;
+        }
+        default: break;
+        }
+    }
+    uint32_t noob = update_aabb_after_kinematic_change(w, &only_translation, &kinematics, oob_ids, cap, 0);
+    uint32_t napplied = only_translation.n + kinematics.n;
+    u32set_free(&only_translation); u32set_free(&kinematics); u32set_free(&deleted);
+    ro_end_of_changes(w);
+    if (end_of_frame) u64set_clear(&w->changed_static_unique);
     if (n_oob) *n_oob = noob;
     return napplied;
 }

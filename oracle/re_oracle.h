@@ -168,6 +168,16 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
 uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt,
                        uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
 
+/* FrameChange::EntityChange entries that touch this path (objects/entity_change_request.rs; applied by
+ * helper_things/entity_change_helpers.rs:32-189).  component: 0 Position, 1 Rotation(axis,angle), 2 Scale, 3 Velocity,
+ * 4 Acceleration, 5 VelocityRotation(axis,rate), 6 AccelerationRotation(axis,rate). */
+#define RO_CHANGE_MODIFY      0u
+#define RO_CHANGE_DELETE      1u
+#define RO_CHANGE_MAKE_STATIC 2u
+#define RO_CHANGE_WAKE_UP     3u
+typedef struct { uint32_t kind, entity_id, component, pad; float value[4]; } ro_change;
+uint32_t ro_apply_changes(ro_world *w, const ro_change *changes, uint32_t n, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
+
 /* ---- config 5: deferred lighting, CPU evaluation of render_engine_assets/shaders/second_pass_frag.glsl:20-139 ----
  * Light uniform arrays as RenderSystem uploads them (render_system/render_system.rs:752-766, 814-830). */
 typedef struct {

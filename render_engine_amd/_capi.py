@@ -46,6 +46,9 @@ class Visible(C.Structure):
                 ("d_entity_ids", C.c_void_p), ("d_matrices", C.c_void_p)]
 
 
+CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP = 0, 1, 2, 3
+
+
 class TickResult(C.Structure):
     _fields_ = [("n_changed", C.c_uint32), ("n_rebucket", C.c_uint32), ("n_out_of_bounds", C.c_uint32)]
 
@@ -69,7 +72,7 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
-           "re_wait", "re_copy_visible", "re_set_output_buffers", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_wait", "re_copy_visible", "re_set_output_buffers", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
@@ -101,6 +104,7 @@ def load():
     L.re_cull_pack.restype = C.c_int; L.re_cull_pack.argtypes = [vp, C.POINTER(CameraC), C.c_uint32, C.POINTER(Visible)]
     L.re_tick.restype = C.c_int; L.re_tick.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(TickResult)]
     L.re_wait.restype = C.c_int; L.re_wait.argtypes = [vp, C.POINTER(Visible), C.POINTER(TickResult)]
+    L.re_apply_changes.restype = C.c_int; L.re_apply_changes.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(TickResult)]
     L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]
     L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]
     L.re_read_component.restype = C.c_int; L.re_read_component.argtypes = [vp, C.c_uint32, C.c_int, vp]

@@ -93,6 +93,7 @@ struct re_ctx {
     std::unordered_map<uint32_t, std::array<uint64_t, 8>> h_row_shared_keys;
     std::vector<SharedIdPub> h_shids; std::vector<uint32_t> h_sh_nact, h_sh_nstat;
     bool dirty_pending = false;
+    std::set<uint32_t> h_uncached;                       // rows made static after the static render cache froze: in the tree's static sets, not drawn
     // groups
     uint32_t ngclass = 0, nslots = 0;
     DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
@@ -488,7 +489,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     for (uint32_t r = 0; r < n; r++) if (row_nk[r] == 0) rejected++;
     if (n_rejected) *n_rejected = rejected;
     c->d_shrec.release(acct);
-    c->h_row_key = row_key; c->h_row_nk = row_nk; c->h_gclass = gclass; c->h_row_shared_keys.clear();
+    c->h_row_key = row_key; c->h_row_nk = row_nk; c->h_gclass = gclass; c->h_row_shared_keys.clear(); c->h_uncached.clear();
     for (const SharedRec &sr : shrec) { std::array<uint64_t, 8> a; memcpy(a.data(), sr.keys, sizeof sr.keys); c->h_row_shared_keys[sr.row] = a; }
     int rc = build_sections(c, row_key, row_nk, shrec, flags);
     if (rc != RE_OK) return rc;
@@ -731,7 +732,10 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
 // few affected sections; the key-sorted arrays are then rebuilt, carrying over everything the reference leaves untouched.
 // Host-assisted and O(N log N): correct first; a GPU-resident incremental update is the next step.
 // ------------------------------------------------------------------------------------------------
-static int rebucket(re_ctx *c, uint32_t n_movers) {
+// pre: tree operations an apply_change batch performs inline, before the kinematic re-adds (MakeObjectStatic / WakeUpRequest:
+// remove + add with the other static flag into the same section; DeleteRequest: remove only), in list order.
+struct TreeOp { uint32_t row; uint8_t kind; };                          // kind: 1 = make static, 2 = wake up, 3 = remove
+static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre = nullptr) {
     hipStream_t st = c->stream;
     const uint32_t M = std::min(n_movers, c->list_cap);
     if (n_movers > c->list_cap) return c->fail(RE_E_CAPACITY, "mover list overflow");
@@ -744,11 +748,13 @@ static int rebucket(re_ctx *c, uint32_t n_movers) {
     });
     DevBuf<uint32_t> d_list; DevBuf<uint8_t> d_nk; DevBuf<uint64_t> d_keys;
     HIPCHK(c, d_list.alloc(M, nullptr)); HIPCHK(c, d_nk.alloc(M, nullptr)); HIPCHK(c, d_keys.alloc((size_t)M * 8, nullptr));
-    HIPCHK(c, hipMemcpyAsync(d_list.p, movers.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_assign_rows, dim3((M + 255) / 256), dim3(256), 0, st, M, d_list.p, row_arrays(c), c->cfg.outline_length, c->cfg.atomic_length, d_nk.p, d_keys.p);
     std::vector<uint8_t> nk(M); std::vector<uint64_t> nkeys((size_t)M * 8);
-    HIPCHK(c, hipMemcpyAsync(nk.data(), d_nk.p, M, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(nkeys.data(), d_keys.p, (size_t)M * 64, hipMemcpyDeviceToHost, st));
+    if (M) {
+        HIPCHK(c, hipMemcpyAsync(d_list.p, movers.data(), (size_t)M * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_assign_rows, dim3((M + 255) / 256), dim3(256), 0, st, M, d_list.p, row_arrays(c), c->cfg.outline_length, c->cfg.atomic_length, d_nk.p, d_keys.p);
+        HIPCHK(c, hipMemcpyAsync(nk.data(), d_nk.p, M, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(nkeys.data(), d_keys.p, (size_t)M * 64, hipMemcpyDeviceToHost, st));
+    }
     // previous structure
     Carry carry;
     const uint32_t oc = c->ncells, os = c->nsh;
@@ -793,10 +799,10 @@ static int rebucket(re_ctx *c, uint32_t n_movers) {
     };
     auto mark_shared = [&](const SharedIdPub &id) { if (carry.changed_shared_set.insert(id).second) carry.changed_shared.push_back(id); };
     uint32_t total = 0;
-    for (uint32_t i = 0; i < M; i++) {
-        const uint32_t r = movers[i] & 0x7FFFFFFFu;
+    // one tree operation: remove_entity (:787-942) from the row's current section, then (unless remove_only) add_entity (:563-762)
+    // into the section given by (new_nk, new_keys) with the given static flag
+    auto replay = [&](uint32_t r, bool remove_only, uint32_t new_nk, const uint64_t *new_keys, bool new_static) {
         const bool was_static = (c->h_flags[r] & F_STATIC) != 0;
-        // remove_entity (:787-942)
         if (c->h_row_nk[r] > 1) {
             SharedIdPub id; id.nk = c->h_row_nk[r]; memcpy(id.keys, c->h_row_shared_keys[r].data(), sizeof id.keys);
             SS &sh = shared(id);
@@ -814,27 +820,41 @@ static int rebucket(re_ctx *c, uint32_t n_movers) {
             else total += carry.changed_cells.count(key) ? 1u : cl.nl + cl.ns;
             carry.changed_cells.insert(key);
         }
-        // add_entity with is_static = false (:563-762)
-        if (nk[i] > 1) {
-            SharedIdPub id; id.nk = nk[i]; memcpy(id.keys, &nkeys[(size_t)i * 8], sizeof id.keys);
+        if (remove_only) { c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 0; c->h_row_key[r] = 0; return; }
+        if (new_nk > 1) {
+            SharedIdPub id; id.nk = new_nk; memcpy(id.keys, new_keys, sizeof id.keys);
             SS &sh = shared(id);
+            if (new_static) for (uint32_t k = 0; k < id.nk; k++) carry.changed_static.insert(id.keys[k]);            // :590-596
             if (!sh.exists) { sh = SS{ 0, 0, true }; for (uint32_t k = 0; k < id.nk; k++) { CS &cl = cell(id.keys[k]); if (!cl.exists) cl = CS{ 0, 0, 0, true }; cl.links++; } }
-            sh.na++;
+            if (new_static) sh.nst++; else sh.na++;
             mark_shared(id);
             std::array<uint64_t, 8> a; memcpy(a.data(), id.keys, sizeof id.keys); c->h_row_shared_keys[r] = a;
             c->h_row_key[r] = id.keys[0];
-        } else if (nk[i] == 1) {
-            const uint64_t key = nkeys[(size_t)i * 8];
+        } else if (new_nk == 1) {
+            const uint64_t key = new_keys[0];
             CS &cl = cell(key);
-            if (cl.exists) { cl.nl++; total += carry.changed_cells.count(key) ? 1u : cl.nl + cl.ns; }
-            else { cl = CS{ 1, 0, 0, true }; total += 1; }
+            if (cl.exists) { if (new_static) cl.ns++; else cl.nl++; total += carry.changed_cells.count(key) ? 1u : cl.nl + cl.ns; }
+            else { cl = CS{ new_static ? 0u : 1u, new_static ? 1u : 0u, 0, true }; total += 1; }
+            if (new_static) carry.changed_static.insert(key);
             carry.changed_cells.insert(key);
             c->h_row_shared_keys.erase(r);
             c->h_row_key[r] = key;
         }
-        c->h_row_nk[r] = nk[i];
-        c->h_flags[r] &= ~F_STATIC;
+        c->h_row_nk[r] = (uint8_t)new_nk;
+        if (new_static) c->h_flags[r] |= F_STATIC; else c->h_flags[r] &= ~F_STATIC;
+    };
+    if (pre) for (const TreeOp &op : *pre) {
+        const uint32_t r = op.row;
+        uint64_t cur[8] = {}; const uint32_t cnk = c->h_row_nk[r];
+        if (cnk > 1) memcpy(cur, c->h_row_shared_keys[r].data(), sizeof cur); else cur[0] = c->h_row_key[r];
+        if (op.kind == 3) replay(r, true, 0, nullptr, false);
+        else if (cnk) replay(r, false, cnk, cur, op.kind == 1);            // same StaticAABB => same section(s)
     }
+    for (uint32_t i = 0; i < M; i++) replay(movers[i] & 0x7FFFFFFFu, false, nk[i], &nkeys[(size_t)i * 8], false);   // update_entity_in_tree: is_static = false (:330)
+    // a hidden (made-static-after-the-cache-froze) row that a re-add turned non-static again is drawn again
+    std::vector<uint32_t> reveal;
+    for (auto it = c->h_uncached.begin(); it != c->h_uncached.end();) { if (!(c->h_flags[*it] & F_STATIC)) { reveal.push_back(*it); it = c->h_uncached.erase(it); } else ++it; }
+    for (uint32_t r : reveal) if (!(c->h_flags[r] & F_DEAD)) HIPCHK(c, hipMemcpyAsync(c->d_gclass.p + r, &c->h_gclass[r], 4, hipMemcpyHostToDevice, st));
     carry.too_many = total > 500;
     // ---- rebuild the key-sorted arrays from the patched per-row decisions
     std::vector<SharedRec> shrec; shrec.reserve(c->h_row_shared_keys.size());
@@ -846,11 +866,22 @@ static int rebucket(re_ctx *c, uint32_t n_movers) {
     return RE_OK;
 }
 
+// rows the last tick / change batch removed because they left the world: mirror RE_F_DEAD on the host
+static int absorb_out_of_bounds(re_ctx *c, uint32_t n_oob) {
+    uint32_t cnt = std::min(n_oob, c->list_cap);
+    if (!cnt) return RE_OK;
+    std::vector<uint32_t> rows(cnt);
+    HIPCHK(c, hipMemcpy(rows.data(), c->d_oob.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    for (uint32_t r : rows) if (r < c->n) c->h_flags[r] |= F_DEAD;
+    return RE_OK;
+}
+
 static int finish_tick(re_ctx *c, re_tick_result *out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tick_inflight = false;
     if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
     if (c->ndyn) {
+        if (c->h_th->n_oob) { int rc = absorb_out_of_bounds(c, c->h_th->n_oob); if (rc != RE_OK) return rc; }
         c->n_dead += c->h_th->n_oob; c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob;
         if (c->h_th->n_rebucket) { uint32_t m = c->h_th->n_rebucket; c->h_th->n_rebucket = 0; int rc = rebucket(c, m); if (rc != RE_OK) return rc; }
     }
@@ -885,6 +916,150 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
     c->tick_inflight = true;
     if (flags & RE_TICK_ASYNC) return RE_OK;
     return finish_tick(c, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// re_apply_changes == apply_change (helper_things/entity_change_helpers.rs:32-189) for the change requests user logic returns
+// (LogicFunction / CollisionFunction -> Vec<EntityChangeInformation>): ModifyRequest of the kinematic components, DeleteRequest,
+// MakeObjectStatic, WakeUpRequest.  The list is replayed on the host exactly as the reference does it (the three HashSets of
+// :34-36, last write per component wins, deleted entities ignore later requests); the component values, the new matrices /
+// AABBs / section decisions run on the GPU (k_write_components, k_apply_rows = the tail of the tick kernel), and the tree is
+// patched by the same re-bucket as after a tick.
+// ------------------------------------------------------------------------------------------------
+extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out) {
+    if (!c) return RE_E_ARG;
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_apply_changes: no world uploaded");
+    if (n && !changes) return c->fail(RE_E_ARG, "re_apply_changes: changes is NULL");
+    if (!c->have_cull) return c->fail(RE_E_STATE, "re_apply_changes: apply_change runs inside a frame, after its render (flows/pipeline.rs:212-271); call re_cull_pack first");
+    (void)flags;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::set<uint32_t> kin, trans, deleted;                                   // rows; the mover list is put in the reference's order (ascending EntityId) by rebucket()
+    std::map<std::pair<uint32_t, uint32_t>, std::array<float, 4>> writes;     // (row, component) -> last value
+    std::map<uint32_t, std::pair<uint32_t, uint32_t>> flag_ops;               // row -> (and-mask, or-mask)
+    std::vector<TreeOp> pre;
+    auto flag_op = [&](uint32_t r, uint32_t clear, uint32_t set) {       // recorded only: nothing of the context changes before the whole list is validated
+        auto &f = flag_ops.emplace(r, std::make_pair(0xFFFFFFFFu, 0u)).first->second;
+        f.first &= ~clear; f.second = (f.second & ~clear) | set;
+    };
+    auto dyn_index = [&](uint32_t r, uint32_t &j) -> bool {
+        auto p = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), r);
+        if (p == c->h_dyn_row.end() || *p != r) return false;
+        j = (uint32_t)(p - c->h_dyn_row.begin()); return true;
+    };
+    auto normalized = [](const float *v) { std::array<float, 4> o; float nn = norm3(v[0], v[1], v[2]); o[0] = v[0] / nn; o[1] = v[1] / nn; o[2] = v[2] / nn; o[3] = v[3]; return o; };
+    // The static render cache of the reference is a snapshot that the logic phase can never refresh (render_flow.rs:549-594 reads
+    // changed_static_unique, which pipeline.rs:271 clears before the next render): a cached static entity that is woken, deleted,
+    // moved or rewritten stays in the picture with its old bytes, and an entity made static later is never drawn.  The second case
+    // is modelled (the row keeps its place in the static sets but its group class is hidden); the first needs ghost instances and
+    // is refused for now.
+    std::map<uint32_t, bool> is_static;                                       // static bit as the batch evolves (the host mirror changes during the replay)
+    auto stat = [&](uint32_t r) -> bool & { auto it = is_static.find(r); if (it == is_static.end()) it = is_static.emplace(r, (c->h_flags[r] & F_STATIC) != 0).first; return it->second; };
+    std::set<uint32_t> hide, unhide; bool new_rotvel = false;
+    auto uncached = [&](uint32_t r) { return (c->h_uncached.count(r) && !unhide.count(r)) || hide.count(r); };
+    const char *frozen = "re_apply_changes: entity %u is a static entity of the frozen static render cache; changing it needs ghost instances (not supported yet)";
+    for (uint32_t i = 0; i < n; i++) {
+        const re_change &ch = changes[i];
+        uint32_t r = 0;
+        if (!c->row_of(ch.entity_id, &r)) return c->fail(RE_E_ARG, "re_apply_changes: unknown entity %u (change %u)", ch.entity_id, i);
+        if ((c->h_flags[r] & F_DEAD) || (deleted.count(r) && ch.kind != RE_CHANGE_MODIFY)) continue;   // removed earlier (out of bounds or deleted)
+        switch (ch.kind) {
+            case RE_CHANGE_MODIFY: {
+                if (deleted.count(r)) break;                                   // :281-284
+                bool pos = false, rot = false, scl = false; uint32_t j = 0;
+                std::array<float, 4> v = { ch.value[0], ch.value[1], ch.value[2], ch.value[3] };
+                switch (ch.component) {
+                    case RE_C_POSITION: pos = true; break;
+                    case RE_C_ROTATION: rot = true; v = normalized(ch.value); flag_op(r, 0, F_HAS_ROT); break;       // Rotation::new normalises the axis (movement_components.rs:108-118)
+                    case RE_C_SCALE: scl = true; flag_op(r, 0, F_HAS_SCALE); break;
+                    case RE_C_VELOCITY: case RE_C_ACCELERATION: case RE_C_ROTATION_VEL: case RE_C_ROTATION_ACC:
+                        if (!dyn_index(r, j)) return c->fail(RE_E_UNSUPPORTED, "re_apply_changes: entity %u was uploaded without Velocity / VelocityRotation; it has no slot in the dynamic table", ch.entity_id);
+                        if (ch.component == RE_C_ROTATION_VEL || ch.component == RE_C_ROTATION_ACC) v = normalized(ch.value);
+                        flag_op(r, 0, ch.component == RE_C_VELOCITY ? F_HAS_VEL : ch.component == RE_C_ACCELERATION ? F_HAS_ACC : ch.component == RE_C_ROTATION_VEL ? F_HAS_ROTVEL : F_HAS_ROTACC);
+                        if (ch.component == RE_C_ROTATION_VEL) new_rotvel = true;
+                        break;
+                    default: return c->fail(RE_E_ARG, "re_apply_changes: component %u cannot be modified (change %u)", ch.component, i);
+                }
+                if ((pos || rot || scl) && stat(r) && !uncached(r)) return c->fail(RE_E_UNSUPPORTED, frozen, ch.entity_id);
+                writes[{ r, ch.component }] = v;
+                if (pos && !rot && !scl) { if (!kin.count(r)) trans.insert(r); }
+                else if (pos || rot || scl) { kin.insert(r); trans.erase(r); }
+                break;
+            }
+            case RE_CHANGE_DELETE:
+                if (stat(r) && !uncached(r)) return c->fail(RE_E_UNSUPPORTED, frozen, ch.entity_id);
+                pre.push_back({ r, 3 }); kin.erase(r); trans.erase(r); deleted.insert(r);
+                flag_op(r, 0, F_DEAD);
+                break;
+            case RE_CHANGE_MAKE_STATIC:
+                pre.push_back({ r, 1 }); flag_op(r, 0, F_STATIC);
+                if (!stat(r)) { stat(r) = true; if (unhide.count(r)) unhide.erase(r); else hide.insert(r); }
+                break;
+            case RE_CHANGE_WAKE_UP:
+                if (stat(r) && !uncached(r)) return c->fail(RE_E_UNSUPPORTED, frozen, ch.entity_id);
+                pre.push_back({ r, 2 }); flag_op(r, F_STATIC, 0);
+                if (stat(r)) { stat(r) = false; if (hide.count(r)) hide.erase(r); else unhide.insert(r); }
+                break;
+            default: return c->fail(RE_E_ARG, "re_apply_changes: unknown change kind %u (change %u)", ch.kind, i);
+        }
+    }
+    // ---- the list is valid: from here on the context changes
+    if (new_rotvel) c->has_rotvel = true;
+    for (auto &kv : flag_ops) c->h_flags[kv.first] = (c->h_flags[kv.first] & (kv.second.first | F_STATIC)) | (kv.second.second & ~F_STATIC);   // the static bit follows the tree replay
+    for (uint32_t r : hide) c->h_uncached.insert(r);
+    for (uint32_t r : unhide) c->h_uncached.erase(r);
+    for (uint32_t r : deleted) c->h_uncached.erase(r);
+    std::vector<WriteOp> ops; ops.reserve(writes.size() + flag_ops.size() + hide.size() + unhide.size());
+    for (auto &kv : writes) {
+        WriteOp w{}; w.comp = kv.first.second; w.index = kv.first.first;
+        if (w.comp >= RE_C_VELOCITY && w.comp <= RE_C_ROTATION_ACC) { uint32_t j = 0; dyn_index(kv.first.first, j); w.index = j; }
+        memcpy(w.v, kv.second.data(), 16); ops.push_back(w);
+    }
+    for (uint32_t r : hide) { WriteOp w{}; w.comp = WRITE_GCLASS; w.index = r; w.v[0] = 0xFFFFFFFFu; ops.push_back(w); }
+    for (uint32_t r : unhide) if (!deleted.count(r)) { WriteOp w{}; w.comp = WRITE_GCLASS; w.index = r; w.v[0] = c->h_gclass[r]; ops.push_back(w); }
+    for (auto &kv : flag_ops) { WriteOp w{}; w.comp = WRITE_FLAGS; w.index = kv.first; w.v[0] = kv.second.first; w.v[1] = kv.second.second; w.v[2] = (kv.second.second & F_DEAD) ? 1u : 0u; ops.push_back(w); }
+    std::vector<uint32_t> list; list.reserve(trans.size() + kin.size());
+    for (uint32_t r : trans) list.push_back(r | 0x80000000u);
+    for (uint32_t r : kin) list.push_back(r);
+    if (list.size() > c->list_cap) return c->fail(RE_E_CAPACITY, "re_apply_changes: %zu moved entities exceed the mover list (%u)", list.size(), c->list_cap);
+    TickHeader th{};
+    if (!ops.empty() || !list.empty()) {
+        DevBuf<WriteOp> d_ops; DevBuf<uint32_t> d_list;
+        HIPCHK(c, d_ops.alloc(ops.size(), nullptr)); HIPCHK(c, d_list.alloc(list.size(), nullptr));
+        HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));
+        if (!ops.empty()) {
+            HIPCHK(c, hipMemcpyAsync(d_ops.p, ops.data(), ops.size() * sizeof(WriteOp), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_write_components, dim3(((uint32_t)ops.size() + 255) / 256), dim3(256), 0, st, (uint32_t)ops.size(), d_ops.p, row_arrays(c),
+                               c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p);
+        }
+        if (!list.empty()) {
+            HIPCHK(c, hipMemcpyAsync(d_list.p, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_apply_rows, dim3(((uint32_t)list.size() + 255) / 256), dim3(256), 0, st, (uint32_t)list.size(), d_list.p, row_arrays(c), c->d_row_cell.p,
+                               c->d_cell_key.p, c->d_sh_cells.p, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(&th, c->d_th.p, sizeof th, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        d_ops.release(nullptr); d_list.release(nullptr);
+        c->th_clean = false;
+    }
+    if (th.n_oob) { int rc = absorb_out_of_bounds(c, th.n_oob); if (rc != RE_OK) return rc; }
+    c->n_dead += th.n_oob + (uint32_t)deleted.size();
+    *c->h_th = TickHeader{ th.n_changed, 0, th.n_oob, 0 };                    // re_get_out_of_bounds reports this batch
+    c->last_tick = re_tick_result{ th.n_changed, th.n_rebucket, th.n_oob };
+    if (th.n_rebucket || !pre.empty()) {
+        int rc = rebucket(c, th.n_rebucket, &pre);
+        if (rc != RE_OK) return rc;
+    }
+    if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique after the logic flow (pipeline.rs:271)
+        uint32_t m = std::max(c->ncells, c->nsh);
+        if (m) hipLaunchKernelGGL(k_clear_static_dirty, dim3((m + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_flags.p, c->nsh, c->d_sh_dirty.p);
+        c->dirty_pending = false;
+    }
+    if (out) *out = c->last_tick;
+    return RE_OK;
 }
 
 extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_tick) {

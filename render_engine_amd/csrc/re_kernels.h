@@ -112,6 +112,12 @@ __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, c
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th);
+struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
+constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
+constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)
+__global__ void k_write_components(uint32_t m, const WriteOp *ops, RowArrays R, float *dyn_vel, float *dyn_acc, float *dyn_rotvel, float *dyn_rotacc);
+__global__ void k_apply_rows(uint32_t m, const uint32_t *rows, RowArrays R, const uint32_t *row_cell, const uint64_t *cell_key, const int32_t *sh_cells, uint32_t outline,
+                             uint32_t atomic, TickHeader *th, uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap);
 __global__ void k_assign_rows(uint32_t m, const uint32_t *rows, RowArrays R, uint32_t outline, uint32_t atomic, uint8_t *out_nk, uint64_t *out_keys);
 __global__ void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
                                     const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many, const uint8_t *refold, const Aabb *carried);

@@ -713,6 +713,56 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
     }
 }
 
+// update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + update_entity_in_tree (:325-351) for one entity whose
+// Position / Rotation / Scale changed: new TransformationMatrix and StaticAABB, out-of-bounds handling, and -- only when the
+// spatial-hash section differs (entity_exists_in_section, bounding_box_tree_v2.rs:765-782) -- an entry in the re-bucket list.
+__device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, uint32_t nfl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
+                                                     RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells,
+                                                     uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+    // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262)
+    Aabb orig = R.orig[r], a;
+    float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
+    if (translation_only) {
+        // translation-only fast path: column 3 xyz overwritten, OriginalAABB translated (rotation/scale ignored, :221-240)
+        float4 c3 = mo[3]; c3.x = pos[0]; c3.y = pos[1]; c3.z = pos[2]; mo[3] = c3;
+        a.xmin = orig.xmin + pos[0]; a.xmax = orig.xmax + pos[0]; a.ymin = orig.ymin + pos[1]; a.ymax = orig.ymax + pos[1]; a.zmin = orig.zmin + pos[2]; a.zmax = orig.zmax + pos[2];
+    } else {
+        float scl[3] = { R.scale[r * 3 + 0], R.scale[r * 3 + 1], R.scale[r * 3 + 2] };   // Scale::default() when absent (set at upload)
+        float m[16];
+        trs_matrix(pos, true, rot, rot[3], true, scl, m);                               // all three factors, defaults when absent (:245-250)
+        mo[0] = make_float4(m[0], m[1], m[2], m[3]); mo[1] = make_float4(m[4], m[5], m[6], m[7]);
+        mo[2] = make_float4(m[8], m[9], m[10], m[11]); mo[3] = make_float4(m[12], m[13], m[14], m[15]);
+        a = apply_transformation(orig, m);
+    }
+    R.aabb[r] = a;
+    // update_entity_in_tree -> add_entity (:325-351): same section => nothing else happens
+    Aabb bv = a;
+    bool oob = normalize_aabb(&bv, (float)outline);
+    if (oob && !(fl & F_OOB_LOGIC)) {
+        uint32_t slot = atomicAdd(&th->n_oob, 1u);
+        if (slot < list_cap) oob_rows[slot] = r;
+        R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
+        return;
+    }
+    uint64_t keys[8];
+    int nk = assign_sections(bv, atomic, keys);
+    bool same;
+    if (rc == ROW_CELL_NONE) same = false;
+    else if (!(rc & ROW_CELL_SHARED)) same = (nk == 1) && keys[0] == cell_key[rc];
+    else {
+        uint32_t s = rc & ~ROW_CELL_SHARED;
+        same = nk > 1;
+        for (int k = 0; k < 8 && same; k++) {
+            int32_t c = sh_cells[s * 8 + k];
+            if (k < nk) same = c >= 0 && cell_key[c] == keys[k]; else same = c < 0;
+        }
+    }
+    if (!same) {
+        uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
+        if (slot < list_cap) mover_rows[slot] = r | (translation_only ? 0x80000000u : 0u);   // bit 31: translation-only mover
+    }
+}
+
 __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                             float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
                                             RowArrays R, const uint32_t *__restrict__ row_cell,
@@ -796,48 +846,7 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
     if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
     if (rot_set) { R.rot[r * 4 + 0] = rot[0]; R.rot[r * 4 + 1] = rot[1]; R.rot[r * 4 + 2] = rot[2]; R.rot[r * 4 + 3] = rot[3]; }
 
-    // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262)
-    Aabb orig = R.orig[r], a;
-    float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
-    if (pos_set && !rot_set) {
-        // translation-only fast path: column 3 xyz overwritten, OriginalAABB translated (rotation/scale ignored, :221-240)
-        float4 c3 = mo[3]; c3.x = pos[0]; c3.y = pos[1]; c3.z = pos[2]; mo[3] = c3;
-        a.xmin = orig.xmin + pos[0]; a.xmax = orig.xmax + pos[0]; a.ymin = orig.ymin + pos[1]; a.ymax = orig.ymax + pos[1]; a.zmin = orig.zmin + pos[2]; a.zmax = orig.zmax + pos[2];
-    } else {
-        float scl[3] = { R.scale[r * 3 + 0], R.scale[r * 3 + 1], R.scale[r * 3 + 2] };   // Scale::default() when absent (set at upload)
-        float m[16];
-        trs_matrix(pos, true, rot, rot[3], true, scl, m);                               // all three factors, defaults when absent (:245-250)
-        mo[0] = make_float4(m[0], m[1], m[2], m[3]); mo[1] = make_float4(m[4], m[5], m[6], m[7]);
-        mo[2] = make_float4(m[8], m[9], m[10], m[11]); mo[3] = make_float4(m[12], m[13], m[14], m[15]);
-        a = apply_transformation(orig, m);
-    }
-    R.aabb[r] = a;
-    // update_entity_in_tree -> add_entity (:325-351): same section => nothing else happens
-    Aabb bv = a;
-    bool oob = normalize_aabb(&bv, (float)outline);
-    if (oob && !(fl & F_OOB_LOGIC)) {
-        uint32_t slot = atomicAdd(&th->n_oob, 1u);
-        if (slot < list_cap) oob_rows[slot] = r;
-        R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
-        return;
-    }
-    uint64_t keys[8];
-    int nk = assign_sections(bv, atomic, keys);
-    bool same;
-    if (rc == ROW_CELL_NONE) same = false;
-    else if (!(rc & ROW_CELL_SHARED)) same = (nk == 1) && keys[0] == cell_key[rc];
-    else {
-        uint32_t s = rc & ~ROW_CELL_SHARED;
-        same = nk > 1;
-        for (int k = 0; k < 8 && same; k++) {
-            int32_t c = sh_cells[s * 8 + k];
-            if (k < nk) same = c >= 0 && cell_key[c] == keys[k]; else same = c < 0;
-        }
-    }
-    if (!same) {
-        uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
-        if (slot < list_cap) mover_rows[slot] = r | ((pos_set && !rot_set) ? 0x80000000u : 0u);   // bit 31: translation-only mover
-    }
+    place_changed_entity(r, fl, nfl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap);
 }
 
 // section decision (add_entity with add_if_out_bounds = true: the box is clamped) for a list of rows, from their current StaticAABB;
@@ -857,6 +866,43 @@ __global__ __launch_bounds__(256) void k_assign_rows(uint32_t m, const uint32_t 
     R.flags[r] &= ~F_STATIC;
 }
 // end_of_changes restricted to the changed sections of an incremental update: unchanged sections keep their (possibly stale) AABB
+// Component writes of user change requests (EntityChangeRequest::apply_changes -> ECS::write_component, objects/ecs.rs:457-474),
+// resolved to "last write wins" per (entity, component) on the host.  comp: RE_C_* (0..6) or WRITE_FLAGS (and-mask, or-mask[, kill]).
+__global__ __launch_bounds__(256) void k_write_components(uint32_t m, const WriteOp *__restrict__ ops, RowArrays R, float *__restrict__ dyn_vel, float *__restrict__ dyn_acc,
+                                                          float *__restrict__ dyn_rotvel, float *__restrict__ dyn_rotacc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const WriteOp w = ops[i];
+    const float *v = reinterpret_cast<const float *>(w.v);
+    switch (w.comp) {
+        case 0: for (int k = 0; k < 3; k++) R.pos[(size_t)w.index * 3 + k] = v[k]; break;
+        case 1: for (int k = 0; k < 4; k++) R.rot[(size_t)w.index * 4 + k] = v[k]; break;
+        case 2: for (int k = 0; k < 3; k++) R.scale[(size_t)w.index * 3 + k] = v[k]; break;
+        case 3: for (int k = 0; k < 3; k++) dyn_vel[(size_t)w.index * 3 + k] = v[k]; break;
+        case 4: for (int k = 0; k < 3; k++) dyn_acc[(size_t)w.index * 3 + k] = v[k]; break;
+        case 5: for (int k = 0; k < 4; k++) dyn_rotvel[(size_t)w.index * 4 + k] = v[k]; break;
+        case 6: for (int k = 0; k < 4; k++) dyn_rotacc[(size_t)w.index * 4 + k] = v[k]; break;
+        case WRITE_GCLASS: R.gclass[w.index] = w.v[0]; break;
+        case WRITE_FLAGS: R.flags[w.index] = (R.flags[w.index] & w.v[0]) | w.v[1]; if (w.v[2]) R.gclass[w.index] = 0xFFFFFFFFu; break;
+        default: break;
+    }
+}
+
+// update_aabb_after_kinematic_change for the entities of one apply_change batch: rows[i] bit 31 = translation-only set
+__global__ __launch_bounds__(256) void k_apply_rows(uint32_t m, const uint32_t *__restrict__ rows, RowArrays R, const uint32_t *__restrict__ row_cell,
+                                                    const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells, uint32_t outline, uint32_t atomic,
+                                                    TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t r = rows[i] & 0x7FFFFFFFu; const bool translation_only = (rows[i] >> 31) != 0;
+    const uint32_t fl = R.flags[r];
+    if (fl & F_DEAD) return;
+    const float pos[3] = { R.pos[r * 3 + 0], R.pos[r * 3 + 1], R.pos[r * 3 + 2] };
+    const float rot[4] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2], R.rot[r * 4 + 3] };
+    atomicAdd(&th->n_changed, 1u);
+    place_changed_entity(r, fl, fl, row_cell[r], pos, rot, translation_only, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap);
+}
+
 __global__ __launch_bounds__(256) void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
                                                            const uint32_t *cell_nstatic, const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight,
                                                            uint32_t atomic, int too_many, const uint8_t *refold, const Aabb *carried) {

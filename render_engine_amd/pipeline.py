@@ -79,6 +79,9 @@ def create_level_of_views(render_distance):
     return np.array([0.0, v1, v2, v3, v4], np.float32), np.array([v1, v2, v3, v4, v5], np.float32)
 
 
+CHANGE_DT = np.dtype([("kind", "u4"), ("entity_id", "u4"), ("component", "u4"), ("reserved", "u4"), ("value", "f4", (4,))])   # re_change
+
+
 class Camera:
     """CameraBuilder defaults of the sample game: fov 45 deg, near 0.1 (main.rs:25-30)."""
 
@@ -206,6 +209,14 @@ class Pipeline:
         flags = (_capi.TICK_ALL_DYNAMIC if all_dynamic else 0) | (_capi.TICK_ASYNC if asynchronous else 0)
         self._check(self._L.re_tick(self._h, np.float32(delta_time), flags, C.byref(tr)), "re_tick")
         return None if asynchronous else dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
+
+    def apply_changes(self, changes):
+        """helper_things/entity_change_helpers.rs:32-189 for the change requests of user logic.
+        `changes`: structured array CHANGE_DT (kind, entity_id, component, reserved, value[4])."""
+        ch = np.ascontiguousarray(changes, dtype=CHANGE_DT)
+        tr = _capi.TickResult()
+        self._check(self._L.re_apply_changes(self._h, ch.ctypes.data, len(ch), 0, C.byref(tr)), "re_apply_changes")
+        return dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
 
     def wait(self, copy=False):
         vis = _capi.Visible(); tr = _capi.TickResult()

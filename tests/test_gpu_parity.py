@@ -134,6 +134,7 @@ def test_spinners_tick_parity(R):
     assert total_changed > 0
     spin = ents[(ents["flags"] & R.F_HAS_ROTVEL) != 0]
     check_entities(R, p, w, spin[:300])
+    check_sections(p, w)            # a body that turns inside its section still changes the section's tight AABB (add_entity + end_of_changes)
     # a tick with dt == 0 mirrors the reference's assert
     with pytest.raises(R.RenderEngineError):
         p.tick(0.0)
@@ -223,3 +224,69 @@ def test_truncation_reports(R):
     assert g["total"] > 100 and g["n_written"] == 100 and len(g["ids"]) == 100
     assert int(g["groups"]["count"].sum()) == g["total"]
     p.close()
+
+
+def random_changes(R, ents, rng, n, frozen, centre=(8192.0, 8192.0, 8192.0)):
+    """a batch of user-logic change requests touching every kind and component.  `frozen`: ids of entities that were static when
+    the static render cache froze (first render): only MakeObjectStatic may name them (see re_apply_changes)."""
+    C = R._capi
+    ch = np.zeros(n, R.CHANGE_DT)
+    ids = ents["id"]; fl = ents["flags"]
+    free = ids[~np.isin(ids, list(frozen))]
+    dyn = ids[(fl & (R.F_HAS_VEL | R.F_HAS_ROTVEL)) != 0]
+    for i in range(n):
+        k = rng.random()
+        if k < 0.45:
+            ch[i] = (C.CHANGE_MODIFY, rng.choice(free), C.C_POSITION, 0, tuple(np.float32(centre) + rng.uniform(-700, 700, 3).astype(np.float32)) + (0,))
+        elif k < 0.6:
+            ch[i] = (C.CHANGE_MODIFY, rng.choice(free), C.C_ROTATION, 0, tuple(rng.uniform(-1, 1, 3).astype(np.float32) + np.float32([0, 1.5, 0])) + (np.float32(rng.uniform(-3, 3)),))
+        elif k < 0.7:
+            ch[i] = (C.CHANGE_MODIFY, rng.choice(free), C.C_SCALE, 0, tuple(rng.uniform(0.5, 3, 3).astype(np.float32)) + (0,))
+        elif k < 0.78:
+            comp = rng.choice([C.C_VELOCITY, C.C_ACCELERATION, C.C_ROTATION_VEL, C.C_ROTATION_ACC])
+            v = rng.uniform(-20, 20, 4).astype(np.float32)
+            if comp in (C.C_ROTATION_VEL, C.C_ROTATION_ACC):
+                v[:3] = rng.uniform(-1, 1, 3) + np.array([1.5, 0, 0]); v[3] = rng.uniform(-1, 1)
+            ch[i] = (C.CHANGE_MODIFY, rng.choice(dyn), comp, 0, tuple(v))
+        elif k < 0.86:
+            ch[i] = (C.CHANGE_MAKE_STATIC, rng.choice(ids), 0, 0, (0, 0, 0, 0))
+        elif k < 0.94:
+            ch[i] = (C.CHANGE_WAKE_UP, rng.choice(free), 0, 0, (0, 0, 0, 0))
+        else:
+            ch[i] = (C.CHANGE_DELETE, rng.choice(free), 0, 0, (0, 0, 0, 0))
+    return ch
+
+
+def test_apply_changes_parity(R):
+    """apply_change for user change requests: Modify (all kinematic components), Delete, MakeObjectStatic, WakeUpRequest;
+    several batches interleaved with frames and ticks; sections, entities and visible sets stay bit-exact"""
+    ents = R.synthetic.mixed_world(3000, seed=21, spread=600.0)
+    p, w = build_pair(R, ents)
+    rng = np.random.default_rng(5)
+    cams = [R.Camera((8192 + 40 * i, 8192, 8500 - 30 * i), (0.05 * i, 0, -1), 1200.0) for i in range(5)]
+    alive = ents
+    frozen = set(int(i) for i in ents["id"][(ents["flags"] & R.F_STATIC) != 0])
+    for f, cam in enumerate(cams):
+        check_frame(R, p, w, cam, f % 2 == 1)
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.016)
+        t = p.tick(0.016)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        ch = random_changes(R, alive, rng, 150, frozen)
+        if f == 2:                                           # push a few entities out of the world: with and without OutOfBoundsLogic
+            far = np.zeros(6, R.CHANGE_DT)
+            for i in range(6):
+                far[i] = (R._capi.CHANGE_MODIFY, [e for e in alive["id"] if int(e) not in frozen][10 + i], R._capi.C_POSITION, 0, (-500.0, 8192.0, 20000.0, 0))
+            ch = np.concatenate([ch, far])
+        n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT))
+        g = p.apply_changes(ch)
+        assert g["n_changed"] == n_a and g["n_out_of_bounds"] == len(oob_a), (g, n_a, len(oob_a))
+        assert sorted(p.out_of_bounds()) == sorted(int(i) for i in oob_a)
+        check_sections(p, w)
+        check_entities(R, p, w, ents)
+    check_frame(R, p, w, cams[0], True)
+    # a static entity of the frozen cache cannot be woken, moved or deleted (ghost instances are not modelled): refused, state untouched
+    bad = np.zeros(1, R.CHANGE_DT); bad[0] = (R._capi.CHANGE_WAKE_UP, sorted(frozen)[0], 0, 0, (0, 0, 0, 0))
+    with pytest.raises(R.RenderEngineError):
+        p.apply_changes(bad)
+    check_frame(R, p, w, cams[1], False)
+    p.close(); w.close()
