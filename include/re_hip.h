@@ -207,7 +207,8 @@ int re_apply_changes(re_ctx *ctx, const re_change *changes, uint32_t n, uint32_t
 
 /* ECS read-back for user logic (LogicFunction reads components through &ECS, exports/logic_components.rs:15-18) */
 int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst);
-/* entity ids rejected by the last re_tick (update_entity_in_tree, entity_change_helpers.rs:325-351) */
+/* entity ids removed because they left the world without OutOfBoundsLogic (update_entity_in_tree, entity_change_helpers.rs:
+ * 325-351) by ticks and change batches since the previous call; the call drains the list */
 int re_get_out_of_bounds(re_ctx *ctx, uint32_t *entity_ids, uint32_t capacity, uint32_t *n);
 
 /* ---- introspection (parity tests, profiling) ---- */

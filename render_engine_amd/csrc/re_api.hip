@@ -109,6 +109,10 @@ struct re_ctx {
     uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0;
     DevBuf<FrameHeader> d_hdr; DevBuf<TickHeader> d_th; DevBuf<uint32_t> d_movers, d_oob;
     // results land in mapped pinned host memory, written directly by the kernels (d_* = device view)
+    SpecState *h_spec = nullptr, *d_hspec = nullptr; DevBuf<SpecState> d_spec;     // cross-frame speculation (see SpecState)
+    struct PendingCall { uint8_t kind; uint32_t frame; re_camera cam; uint32_t flags; float dt; };   // kind 0 = cull_pack, 1 = tick
+    std::vector<uint32_t> h_oob_ids;                    // entities removed because they left the world, since the last re_get_out_of_bounds
+    std::vector<PendingCall> pending;                   // calls enqueued since the last resolved synchronisation, in order
     HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr; TickHeader *h_th = nullptr, *d_hth = nullptr;
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
@@ -162,6 +166,8 @@ static void free_world(re_ctx *c) {
     if (c->h_res) { (void)hipHostFree(c->h_res); c->h_res = nullptr; }
     if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
     if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
+    if (c->h_spec) { (void)hipHostFree(c->h_spec); c->h_spec = nullptr; }
+    c->d_spec.release(nullptr); c->pending.clear();
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false;
 }
 
@@ -489,7 +495,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     for (uint32_t r = 0; r < n; r++) if (row_nk[r] == 0) rejected++;
     if (n_rejected) *n_rejected = rejected;
     c->d_shrec.release(acct);
-    c->h_row_key = row_key; c->h_row_nk = row_nk; c->h_gclass = gclass; c->h_row_shared_keys.clear(); c->h_uncached.clear();
+    c->h_row_key = row_key; c->h_row_nk = row_nk; c->h_gclass = gclass; c->h_row_shared_keys.clear(); c->h_uncached.clear(); c->h_oob_ids.clear(); c->pending.clear();
     for (const SharedRec &sr : shrec) { std::array<uint64_t, 8> a; memcpy(a.data(), sr.keys, sizeof sr.keys); c->h_row_shared_keys[sr.row] = a; }
     int rc = build_sections(c, row_key, row_nk, shrec, flags);
     if (rc != RE_OK) return rc;
@@ -506,6 +512,9 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hres), c->h_res, 0));
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hranges), c->h_ranges, 0));
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hth), c->h_th, 0));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_spec), sizeof(SpecState), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hspec), c->h_spec, 0));
+    memset(c->h_spec, 0, sizeof(SpecState)); HIPCHK(c, c->d_spec.alloc(1, nullptr)); HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
     memset(c->h_res, 0, sizeof(HostResult)); memset(c->h_th, 0, sizeof(TickHeader));
     HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, 2 * sizeof(FrameHeader), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
@@ -597,6 +606,7 @@ static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
 }
 
 static int finish_tick(re_ctx *c, re_tick_result *out);
+static int resolve(re_ctx *c);
 
 static void fill_visible(re_ctx *c, re_visible *out) {
     const HostResult &h = *c->h_res;
@@ -633,19 +643,19 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next)
     size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
     // few workgroups for the count: every workgroup flushes its LDS histogram with one global atomic per non-empty group,
     // and a handful of hot (model, LOD) groups saturate near 88 atomics/us per address
-    hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, c->d_item_slot.p, nshards, seg_cap, c->d_group_count.p, c->nslots);
+    hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, c->d_item_slot.p, nshards, seg_cap, c->d_group_count.p, c->nslots, c->d_spec.p);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
-                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres);
+                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p);
     hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
-                       c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap);
+                       c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->d_spec.p);
     HIPCHK(c, hipGetLastError());
     return RE_OK;
 }
 
 static int finish_cull(re_ctx *c, re_visible *out) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc = resolve(c); if (rc != RE_OK) return rc; }
     c->cull_inflight = false;
-    if (c->h_res->overflow) {
+    if (c->h_res->overflow == 1) {
         // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
         int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u));
         if (rc != RE_OK) return rc;
@@ -666,13 +676,9 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     return RE_OK;
 }
 
-extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_visible *out) {
-    if (!c) return RE_E_ARG;
-    if (!cam) return c->fail(RE_E_ARG, "re_cull_pack: camera is NULL");
-    if (!c->h_res) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
-    HIPCHK(c, hipSetDevice(c->device));
+// enqueue one frame's cull + pack (no synchronisation)
+static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     hipStream_t st = c->stream;
-    if (c->tick_inflight && c->ndyn) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }   // movers of the previous tick may change the section table
     if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
@@ -691,13 +697,13 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
     PackArgs A{}; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
-    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres;
+    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p;
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
     ScanCullArgs SA; SA.B = c->PB; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p;
-    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c);
+    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
     static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
 #ifdef RE_EXP_STAMPS
     if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 4, nullptr));
@@ -719,7 +725,21 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[2], st));
     c->have_cull = true; c->cull_inflight = true; c->th_clean = true;
-    if (flags & RE_CULL_ASYNC) return RE_OK;
+    c->pending.push_back(re_ctx::PendingCall{ 0, c->frame, *cam, flags, 0.f });
+    return RE_OK;
+}
+
+static int resolve(re_ctx *c);
+extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_visible *out) {
+    if (!c) return RE_E_ARG;
+    if (!cam) return c->fail(RE_E_ARG, "re_cull_pack: camera is NULL");
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    // Movers of the previous tick may change the section table.  A synchronous call waits for that tick; an asynchronous one is
+    // enqueued speculatively: if the tick does find movers, this frame's kernels cancel themselves and resolve() replays it.
+    if (!(flags & RE_CULL_ASYNC) && c->tick_inflight && c->ndyn) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    int rc = issue_cull(c, cam, flags);
+    if (rc != RE_OK || (flags & RE_CULL_ASYNC)) return rc;
     return finish_cull(c, out);
 }
 
@@ -872,30 +892,22 @@ static int absorb_out_of_bounds(re_ctx *c, uint32_t n_oob) {
     if (!cnt) return RE_OK;
     std::vector<uint32_t> rows(cnt);
     HIPCHK(c, hipMemcpy(rows.data(), c->d_oob.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-    for (uint32_t r : rows) if (r < c->n) c->h_flags[r] |= F_DEAD;
+    for (uint32_t r : rows) if (r < c->n) { c->h_flags[r] |= F_DEAD; c->h_oob_ids.push_back(c->h_id[r]); }
     return RE_OK;
 }
 
 static int finish_tick(re_ctx *c, re_tick_result *out) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int rc = resolve(c);
+    if (rc != RE_OK) return rc;
     c->tick_inflight = false;
     if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
-    if (c->ndyn) {
-        if (c->h_th->n_oob) { int rc = absorb_out_of_bounds(c, c->h_th->n_oob); if (rc != RE_OK) return rc; }
-        c->n_dead += c->h_th->n_oob; c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob;
-        if (c->h_th->n_rebucket) { uint32_t m = c->h_th->n_rebucket; c->h_th->n_rebucket = 0; int rc = rebucket(c, m); if (rc != RE_OK) return rc; }
-    }
+    if (c->ndyn) { c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
     else c->last_tick = re_tick_result{ 0, 0, 0 };
     if (out) *out = c->last_tick;
     return RE_OK;
 }
 
-extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out) {
-    if (!c) return RE_E_ARG;
-    if (!c->h_res) return c->fail(RE_E_STATE, "re_tick: no world uploaded");
-    if (!(flags & RE_TICK_ALL_DYNAMIC) && !c->have_cull) return c->fail(RE_E_STATE, "re_tick: reference semantics tick entities of the last visibility query; call re_cull_pack first or pass RE_TICK_ALL_DYNAMIC");
-    if (dt == 0.0f && c->has_rotvel) return c->fail(RE_E_ARG, "re_tick: delta_time == 0 with rotating entities (the reference asserts, exports/movement_components.rs:287)");
-    HIPCHK(c, hipSetDevice(c->device));
+static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     hipStream_t st = c->stream;
     c->timed_tick = !(flags & RE_TICK_ASYNC);
     if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[3], st));
@@ -903,7 +915,7 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
         hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
-                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_hth);
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_hth, c->d_spec.p, c->d_hspec);
         c->th_clean = false;
     }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
@@ -914,8 +926,48 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
     HIPCHK(c, hipGetLastError());
     if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[4], st));
     c->tick_inflight = true;
-    if (flags & RE_TICK_ASYNC) return RE_OK;
+    c->pending.push_back(re_ctx::PendingCall{ 1, c->frame, re_camera{}, flags, dt });
+    return RE_OK;
+}
+
+extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out) {
+    if (!c) return RE_E_ARG;
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_tick: no world uploaded");
+    if (!(flags & RE_TICK_ALL_DYNAMIC) && !c->have_cull) return c->fail(RE_E_STATE, "re_tick: reference semantics tick entities of the last visibility query; call re_cull_pack first or pass RE_TICK_ALL_DYNAMIC");
+    if (dt == 0.0f && c->has_rotvel) return c->fail(RE_E_ARG, "re_tick: delta_time == 0 with rotating entities (the reference asserts, exports/movement_components.rs:287)");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = issue_tick(c, dt, flags);
+    if (rc != RE_OK || (flags & RE_TICK_ASYNC)) return rc;
     return finish_tick(c, out);
+}
+
+// Synchronise and settle speculation: when a tick raised `stale` (entities changed section or left the world), everything enqueued
+// after it has cancelled itself; patch the tree from that tick's lists, then replay the cancelled calls (which may go stale again).
+static int resolve(re_ctx *c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    while (c->h_spec && c->h_spec->stale) {
+        const uint32_t sf = c->h_spec->stale_frame;
+        c->h_spec->stale = 0; HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
+        const TickHeader th = *c->h_th;
+        if (th.n_oob) { int rc = absorb_out_of_bounds(c, th.n_oob); if (rc != RE_OK) return rc; c->n_dead += th.n_oob; }
+        c->last_tick = re_tick_result{ th.n_changed, th.n_rebucket, th.n_oob };
+        if (th.n_rebucket) { int rc = rebucket(c, th.n_rebucket); if (rc != RE_OK) return rc; }
+        // calls enqueued after that tick did nothing: run them again on the patched tree
+        std::vector<re_ctx::PendingCall> replay; bool after = false;
+        for (const auto &pc : c->pending) { if (after) replay.push_back(pc); else if (pc.kind == 1 && pc.frame == sf) after = true; }
+        c->pending.clear();
+        if (!replay.empty()) {
+            HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, 2 * sizeof(FrameHeader), c->stream)); c->th_clean = false;
+            c->cull_inflight = false;
+            for (const auto &pc : replay) {
+                int rc = pc.kind == 0 ? issue_cull(c, &pc.cam, pc.flags | RE_CULL_ASYNC) : issue_tick(c, pc.dt, pc.flags | RE_TICK_ASYNC);
+                if (rc != RE_OK) return rc;
+            }
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->pending.clear();
+    return RE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,7 +987,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
-    HIPCHK(c, hipStreamSynchronize(st));
+    { int rc = resolve(c); if (rc != RE_OK) return rc; }
     std::set<uint32_t> kin, trans, deleted;                                   // rows; the mover list is put in the reference's order (ascending EntityId) by rebucket()
     std::map<std::pair<uint32_t, uint32_t>, std::array<float, 4>> writes;     // (row, component) -> last value
     std::map<uint32_t, std::pair<uint32_t, uint32_t>> flag_ops;               // row -> (and-mask, or-mask)
@@ -1047,7 +1099,6 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     }
     if (th.n_oob) { int rc = absorb_out_of_bounds(c, th.n_oob); if (rc != RE_OK) return rc; }
     c->n_dead += th.n_oob + (uint32_t)deleted.size();
-    *c->h_th = TickHeader{ th.n_changed, 0, th.n_oob, 0 };                    // re_get_out_of_bounds reports this batch
     c->last_tick = re_tick_result{ th.n_changed, th.n_rebucket, th.n_oob };
     if (th.n_rebucket || !pre.empty()) {
         int rc = rebucket(c, th.n_rebucket, &pre);
@@ -1066,7 +1117,7 @@ extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_t
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = RE_OK;
-    if (c->cull_inflight) rc = finish_cull(c, out_visible); else { HIPCHK(c, hipStreamSynchronize(c->stream)); if (out_visible && c->h_res) fill_visible(c, out_visible); }
+    if (c->cull_inflight) rc = finish_cull(c, out_visible); else { rc = resolve(c); if (rc == RE_OK && out_visible && c->h_res) fill_visible(c, out_visible); }
     if (rc != RE_OK) return rc;
     if (c->tick_inflight) rc = finish_tick(c, out_tick); else if (out_tick) *out_tick = c->last_tick;
     return rc;
@@ -1098,7 +1149,7 @@ extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, v
     uint32_t r = 0;
     if (!c->row_of(entity_id, &r)) return c->fail(RE_E_ARG, "re_read_component: unknown entity %u", entity_id);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
     auto dynidx = [&](uint32_t &j) -> bool {                      // dynamic rows are kept in ascending row order
         auto p = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), r);
         if (p == c->h_dyn_row.end() || *p != r) return false;
@@ -1125,12 +1176,11 @@ extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, v
 extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity, uint32_t *n) {
     if (!c || !c->h_th) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc) return rc; }
-    uint32_t cnt = std::min(c->h_th->n_oob, c->list_cap);
-    std::vector<uint32_t> rows(cnt);
-    if (cnt) HIPCHK(c, hipMemcpy(rows.data(), c->d_oob.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < cnt && i < capacity; i++) if (ids) ids[i] = c->h_id[rows[i]];
+    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc) return rc; } else { int rc = resolve(c); if (rc) return rc; }
+    const uint32_t cnt = (uint32_t)c->h_oob_ids.size();
+    for (uint32_t i = 0; i < cnt && i < capacity; i++) if (ids) ids[i] = c->h_oob_ids[i];
     if (n) *n = cnt;
+    c->h_oob_ids.clear();
     return RE_OK;
 }
 
@@ -1143,7 +1193,7 @@ extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
 extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, float *tight, uint32_t *n_local, uint32_t *n_static, uint8_t *is_static_section, uint32_t *n) {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
     if (n) *n = c->n_real_sections;
     const uint32_t m = c->ncells;
     if (!m || !capacity) return RE_OK;
@@ -1176,7 +1226,7 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
     if (c->ncells) hipLaunchKernelGGL(k_collect_visible, dim3((c->ncells + 255) / 256), dim3(256), 0, c->stream, c->ncells, c->d_cell_stamp.p, c->frame, d_idx, d_mult, cap, d_cnt);
     uint32_t cnt = 0;
     HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
     std::vector<uint32_t> idx(cnt); std::vector<uint8_t> mult(cnt);
     if (cnt) { HIPCHK(c, hipMemcpy(idx.data(), d_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(mult.data(), d_mult, cnt, hipMemcpyDeviceToHost)); }
     (void)hipFree(d_idx); (void)hipFree(d_mult); (void)hipFree(d_cnt);
@@ -1208,7 +1258,7 @@ extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches, uint32_t every)
 extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
     uint32_t launches = c->k1_used / 2;
     for (uint32_t i = 0; i < launches && i < capacity; i++) { float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->k1_events[2 * i], c->k1_events[2 * i + 1])); if (us) us[i] = ms * 1000.f; }
     if (n) *n = launches;

@@ -55,7 +55,12 @@ struct FrameHeader {
                                             // reference), [1] visible sections (map), [2] visible sections (vec, with duplicates)
 };
 struct FrameCounts { uint32_t n_candidates, n_vis_map, n_vis_vec; };
-struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; };
+constexpr uint32_t TICK_TICKET_SHARDS = 32;
+struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * 16]; };   // shard: finished-workgroup counters, one per 64-byte line
+// Speculation across frames of a world with dynamic entities: frames are enqueued without waiting for the previous tick; a tick that
+// finds entities that change section (or leave the world) raises `stale`, and every kernel enqueued after it cancels itself until the
+// host has patched the tree and replayed those frames.
+struct SpecState { uint32_t stale, stale_frame; };
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
@@ -84,13 +89,13 @@ struct ItemSink {
 struct PackArgs {                           // what k_pack_small needs besides the item list
     uint32_t nslots, out_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
-    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres;
+    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; const SpecState *spec;
 };
 struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull after its two leading scalars (the kernel addresses it explicitly)
     PBoxTable B;                            // read by every wave; everything below by candidate waves only
     FrameParams P; FrameParams *P_dev;
     const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic; const uint8_t *cell_flags; uint32_t *cell_stamp;
-    ItemSink K; FrameHeader *hdr; SharedArrays S;
+    ItemSink K; FrameHeader *hdr; SharedArrays S; const SpecState *spec;
 #ifdef RE_EXP_STAMPS
     unsigned long long *timeline;           // development builds: [wave] = {start, keys arrived, end} 100 MHz stamps
 #endif
@@ -103,15 +108,15 @@ constexpr uint32_t SCAN_CULL_ARGS_OFFSET = 48;   // cell_key (8 bytes) + ncells 
 __global__ void k_scan_cull(const uint64_t *cell_key, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
                             uint32_t s3, uint32_t c3, ScanCullArgs A);   // nsp..c3 = ScanSpans as scalars: they arrive preloaded in SGPRs
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K);
-__global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots);
+__global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots, const SpecState *spec);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
-                             const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres);
+                             const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
-                               uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap);
+                               uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap, const SpecState *spec);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
-                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th);
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th, SpecState *spec, SpecState *h_spec);
 struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)

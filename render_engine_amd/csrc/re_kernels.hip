@@ -333,7 +333,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__re
             const ItemSink K = R.K; FrameHeader *hdr = R.hdr;
             const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic;
             const uint8_t *__restrict__ cell_flags = R.cell_flags; uint32_t *__restrict__ cell_stamp = R.cell_stamp;
-            if (lv0 < P.max_level) {
+            if (lv0 < P.max_level && !R.spec->stale) {                       // (a stale tree cancels the frame: see SpecState)
             uint32_t *q = s_cand[wid];
             uint32_t qn = 0;
 #pragma unroll
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__re
         asm volatile("" : "+s"(ka));
         const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
         const uint32_t nsh = R.S.n;
-        if (blockIdx.x * CULL_THREADS < nsh) {
+        if (blockIdx.x * CULL_THREADS < nsh && !R.spec->stale) {
             const SharedArrays S = R.S; const ItemSink K = R.K;
             for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < nsh; s0 += gridDim.x * CULL_THREADS)
                 cull_shared_section(s0 + threadIdx.x, S, cell_key, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
         }
-        if (blockIdx.x == gridDim.x - 1u) {
+        if (blockIdx.x == gridDim.x - 1u && !R.spec->stale) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
             for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
         }
@@ -445,8 +445,9 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
 // K2a (large visible sets): per-group instance counts from the expanded item list.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit_count(const FrameHeader *hdr, const uint32_t *__restrict__ item_slot, uint32_t nshards, uint32_t seg_cap,
-                                                    uint32_t *__restrict__ group_count, uint32_t nslots) {
+                                                    uint32_t *__restrict__ group_count, uint32_t nslots, const SpecState *spec) {
     extern __shared__ uint32_t s_hist[];
+    if (spec->stale) return;
     const bool use_lds = nslots <= LDS_HIST_SLOTS;
     if (use_lds) { for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) s_hist[i] = 0; __syncthreads(); }
     const ShardMap sm = load_shard_map(hdr, nshards, seg_cap);
@@ -466,8 +467,9 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 // render_flow.rs:964-983).  One workgroup; also resets the per-frame counters.
 __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
                                                      uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
-                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres) {
+                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec) {
     __shared__ uint32_t s_wsum[16], s_wcnt[16];
+    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; } return; }
     __shared__ uint32_t s_carry, s_gcarry;
     if (threadIdx.x == 0) { s_carry = 0; s_gcarry = 0; }
     __syncthreads();
@@ -503,9 +505,9 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = fc.n_candidates;
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         *hres = r;                                              // mapped pinned host memory
-        TickHeader tz = {}; *th = tz;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
+    for (uint32_t i = threadIdx.x; i < sizeof(TickHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(th)[i] = 0u;
 }
 
 // K2c: scatter -- the instance pack (specify_type_ids! callback + MappedBuffer::write_data_serialized,
@@ -517,8 +519,9 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
 __global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, const uint32_t *__restrict__ item_row, const uint32_t *__restrict__ item_slot, uint32_t nshards, uint32_t seg_cap,
                                                       const uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill, uint32_t nslots,
                                                       const uint32_t *__restrict__ row_id, const float *__restrict__ row_mat,
-                                                      uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap) {
+                                                      uint32_t *__restrict__ out_ids, float *__restrict__ out_mats, uint32_t out_cap, const SpecState *spec) {
     extern __shared__ uint32_t s_hist[];                       // [nslots] local counts, then the reserved bases
+    if (spec->stale) return;
     __shared__ uint32_t s_pos[256], s_row[256];
     const bool use_lds = nslots <= LDS_HIST_SLOTS;
     const ShardMap sm = load_shard_map(hdr, nshards, seg_cap);
@@ -576,6 +579,10 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
     __shared__ uint32_t s_pos[64], s_row[64];
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
+        if (blockIdx.x == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; }
+        return;
+    }
     const uint32_t nslots = A.nslots;
     uint32_t *s_tot = s_dyn, *s_fill = s_dyn + nslots;
     // raw cursors: a segment that ran over its capacity dropped instances -> the host re-runs the frame through the large path
@@ -649,11 +656,13 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
                 r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
                 *A.hres = r;                                        // mapped pinned host memory
-                if (!overflow) { TickHeader tz = {}; *th = tz; }
             }
         }
         // next frame's cursors / counters (this frame's header stays readable); on overflow the large path does it
-        if (!overflow) for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
+        if (!overflow) {
+            for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
+            for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(th)[i] = 0u;       // the tick of this frame starts from zero counters
+        }
     }
     if (overflow) return;
     // ---- this workgroup's chunk: rank inside the group, then move the matrices (4 lanes per instance, one float4 each) ----
@@ -695,21 +704,35 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
                                               const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                               const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, TickHeader *h_th) {
+                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, TickHeader *h_th,
+                                              SpecState *spec, SpecState *h_spec) {
+    if (spec->stale) return;                                   // an earlier tick left the tree stale: this frame is replayed by the host
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap);
-    // the last workgroup to finish publishes the counters into mapped pinned host memory
-    // (the counters are device-scope atomics, already at L2: no fence is needed before the ticket)
+    // the last workgroup to finish publishes the counters into mapped pinned host memory (the counters are device-scope atomics,
+    // already at L2: no fence is needed before the ticket).  Two-level ticket: a single word saturates near 88 atomics/us, which
+    // would cost several microseconds for a few hundred workgroups.
     __shared__ uint32_t s_last;
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&th->ticket, 1u) == gridDim.x - 1u);
+    if (threadIdx.x == 0) {
+        const uint32_t k = blockIdx.x % TICK_TICKET_SHARDS;
+        const uint32_t in_shard = (gridDim.x - 1u - k) / TICK_TICKET_SHARDS + 1u;
+        const uint32_t nshards = gridDim.x < TICK_TICKET_SHARDS ? gridDim.x : TICK_TICKET_SHARDS;
+        uint32_t last = 0;
+        if (atomicAdd(&th->shard[k * 16u], 1u) == in_shard - 1u) last = (atomicAdd(&th->ticket, 1u) == nshards - 1u) ? 1u : 0u;
+        s_last = last;
+    }
     __syncthreads();
     if (s_last && threadIdx.x == 0) {
-        TickHeader r;
+        TickHeader r = {};
         r.n_changed = __hip_atomic_load(&th->n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         r.n_rebucket = __hip_atomic_load(&th->n_rebucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         r.n_oob = __hip_atomic_load(&th->n_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.ticket = gridDim.x;
-        *h_th = r;
+        h_th->n_changed = r.n_changed; h_th->n_rebucket = r.n_rebucket; h_th->n_oob = r.n_oob; h_th->ticket = r.ticket;
+        if (r.n_rebucket || r.n_oob) {                          // the host must patch the tree (or retire rows) before any later frame may run
+            SpecState sp; sp.stale = 1u; sp.stale_frame = Pp->frame;
+            *spec = sp; *h_spec = sp;
+        }
     }
 }
 

@@ -290,3 +290,31 @@ def test_apply_changes_parity(R):
         p.apply_changes(bad)
     check_frame(R, p, w, cams[1], False)
     p.close(); w.close()
+
+
+def test_async_frames_with_movers_are_replayed(R):
+    """frames of a world with movers enqueued without waiting (speculation): a tick that finds section changes cancels the frames
+    behind it and the library replays them on the patched tree -- the end state equals the frame-by-frame reference"""
+    ents = R.synthetic.mixed_world(3000, seed=21, spread=600.0)
+    ents["vel"] *= 12.0
+    p, w = build_pair(R, ents)
+    cams = [R.Camera((8192 + 25 * i, 8192 - 10 * i, 8600 - 30 * i), (0, 0, -1), 1500.0) for i in range(7)]
+    for cam in cams[:-1]:                                            # reference: one frame after the other
+        oc = oracle_camera(cam); w.cull(oc); w.render(oc); w.tick(oc, 0.05)
+    for cam in cams[:-1]:                                            # GPU path: everything enqueued, nothing awaited
+        p.cull_and_pack(cam, asynchronous=True, copy=False)
+        p.tick(0.05, asynchronous=True)
+    vis, tick = p.wait()
+    assert p.stats()["n_rebuilds"] >= 3 if "n_rebuilds" in p.stats() else True
+    check_sections(p, w)
+    check_entities(R, p, w, ents[:600])
+    check_frame(R, p, w, cams[-1], True)
+    # the same again with a frame loop that mixes styles
+    for i, cam in enumerate(cams):
+        oc = oracle_camera(cam); w.cull(oc); w.render(oc); w.tick(oc, 0.03)
+        p.cull_and_pack(cam, asynchronous=(i % 3 != 0), copy=False)
+        p.tick(0.03, asynchronous=(i % 2 == 0))
+    p.wait()
+    check_sections(p, w)
+    check_entities(R, p, w, ents[:600])
+    p.close(); w.close()
