@@ -71,6 +71,7 @@ typedef struct {
 } re_config;
 
 #define RE_CFG_DEFAULT 0u
+#define RE_CFG_FULL_REBUILD 0x1u  /* testing: after section changes rebuild the whole section table instead of patching it in place */
 
 /* Entities, struct-of-arrays, host pointers; copied during the call.  Optional arrays may be
  * NULL when no entity carries the corresponding flag. */

@@ -46,6 +46,7 @@ class Visible(C.Structure):
                 ("d_entity_ids", C.c_void_p), ("d_matrices", C.c_void_p)]
 
 
+CFG_FULL_REBUILD = 0x1
 CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP = 0, 1, 2, 3
 
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <chrono>
 #include <array>
 #include <set>
 #include <cstdarg>
@@ -93,6 +94,14 @@ struct re_ctx {
     std::unordered_map<uint32_t, std::array<uint64_t, 8>> h_row_shared_keys;
     std::vector<SharedIdPub> h_shids; std::vector<uint32_t> h_sh_nact, h_sh_nstat;
     bool dirty_pending = false;
+    // host mirrors of the section table for incremental patches (see patch_sections)
+    std::vector<uint32_t> h_cell_nl, h_cell_ns, h_cell_begin, h_cell_cap, h_rows;   // per slot; h_rows mirrors the row pool
+    std::vector<uint64_t> base_keys;                    // slot keys of the last full build (sorted: the lookup base and the span hint)
+    std::vector<uint64_t> base_index;                   // every 1024th base key: the cache-resident first level of the lookup
+    DevBuf<uint8_t> d_stage;                            // staging area of patch uploads
+    std::unordered_map<uint64_t, uint32_t> extra_slots;  // sections created since, key -> slot
+    std::vector<std::vector<uint32_t>> free_slots;       // per level: padding / emptied slots a new section of that level may take
+    uint32_t pool_used = 0, pool_cap = 0, n_patches = 0;
     std::set<uint32_t> h_uncached;                       // rows made static after the static render cache froze: in the tree's static sets, not drawn
     // groups
     uint32_t ngclass = 0, nslots = 0;
@@ -236,12 +245,17 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     // pad every level run to whole wave chunks of k_cull_sections (so the level is uniform inside a wave); a pad slot
     // carries the largest key of its level (x = z = y = 0xFFFF: never a world section, outline/atomic <= 32768)
     c->n_real_sections = (uint32_t)keys.size();
+    bool has_movers = false; for (uint32_t r = 0; r < n && !has_movers; r++) has_movers = (flags[r] & F_HAS_VEL) != 0;
     {
         std::vector<uint64_t> padded; padded.reserve(keys.size() + MAX_LEVELS * WAVE_KEYS);
         size_t i = 0;
         while (i < keys.size()) {
             uint32_t lv = key_level(keys[i]);
+            const size_t run0 = padded.size();
             while (i < keys.size() && key_level(keys[i]) == lv) padded.push_back(keys[i++]);
+            // worlds with movers get spare slots per level run (sections created by re-bucket patches live there): ~0.8 %, at least one chunk
+            size_t spare = has_movers ? std::max<size_t>(WAVE_KEYS, (padded.size() - run0) / 128) : 0;
+            for (size_t k = 0; k < spare; k++) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
             while (padded.size() % WAVE_KEYS) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
         }
         keys.swap(padded);
@@ -313,11 +327,16 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     // --- upload
     c->ncells = ncells; c->nsh = nsh; c->nrows_csr = (uint32_t)rows.size();
     c->h_cell_key = keys; c->h_row_cell = row_cell; c->h_shids = shids; c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat;
+    c->base_keys = keys; c->extra_slots.clear(); c->base_index.clear(); for (size_t i = 0; i < keys.size(); i += 1024) c->base_index.push_back(keys[i]); c->h_cell_nl = nlocal; c->h_cell_ns = nstatic; c->h_cell_begin.assign(begin.begin(), begin.begin() + ncells);
+    c->h_cell_cap.resize(ncells); for (uint32_t ci = 0; ci < ncells; ci++) c->h_cell_cap[ci] = nlocal[ci] + nstatic[ci];
+    c->h_rows = rows; c->free_slots.assign(MAX_LEVELS, {});
+    for (uint32_t ci = ncells; ci-- > 0;) if (is_pad(keys[ci])) c->free_slots[key_level(keys[ci]) & (MAX_LEVELS - 1)].push_back(ci);   // popped from the back: lowest slot first
     std::vector<uint64_t> keys_padded(keys); keys_padded.resize((size_t)((ncells + 1) & ~1u) + 2, 0xFFFFFFFFFFFFFFFFull);
     HIPCHK(c, c->d_cell_key.alloc(keys_padded.size(), acct));
     HIPCHK(c, c->d_cell_tight.alloc(ncells, acct)); HIPCHK(c, c->d_cell_begin.alloc(ncells + 1, acct)); HIPCHK(c, c->d_cell_nlocal.alloc(ncells, acct));
     HIPCHK(c, c->d_cell_nstatic.alloc(ncells, acct)); HIPCHK(c, c->d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, c->d_cell_flags.alloc(ncells, acct));
-    HIPCHK(c, c->d_rows.alloc(rows.size(), acct)); HIPCHK(c, c->d_row_cell.alloc(n, acct));
+    c->pool_used = (uint32_t)rows.size(); c->pool_cap = c->pool_used + c->pool_used / 4u + 65536u;      // slack: re-bucket patches append relocated segments
+    HIPCHK(c, c->d_rows.alloc(c->pool_cap, acct)); HIPCHK(c, c->d_row_cell.alloc(n, acct));
     HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
     HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));
     HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
@@ -559,7 +578,7 @@ static ScanSpans candidate_spans(re_ctx *c, uint32_t nchunks) {
     ScanSpans SP{}; const FrameParams &P = c->P;
     const uint32_t per = (uint32_t)(CULL_THREADS / 64) * WAVE_KEYS;
     std::vector<std::pair<uint32_t, uint32_t>> sp;                            // [first chunk, end chunk)
-    const std::vector<uint64_t> &K = c->h_cell_key;
+    const std::vector<uint64_t> &K = c->base_keys;                            // slot order of the last full build (sorted); sections patched in since sit in padding slots and are only a hint short
     for (uint32_t l = 0; l < P.max_level && l < (uint32_t)MAX_LEVELS; l++) {
         uint32_t x0 = 0xFFFFFFFFu, x1 = 0;
         for (int w = 0; w < 2; w++) {
@@ -743,20 +762,261 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     return finish_cull(c, out);
 }
 
+// slot of a world section in the resident table, -1 when it does not exist (base = last full build, overlay = created since)
+static int32_t find_slot(const re_ctx *c, uint64_t key) {
+    auto e = c->extra_slots.find(key);
+    if (e != c->extra_slots.end()) return c->h_cell_key[e->second] == key ? (int32_t)e->second : -1;
+    if (c->base_index.empty()) return -1;
+    // two-level binary search: the block index stays in cache, the second level touches a few lines of the 8 B/section key array
+    size_t blk = std::upper_bound(c->base_index.begin(), c->base_index.end(), key) - c->base_index.begin();
+    if (blk == 0) return -1;
+    const size_t lo = (blk - 1) * 1024, hi = std::min(lo + 1024, c->base_keys.size());
+    auto o = std::lower_bound(c->base_keys.begin() + lo, c->base_keys.begin() + hi, key);
+    if (o != c->base_keys.begin() + hi && *o == key) { size_t sl = o - c->base_keys.begin(); if (c->h_cell_key[sl] == key) return (int32_t)sl; }
+    return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch_sections: the result of a re-bucket written INTO the resident section table instead of rebuilding it -- cost
+// proportional to the sections the movers touched, not to the world.  Sections keep their slot; a section that gains
+// entities beyond its segment's capacity is relocated to the end of the row pool; a new section takes a free (padding or
+// emptied) slot of its level run, so every 512-key chunk of the scan stays level-uniform; an emptied, unlinked section
+// becomes a padding slot.  The (small) shared-section table is rebuilt whole.  Only changed sections are re-folded and
+// re-flagged, exactly what end_of_changes / update_static_world_sections touch (bounding_box_tree_v2.rs:1055-1213).
+// Returns 1 when the slack is exhausted (no free slot of a level, row pool full): the caller rebuilds from scratch.
+// ------------------------------------------------------------------------------------------------
+static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t, std::vector<uint32_t>> &arrive, const std::vector<uint32_t> &removed_rows) {
+    hipStream_t st = c->stream;
+    static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "    patch %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
+    auto is_pad = [](uint64_t k) { return (k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull; };
+    auto by_id = [&](uint32_t a, uint32_t b) { return c->h_id[a] < c->h_id[b]; };
+    // ---- A. shared-section table from the per-row decisions (surviving sections keep their creation order)
+    std::vector<SharedRec> shrec; shrec.reserve(c->h_row_shared_keys.size());
+    for (auto &kv : c->h_row_shared_keys) { SharedRec sr; sr.row = kv.first; sr.nk = c->h_row_nk[kv.first]; memcpy(sr.keys, kv.second.data(), sizeof sr.keys); shrec.push_back(sr); }
+    std::sort(shrec.begin(), shrec.end(), [](const SharedRec &a, const SharedRec &b) { return a.row < b.row; });
+    std::map<SharedIdPub, uint32_t> shmap; std::vector<SharedIdPub> shids; std::vector<std::vector<uint32_t>> sh_act, sh_sta;
+    {
+        std::set<SharedIdPub> alive;
+        for (const SharedRec &sr : shrec) { SharedIdPub id; id.nk = sr.nk; memcpy(id.keys, sr.keys, sizeof id.keys); alive.insert(id); }
+        for (const SharedIdPub &id : c->h_shids) if (alive.count(id)) { shmap.emplace(id, (uint32_t)shids.size()); shids.push_back(id); sh_act.emplace_back(); sh_sta.emplace_back(); }
+    }
+    for (const SharedRec &sr : shrec) {
+        SharedIdPub id; id.nk = sr.nk; memcpy(id.keys, sr.keys, sizeof id.keys);
+        auto it = shmap.find(id); uint32_t s2;
+        if (it == shmap.end()) { s2 = (uint32_t)shids.size(); shmap.emplace(id, s2); shids.push_back(id); sh_act.emplace_back(); sh_sta.emplace_back(); } else s2 = it->second;
+        ((c->h_flags[sr.row] & F_STATIC) ? sh_sta[s2] : sh_act[s2]).push_back(sr.row);
+    }
+    const uint32_t nsh = (uint32_t)shids.size(), old_nsh = c->nsh;
+    for (uint32_t s2 = 0; s2 < nsh; s2++) { std::sort(sh_act[s2].begin(), sh_act[s2].end(), by_id); std::sort(sh_sta[s2].begin(), sh_sta[s2].end(), by_id); }
+    std::set<uint64_t> linked;
+    for (const SharedIdPub &id : shids) for (uint32_t k = 0; k < id.nk; k++) linked.insert(id.keys[k]);
+    lap("A shared");
+    // ---- B. unique sections that may change: changed ones, newly linked ones, formerly linked ones
+    std::set<uint64_t> affected(carry.changed_cells.begin(), carry.changed_cells.end());
+    for (uint64_t k : linked) if (find_slot(c, k) < 0) affected.insert(k);
+    for (const SharedIdPub &id : c->h_shids) for (uint32_t k = 0; k < id.nk; k++) if (!linked.count(id.keys[k])) affected.insert(id.keys[k]);
+    std::vector<Pair64> p_key; std::vector<Pair32> p_begin, p_nl, p_ns, p_rows, p_rowcell, p_stamp;
+    std::map<uint32_t, FlagOp> fops;                                          // one merged op per slot
+    auto fop = [&](uint32_t slot) -> FlagOp & { auto it = fops.find(slot); if (it == fops.end()) { FlagOp f{}; f.idx = slot; f.and_mask = 0xFF; f.or_mask = 0; it = fops.emplace(slot, f).first; } return it->second; };
+    std::vector<uint32_t> refold; std::set<uint32_t> created; std::vector<std::pair<uint32_t, uint32_t>> freed;   // (level, slot): reusable from the next patch on
+    int32_t n_real_delta = 0;
+    for (uint32_t r : removed_rows) if (c->h_row_cell[r] != ROW_CELL_NONE) { c->h_row_cell[r] = ROW_CELL_NONE; p_rowcell.push_back(Pair32{ r, ROW_CELL_NONE }); }
+    for (uint64_t K : affected) {
+        int32_t slot = find_slot(c, K);
+        std::vector<uint32_t> mem;
+        if (slot >= 0) for (uint32_t i = 0, b = c->h_cell_begin[slot], e = c->h_cell_nl[slot] + c->h_cell_ns[slot]; i < e; i++) { uint32_t r = c->h_rows[b + i]; if (c->h_row_nk[r] == 1 && c->h_row_key[r] == K) mem.push_back(r); }
+        auto ar = arrive.find(K);
+        if (ar != arrive.end()) for (uint32_t r : ar->second) if (c->h_row_nk[r] == 1 && c->h_row_key[r] == K) mem.push_back(r);
+        std::sort(mem.begin(), mem.end()); mem.erase(std::unique(mem.begin(), mem.end()), mem.end());
+        std::sort(mem.begin(), mem.end(), [&](uint32_t a, uint32_t b) { bool sa = (c->h_flags[a] & F_STATIC) != 0, sb = (c->h_flags[b] & F_STATIC) != 0; return sa != sb ? sb : c->h_id[a] < c->h_id[b]; });
+        const bool exists = !mem.empty() || linked.count(K);
+        if (!exists) {
+            if (slot < 0) continue;
+            const uint32_t lv = key_level(K) & (MAX_LEVELS - 1);
+            const uint64_t padk = pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu);
+            c->h_cell_key[slot] = padk; c->h_cell_nl[slot] = 0; c->h_cell_ns[slot] = 0; freed.push_back({ lv, (uint32_t)slot }); c->extra_slots.erase(K);
+            p_key.push_back(Pair64{ (uint32_t)slot, 0, padk }); p_nl.push_back(Pair32{ (uint32_t)slot, 0 }); p_ns.push_back(Pair32{ (uint32_t)slot, 0 });
+            FlagOp &f = fop((uint32_t)slot); f.and_mask = 0; f.or_mask = (uint8_t)(CF_PAD | CF_STATIC_SECTION);
+            n_real_delta--;
+            continue;
+        }
+        if (slot < 0) {
+            const uint32_t lv = key_level(K) & (MAX_LEVELS - 1);
+            if (c->free_slots[lv].empty()) return 1;
+            slot = (int32_t)c->free_slots[lv].back(); c->free_slots[lv].pop_back();
+            c->h_cell_key[slot] = K; c->extra_slots[K] = (uint32_t)slot; c->h_cell_cap[slot] = 0; c->h_cell_begin[slot] = 0;
+            p_key.push_back(Pair64{ (uint32_t)slot, 0, K }); p_stamp.push_back(Pair32{ (uint32_t)slot, 0 });
+            FlagOp &f = fop((uint32_t)slot); f.and_mask = 0; f.or_mask = 0;
+            created.insert((uint32_t)slot); n_real_delta++;
+        }
+        const uint32_t size = (uint32_t)mem.size();
+        bool relocated = false;
+        if (size > c->h_cell_cap[slot]) {
+            relocated = true;
+            const uint32_t cap = std::max(4u, size * 2u);
+            if ((uint64_t)c->pool_used + cap > c->pool_cap) return 1;
+            c->h_cell_begin[slot] = c->pool_used; c->h_cell_cap[slot] = cap; c->pool_used += cap;
+            if (c->h_rows.size() < c->pool_used) c->h_rows.resize(c->pool_used, 0);
+            p_begin.push_back(Pair32{ (uint32_t)slot, c->h_cell_begin[slot] });
+        }
+        uint32_t nl = 0; for (uint32_t r : mem) if (!(c->h_flags[r] & F_STATIC)) nl++;
+        c->h_cell_nl[slot] = nl; c->h_cell_ns[slot] = size - nl;
+        p_nl.push_back(Pair32{ (uint32_t)slot, nl }); p_ns.push_back(Pair32{ (uint32_t)slot, size - nl });
+        for (uint32_t i = 0; i < size; i++) {
+            const uint32_t pos = c->h_cell_begin[slot] + i, r = mem[i];
+            if (c->h_rows[pos] != r || relocated) { c->h_rows[pos] = r; p_rows.push_back(Pair32{ pos, r }); }
+            if (c->h_row_cell[r] != (uint32_t)slot) { c->h_row_cell[r] = (uint32_t)slot; p_rowcell.push_back(Pair32{ r, (uint32_t)slot }); }
+        }
+        if (carry.changed_cells.count(K) || created.count((uint32_t)slot)) refold.push_back((uint32_t)slot);
+    }
+    lap("B cells");
+    // ---- C. shared sections: members in one fresh region at the end of the pool, table arrays re-uploaded whole
+    uint32_t sh_total = 0; for (uint32_t s2 = 0; s2 < nsh; s2++) sh_total += (uint32_t)(sh_act[s2].size() + sh_sta[s2].size());
+    if ((uint64_t)c->pool_used + sh_total > c->pool_cap) return 1;
+    std::vector<int32_t> sh_cells((size_t)nsh * 8 + 8, -1); std::vector<uint32_t> sh_begin(nsh + 1, 0), sh_nact(nsh + 1, 0), sh_nstat(nsh + 1, 0);
+    std::unordered_map<uint32_t, std::vector<uint32_t>> cell_links;
+    const uint32_t sh_region = c->pool_used;
+    if (c->h_rows.size() < (size_t)c->pool_used + sh_total) c->h_rows.resize((size_t)c->pool_used + sh_total, 0);
+    for (uint32_t s2 = 0; s2 < nsh; s2++) {
+        for (uint32_t k = 0; k < shids[s2].nk; k++) {
+            int32_t ci = find_slot(c, shids[s2].keys[k]);
+            if (ci < 0) return c->fail(RE_E_STATE, "patch_sections: linked section missing");
+            sh_cells[(size_t)s2 * 8 + k] = ci; cell_links[(uint32_t)ci].push_back(s2);
+        }
+        sh_begin[s2] = c->pool_used; sh_nact[s2] = (uint32_t)sh_act[s2].size(); sh_nstat[s2] = (uint32_t)sh_sta[s2].size();
+        for (int pass = 0; pass < 2; pass++) for (uint32_t r : (pass ? sh_sta[s2] : sh_act[s2])) {
+            c->h_rows[c->pool_used++] = r;
+            if (c->h_row_cell[r] != (ROW_CELL_SHARED | s2)) { c->h_row_cell[r] = ROW_CELL_SHARED | s2; p_rowcell.push_back(Pair32{ r, ROW_CELL_SHARED | s2 }); }
+        }
+    }
+    // rows that left the tree altogether (DeleteRequest)
+    // (their row_cell was set by the caller through `arrive` being empty: handled below by the caller-provided list)
+    // ---- D. update_static_world_sections for the changed sections (first loop), then for the changed shared sections (second loop)
+    auto loop1 = [&](uint32_t slot) {
+        if (c->h_cell_nl[slot] != 0) return false;
+        auto it = cell_links.find(slot);
+        if (it == cell_links.end()) return true;
+        for (uint32_t s2 : it->second) if (sh_nact[s2] == 0) return true;
+        return false;
+    };
+    auto set_static = [&](uint32_t slot, bool v) { FlagOp &f = fop(slot); f.and_mask &= (uint8_t)~CF_STATIC_SECTION; f.or_mask = (uint8_t)((f.or_mask & ~CF_STATIC_SECTION) | (v ? CF_STATIC_SECTION : 0)); };
+    for (uint64_t K : affected) {
+        int32_t slot = find_slot(c, K);
+        if (slot < 0) continue;
+        if (carry.changed_cells.count(K) || created.count((uint32_t)slot)) set_static((uint32_t)slot, loop1((uint32_t)slot));
+    }
+    for (uint64_t K : carry.changed_static) { int32_t slot = find_slot(c, K); if (slot >= 0) fop((uint32_t)slot).or_mask |= CF_STATIC_DIRTY; }
+    {
+        std::vector<uint32_t> order(nsh); for (uint32_t s2 = 0; s2 < nsh; s2++) order[s2] = s2;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return shids[a] < shids[b]; });   // canonical id order
+        // the running value of the flag: what the first loop decided, else unknown -> the ops below are pure set / clear, no read needed
+        for (uint32_t s2 : order) {
+            if (!carry.changed_shared_set.count(shids[s2])) continue;
+            for (uint32_t k = 0; k < shids[s2].nk; k++) {
+                const uint32_t ci = (uint32_t)sh_cells[(size_t)s2 * 8 + k];
+                if (sh_nact[s2] == 0) { if (c->h_cell_nl[ci] == 0) set_static(ci, true); }
+                else set_static(ci, false);
+            }
+        }
+    }
+    // ---- E/F. previous shared-section state (AABB of unchanged sections, cache owner) keyed by id; tiny arrays
+    std::vector<Aabb> old_aabb(old_nsh); std::vector<int32_t> old_owner(old_nsh); std::vector<uint8_t> old_cached(old_nsh);
+    if (old_nsh) {
+        HIPCHK(c, hipMemcpyAsync(old_aabb.data(), c->d_sh_aabb.p, (size_t)old_nsh * sizeof(Aabb), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(old_owner.data(), c->d_sh_owner.p, (size_t)old_nsh * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(old_cached.data(), c->d_sh_cached.p, old_nsh, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    std::map<SharedIdPub, uint32_t> old_index; for (uint32_t s2 = 0; s2 < old_nsh; s2++) old_index.emplace(c->h_shids[s2], s2);
+    std::vector<int32_t> owner(nsh, -1); std::vector<uint8_t> cached(nsh, 0), dirty(nsh, 0);
+    for (uint32_t s2 = 0; s2 < nsh; s2++) {
+        auto it = old_index.find(shids[s2]);
+        if (it == old_index.end()) continue;
+        cached[s2] = old_cached[it->second];
+        const int32_t oo = old_owner[it->second];                               // slots are stable; the owner may have been emptied
+        if (oo >= 0 && !is_pad(c->h_cell_key[oo])) owner[s2] = oo;
+    }
+    lap("C-F");
+    // ---- G. upload + kernels
+    uint64_t *acct = &c->dev_bytes;
+    {
+        std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
+        std::vector<Pair32> *v32[6] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell };
+        uint32_t *dst32[6] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p };
+        size_t bytes = p_key.size() * sizeof(Pair64) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + 64;
+        for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
+        if (c->d_stage.n < bytes) HIPCHK(c, c->d_stage.alloc(bytes * 2, nullptr));
+        std::vector<uint8_t> host(bytes); size_t off = 0;
+        auto put = [&](const void *src, size_t nb) { size_t o = off; if (nb) memcpy(host.data() + off, src, nb); off = (off + nb + 15) & ~(size_t)15; return o; };
+        const size_t o_key = put(p_key.data(), p_key.size() * sizeof(Pair64)), o_fl = put(vf.data(), vf.size() * sizeof(FlagOp)), o_rf = put(refold.data(), refold.size() * 4);
+        size_t o32[6]; for (int k = 0; k < 6; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
+        HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
+        if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
+        for (int k = 0; k < 6; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
+        if (sh_total) HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
+        if (!vf.empty()) hipLaunchKernelGGL(k_flag_ops, dim3(((uint32_t)vf.size() + 255) / 256), dim3(256), 0, st, (uint32_t)vf.size(), reinterpret_cast<const FlagOp *>(c->d_stage.p + o_fl), c->d_cell_flags.p);
+        // end_of_changes: tight AABBs of the changed sections (stream order: after the table patches above)
+        if (!refold.empty()) hipLaunchKernelGGL(k_fold_tight_list, dim3(((uint32_t)refold.size() + 255) / 256), dim3(256), 0, st, (uint32_t)refold.size(), reinterpret_cast<const uint32_t *>(c->d_stage.p + o_rf), c->d_cell_key.p,
+                                                c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, carry.too_many ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));                                 // `host` goes out of scope
+    }
+    lap("G upload");
+    if (nsh || old_nsh) {
+        HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
+        HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));
+        HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
+    }
+    if (nsh) {
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_cells.p, sh_cells.data(), (size_t)nsh * 8 * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_begin.p, sh_begin.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_nact.p, sh_nact.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_nstat.p, sh_nstat.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_owner.p, owner.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_cached.p, cached.data(), nsh, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_dirty.p, dirty.data(), nsh, hipMemcpyHostToDevice, st));
+    }
+    // AABBs of the changed shared sections
+    if (nsh) {
+        hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
+        std::vector<Aabb> sa(nsh);
+        HIPCHK(c, hipMemcpyAsync(sa.data(), c->d_sh_aabb.p, (size_t)nsh * sizeof(Aabb), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (uint32_t s2 = 0; s2 < nsh; s2++) {
+            if (carry.changed_shared_set.count(shids[s2])) continue;
+            auto it = old_index.find(shids[s2]);
+            if (it != old_index.end()) sa[s2] = old_aabb[it->second];
+        }
+        HIPCHK(c, hipMemcpy(c->d_sh_aabb.p, sa.data(), (size_t)nsh * sizeof(Aabb), hipMemcpyHostToDevice));
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (auto &f : freed) c->free_slots[f.first].push_back(f.second);
+    c->nsh = nsh; c->h_shids = shids; sh_nact.resize(nsh); sh_nstat.resize(nsh); c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat;
+    c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + n_real_delta);
+    c->nrows_csr = c->pool_used;
+    if (!carry.changed_static.empty()) c->dirty_pending = true;
+    c->n_patches++;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Incremental re-bucket after a tick: update_entity_in_tree -> BoundingBoxTree::add_entity (which removes the entity from
 // its previous section) for every mover whose section changed, then end_of_changes (helper_things/entity_change_helpers.rs:
 // 217-262, 325-351; world/bounding_box_tree_v2.rs:563-942, 1055-1213).  Order of the reference: translation-only movers, then
 // kinematic movers, each set in ascending EntityId (stand-in for hash order).  The sequential bookkeeping that decides
 // total_world_aabb_combining (> 500 => crowded changed sections fall back to their grid AABB) is replayed exactly on the
-// few affected sections; the key-sorted arrays are then rebuilt, carrying over everything the reference leaves untouched.
-// Host-assisted and O(N log N): correct first; a GPU-resident incremental update is the next step.
+// few affected sections; the result is then patched into the resident table (patch_sections), or -- when its slack is used
+// up -- the key-sorted arrays are rebuilt, carrying over everything the reference leaves untouched.
 // ------------------------------------------------------------------------------------------------
 // pre: tree operations an apply_change batch performs inline, before the kinematic re-adds (MakeObjectStatic / WakeUpRequest:
 // remove + add with the other static flag into the same section; DeleteRequest: remove only), in list order.
 struct TreeOp { uint32_t row; uint8_t kind; };                          // kind: 1 = make static, 2 = wake up, 3 = remove
 static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre = nullptr) {
     hipStream_t st = c->stream;
+    static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
     const uint32_t M = std::min(n_movers, c->list_cap);
     if (n_movers > c->list_cap) return c->fail(RE_E_CAPACITY, "mover list overflow");
     std::vector<uint32_t> movers(M);
@@ -775,26 +1035,12 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         HIPCHK(c, hipMemcpyAsync(nk.data(), d_nk.p, M, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(nkeys.data(), d_keys.p, (size_t)M * 64, hipMemcpyDeviceToHost, st));
     }
-    // previous structure
     Carry carry;
-    const uint32_t oc = c->ncells, os = c->nsh;
-    carry.keys = c->h_cell_key; carry.tight.resize(oc); carry.flags.resize(oc); carry.shids = c->h_shids; carry.sh_aabb.resize(os); carry.sh_cached.resize(os);
-    std::vector<int32_t> sh_owner(os); std::vector<uint32_t> o_nl(oc), o_ns(oc);
-    if (oc) {
-        HIPCHK(c, hipMemcpyAsync(carry.tight.data(), c->d_cell_tight.p, (size_t)oc * sizeof(Aabb), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(carry.flags.data(), c->d_cell_flags.p, oc, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(o_nl.data(), c->d_cell_nlocal.p, (size_t)oc * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(o_ns.data(), c->d_cell_nstatic.p, (size_t)oc * 4, hipMemcpyDeviceToHost, st));
-    }
-    if (os) {
-        HIPCHK(c, hipMemcpyAsync(carry.sh_aabb.data(), c->d_sh_aabb.p, (size_t)os * sizeof(Aabb), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(carry.sh_cached.data(), c->d_sh_cached.p, os, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(sh_owner.data(), c->d_sh_owner.p, (size_t)os * 4, hipMemcpyDeviceToHost, st));
-    }
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (M) HIPCHK(c, hipStreamSynchronize(st));
+    lap("assign");
     d_list.release(nullptr); d_nk.release(nullptr); d_keys.release(nullptr);
-    carry.sh_owner_key_idx = sh_owner; carry.sh_owner_key.resize(os, 0);
-    for (uint32_t s = 0; s < os; s++) if (sh_owner[s] >= 0) carry.sh_owner_key[s] = c->h_cell_key[sh_owner[s]];
+    const uint32_t os = c->nsh;
+    std::map<uint64_t, std::vector<uint32_t>> arrive; std::vector<uint32_t> removed_rows;
     // ---- replay of remove_entity / add_entity on the affected sections (counts only)
     struct CS { uint32_t nl, ns, links; bool exists; };
     struct SS { uint32_t na, nst; bool exists; };
@@ -805,8 +1051,8 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         auto it = cs.find(key);
         if (it != cs.end()) return it->second;
         CS v{ 0, 0, 0, false };
-        auto o = std::lower_bound(carry.keys.begin(), carry.keys.end(), key);
-        if (o != carry.keys.end() && *o == key) { size_t i = o - carry.keys.begin(); v.nl = o_nl[i]; v.ns = o_ns[i]; v.exists = true; auto lc = link_count.find(key); v.links = lc == link_count.end() ? 0u : lc->second; }
+        const int32_t sl = find_slot(c, key);
+        if (sl >= 0) { v.nl = c->h_cell_nl[sl]; v.ns = c->h_cell_ns[sl]; v.exists = true; auto lc = link_count.find(key); v.links = lc == link_count.end() ? 0u : lc->second; }
         return cs.emplace(key, v).first->second;
     };
     auto shared = [&](const SharedIdPub &id) -> SS & {
@@ -840,7 +1086,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
             else total += carry.changed_cells.count(key) ? 1u : cl.nl + cl.ns;
             carry.changed_cells.insert(key);
         }
-        if (remove_only) { c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 0; c->h_row_key[r] = 0; return; }
+        if (remove_only) { c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 0; c->h_row_key[r] = 0; removed_rows.push_back(r); return; }
         if (new_nk > 1) {
             SharedIdPub id; id.nk = new_nk; memcpy(id.keys, new_keys, sizeof id.keys);
             SS &sh = shared(id);
@@ -859,6 +1105,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
             carry.changed_cells.insert(key);
             c->h_row_shared_keys.erase(r);
             c->h_row_key[r] = key;
+            arrive[key].push_back(r);
         }
         c->h_row_nk[r] = (uint8_t)new_nk;
         if (new_static) c->h_flags[r] |= F_STATIC; else c->h_flags[r] &= ~F_STATIC;
@@ -876,7 +1123,35 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     for (auto it = c->h_uncached.begin(); it != c->h_uncached.end();) { if (!(c->h_flags[*it] & F_STATIC)) { reveal.push_back(*it); it = c->h_uncached.erase(it); } else ++it; }
     for (uint32_t r : reveal) if (!(c->h_flags[r] & F_DEAD)) HIPCHK(c, hipMemcpyAsync(c->d_gclass.p + r, &c->h_gclass[r], 4, hipMemcpyHostToDevice, st));
     carry.too_many = total > 500;
-    // ---- rebuild the key-sorted arrays from the patched per-row decisions
+    // ---- write the result into the resident table; rebuild everything only when its slack is exhausted
+    lap("replay");
+    {
+        int prc = (c->cfg.flags & RE_CFG_FULL_REBUILD) ? 1 : patch_sections(c, carry, arrive, removed_rows);
+        lap("patch");
+        if (prc == 0) return RE_OK;
+        if (prc < 0) return prc;
+    }
+    // full rebuild: key-sorted arrays from the patched per-row decisions, carrying over what the reference leaves untouched.
+    // The previous state is fetched by key (slots are no longer key-ordered after patches).
+    {
+        const uint32_t oc = c->ncells;
+        std::vector<Aabb> tight(oc); std::vector<uint8_t> fl(oc);
+        if (oc) { HIPCHK(c, hipMemcpy(tight.data(), c->d_cell_tight.p, (size_t)oc * sizeof(Aabb), hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(fl.data(), c->d_cell_flags.p, oc, hipMemcpyDeviceToHost)); }
+        std::vector<uint32_t> order; order.reserve(oc);
+        for (uint32_t i = 0; i < oc; i++) if ((c->h_cell_key[i] & 0xFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFull) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b2) { return c->h_cell_key[a] < c->h_cell_key[b2]; });
+        carry.keys.resize(order.size()); carry.tight.resize(order.size()); carry.flags.resize(order.size());
+        for (size_t i = 0; i < order.size(); i++) { carry.keys[i] = c->h_cell_key[order[i]]; carry.tight[i] = tight[order[i]]; carry.flags[i] = fl[order[i]]; }
+        carry.shids = c->h_shids; carry.sh_aabb.resize(os); carry.sh_cached.resize(os);
+        std::vector<int32_t> sh_owner(os);
+        if (os) {
+            HIPCHK(c, hipMemcpy(carry.sh_aabb.data(), c->d_sh_aabb.p, (size_t)os * sizeof(Aabb), hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(carry.sh_cached.data(), c->d_sh_cached.p, os, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(sh_owner.data(), c->d_sh_owner.p, (size_t)os * 4, hipMemcpyDeviceToHost));
+        }
+        carry.sh_owner_key_idx = sh_owner; carry.sh_owner_key.resize(os, 0);
+        for (uint32_t s2 = 0; s2 < os; s2++) if (sh_owner[s2] >= 0) carry.sh_owner_key[s2] = c->h_cell_key[sh_owner[s2]];
+    }
     std::vector<SharedRec> shrec; shrec.reserve(c->h_row_shared_keys.size());
     for (auto &kv : c->h_row_shared_keys) { SharedRec sr; sr.row = kv.first; sr.nk = c->h_row_nk[kv.first]; memcpy(sr.keys, kv.second.data(), sizeof sr.keys); shrec.push_back(sr); }
     std::vector<uint32_t> flags(c->h_flags);
@@ -1202,15 +1477,16 @@ extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *key
     HIPCHK(c, hipMemcpy(nl.data(), c->d_cell_nlocal.p, (size_t)m * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(ns.data(), c->d_cell_nstatic.p, (size_t)m * 4, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(f.data(), c->d_cell_flags.p, m, hipMemcpyDeviceToHost));
-    uint32_t o = 0;
-    for (uint32_t i = 0; i < m && o < capacity; i++) {
-        if (f[i] & CF_PAD) continue;                               // padding slots are not world sections
+    std::vector<uint32_t> order; order.reserve(m);
+    for (uint32_t i = 0; i < m; i++) if (!(f[i] & CF_PAD)) order.push_back(i);            // padding slots are not world sections
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->h_cell_key[a] < c->h_cell_key[b]; });   // ascending key (slots are not, after patches)
+    for (uint32_t o = 0; o < order.size() && o < capacity; o++) {
+        const uint32_t i = order[o];
         if (keys) keys[o] = c->h_cell_key[i];
         if (tight) memcpy(tight + (size_t)o * 6, &t[i], 24);
         if (n_local) n_local[o] = nl[i];
         if (n_static) n_static[o] = ns[i];
         if (is_static_section) is_static_section[o] = f[i] & CF_STATIC_SECTION;
-        o++;
     }
     return RE_OK;
 }
@@ -1231,7 +1507,7 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
     if (cnt) { HIPCHK(c, hipMemcpy(idx.data(), d_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(mult.data(), d_mult, cnt, hipMemcpyDeviceToHost)); }
     (void)hipFree(d_idx); (void)hipFree(d_mult); (void)hipFree(d_cnt);
     std::vector<uint32_t> order(cnt); for (uint32_t i = 0; i < cnt; i++) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return idx[a] < idx[b]; });
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->h_cell_key[idx[a]] < c->h_cell_key[idx[b]]; });
     for (uint32_t i = 0; i < cnt && i < capacity; i++) { if (keys) keys[i] = c->h_cell_key[idx[order[i]]]; if (multiplicity) multiplicity[i] = mult[order[i]]; }
     if (n) *n = cnt;
     return RE_OK;

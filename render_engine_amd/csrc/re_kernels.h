@@ -126,6 +126,15 @@ __global__ void k_apply_rows(uint32_t m, const uint32_t *rows, RowArrays R, cons
 __global__ void k_assign_rows(uint32_t m, const uint32_t *rows, RowArrays R, uint32_t outline, uint32_t atomic, uint8_t *out_nk, uint64_t *out_keys);
 __global__ void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
                                     const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many, const uint8_t *refold, const Aabb *carried);
+// incremental section-table patches (host-assisted re-bucket): staged (index, value) pairs scattered into the resident arrays
+struct Pair32 { uint32_t idx, val; };
+struct Pair64 { uint32_t idx, pad; uint64_t val; };
+struct FlagOp { uint32_t idx; uint8_t and_mask, or_mask, pad[2]; };
+__global__ void k_scatter32(uint32_t m, const Pair32 *pairs, uint32_t *dst);
+__global__ void k_scatter64(uint32_t m, const Pair64 *pairs, uint64_t *dst);
+__global__ void k_flag_ops(uint32_t m, const FlagOp *ops, uint8_t *flags);
+__global__ void k_fold_tight_list(uint32_t m, const uint32_t *slots, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
+                                  const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many);
 __global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
 
 }  // namespace re

@@ -944,6 +944,37 @@ __global__ __launch_bounds__(256) void k_fold_tight_masked(uint32_t ncells, cons
     cell_tight[c] = u;
 }
 
+// ---- incremental patches of the resident section table (re-bucket of movers, host-assisted bookkeeping) ----
+__global__ __launch_bounds__(256) void k_scatter32(uint32_t m, const Pair32 *__restrict__ pairs, uint32_t *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[pairs[i].idx] = pairs[i].val;
+}
+__global__ __launch_bounds__(256) void k_scatter64(uint32_t m, const Pair64 *__restrict__ pairs, uint64_t *__restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) dst[pairs[i].idx] = pairs[i].val;
+}
+__global__ __launch_bounds__(256) void k_flag_ops(uint32_t m, const FlagOp *__restrict__ ops, uint8_t *__restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) flags[ops[i].idx] = (uint8_t)((flags[ops[i].idx] & ops[i].and_mask) | ops[i].or_mask);      // one op per slot (the host merges)
+}
+// end_of_changes for the changed sections only (bounding_box_tree_v2.rs:1055-1130): same fold as k_fold_tight
+__global__ __launch_bounds__(256) void k_fold_tight_list(uint32_t m, const uint32_t *__restrict__ slots, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
+                                                         const uint32_t *cell_nstatic, const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t c = slots[i];
+    uint64_t key = cell_key[c];
+    uint32_t n = cell_nlocal[c] + cell_nstatic[c];
+    uint32_t adj = 20u + key_level(key) * 5u; if (adj > 50u) adj = 50u;
+    Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (too_many && n > adj) u = key_to_aabb(key, atomic);
+    else {
+        uint32_t b = cell_begin[c];
+        for (uint32_t k = 0; k < n; k++) { Aabb e = ent_aabb[rows[b + k]]; u = (k == 0) ? e : combine_aabb(u, e); }
+    }
+    cell_tight[c] = u;
+}
+
 // gathers the visible sections of the last cull for re_debug_get_visible_sections
 __global__ __launch_bounds__(256) void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -113,9 +113,9 @@ class Camera:
 class Pipeline:
     """One GPU's share of the world: BoundingBoxTree + ECS columns resident in HBM."""
 
-    def __init__(self, tree_outline_length=16384, tree_atomic_length=64, device=0, max_instances=0):
+    def __init__(self, tree_outline_length=16384, tree_atomic_length=64, device=0, max_instances=0, flags=0):
         self._L = _capi.load()
-        cfg = _capi.Config(device, tree_outline_length, tree_atomic_length, max_instances, 0)
+        cfg = _capi.Config(device, tree_outline_length, tree_atomic_length, max_instances, flags)
         h = C.c_void_p()
         rc = self._L.re_create(C.byref(cfg), C.byref(h))
         if rc != _capi.RE_OK:

@@ -16,8 +16,8 @@ def R():
     return R
 
 
-def build_pair(R, ents, outline=16384, atomic=64):
-    p = R.Pipeline(outline, atomic)
+def build_pair(R, ents, outline=16384, atomic=64, flags=0):
+    p = R.Pipeline(outline, atomic, flags=flags)
     rej = p.register_model_instances(ents)
     w = ro.World(outline, atomic)
     rej_o = w.register(to_oracle(ents))
@@ -193,12 +193,13 @@ def test_async_frames_match_sync(R):
     p.close(); w.close()
 
 
-def test_movers_rebucket_parity(R):
+@pytest.mark.parametrize("full_rebuild", [False, True])
+def test_movers_rebucket_parity(R, full_rebuild):
     """entities that leave their world section (unique <-> unique, unique <-> shared, new and emptied sections): the section table,
     tight AABBs (stale ones included), static flags, visible set and matrices must follow the reference's apply_change semantics"""
     ents = R.synthetic.mixed_world(3000, seed=21, spread=600.0)
     ents["vel"] *= 12.0                                              # fast movers: many section changes per tick
-    p, w = build_pair(R, ents)
+    p, w = build_pair(R, ents, flags=R._capi.CFG_FULL_REBUILD if full_rebuild else 0)   # in-place patches, and the from-scratch fallback
     check_sections(p, w)
     cams = [R.Camera((8192 + 25 * i, 8192 - 10 * i, 8600 - 30 * i), (0, 0, -1), 1500.0) for i in range(6)]
     moved = 0
