@@ -185,6 +185,9 @@ int re_copy_visible(re_ctx *ctx, uint32_t *entity_ids_host, float *matrices_host
 /* Direct the packed output into caller-owned DEVICE buffers (e.g. the all-gather send slab);
  * NULLs restore the internal buffers. */
 int re_set_output_buffers(re_ctx *ctx, uint32_t *d_entity_ids, float *d_matrices, uint32_t capacity_instances);
+/* Optional DEVICE word that receives the number of instances written to the output buffers by every later re_cull_pack (the
+ * header of an all-gather slab, so that the exchange needs no host round trip); NULL switches it off. */
+int re_set_output_count(re_ctx *ctx, uint32_t *d_count);
 
 /* Change requests returned by user logic (LogicFunction / CollisionFunction -> Vec<EntityChangeInformation>,
  * objects/entity_change_request.rs) == apply_change (helper_things/entity_change_helpers.rs:32-189) for the kinds that touch

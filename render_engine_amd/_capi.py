@@ -73,7 +73,7 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_wait", "re_copy_visible", "re_set_output_buffers", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
@@ -115,6 +115,7 @@ def load():
     L.re_debug_get_visible_sections.restype = C.c_int; L.re_debug_get_visible_sections.argtypes = [vp, C.c_uint32, vp, vp, _u32p]
     L.re_get_timings.restype = C.c_int; L.re_get_timings.argtypes = [vp, _fp, _fp, _fp]
     L.re_get_stream.restype = vp; L.re_get_stream.argtypes = [vp]
+    L.re_set_output_count.restype = C.c_int; L.re_set_output_count.argtypes = [vp, vp]
     L.re_timing_begin.restype = C.c_int; L.re_timing_begin.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.re_timing_collect.restype = C.c_int; L.re_timing_collect.argtypes = [vp, vp, C.c_uint32, _u32p]
     L.re_get_last_candidates.restype = C.c_int; L.re_get_last_candidates.argtypes = [vp, _u32p]

@@ -115,11 +115,11 @@ struct re_ctx {
     uint32_t nlists = 0, pred_candidates = 0;             // nlists: 512-key chunks == waves of k_scan_cull
     uint32_t item_cap = 0, out_cap = 0, list_cap = 0;
     DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids; DevBuf<float> d_out_mats;
-    uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0;
+    uint32_t *ext_out_ids = nullptr; float *ext_out_mats = nullptr; uint32_t ext_out_cap = 0; uint32_t *ext_out_count = nullptr;
     DevBuf<FrameHeader> d_hdr; DevBuf<TickHeader> d_th; DevBuf<uint32_t> d_movers, d_oob;
     // results land in mapped pinned host memory, written directly by the kernels (d_* = device view)
     SpecState *h_spec = nullptr, *d_hspec = nullptr; DevBuf<SpecState> d_spec;     // cross-frame speculation (see SpecState)
-    struct PendingCall { uint8_t kind; uint32_t frame; re_camera cam; uint32_t flags; float dt; };   // kind 0 = cull_pack, 1 = tick
+    struct PendingCall { uint8_t kind; uint32_t frame; re_camera cam; uint32_t flags; float dt; uint32_t *out_ids; float *out_mats; uint32_t out_cap; uint32_t *out_count; };   // kind 0 = cull_pack, 1 = tick
     std::vector<uint32_t> h_oob_ids;                    // entities removed because they left the world, since the last re_get_out_of_bounds
     std::vector<PendingCall> pending;                   // calls enqueued since the last resolved synchronisation, in order
     HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr; TickHeader *h_th = nullptr, *d_hth = nullptr;
@@ -664,7 +664,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next)
     // and a handful of hot (model, LOD) groups saturate near 88 atomics/us per address
     hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, c->d_item_slot.p, nshards, seg_cap, c->d_group_count.p, c->nslots, c->d_spec.p);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
-                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p);
+                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p, c->ext_out_count, c->ext_out_ids ? c->ext_out_cap : c->out_cap);
     hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
                        c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->d_spec.p);
     HIPCHK(c, hipGetLastError());
@@ -716,7 +716,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
     PackArgs A{}; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
-    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p;
+    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count;
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
@@ -744,7 +744,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[2], st));
     c->have_cull = true; c->cull_inflight = true; c->th_clean = true;
-    c->pending.push_back(re_ctx::PendingCall{ 0, c->frame, *cam, flags, 0.f });
+    c->pending.push_back(re_ctx::PendingCall{ 0, c->frame, *cam, flags, 0.f, c->ext_out_ids, c->ext_out_mats, c->ext_out_cap, c->ext_out_count });
     return RE_OK;
 }
 
@@ -1201,7 +1201,7 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     HIPCHK(c, hipGetLastError());
     if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[4], st));
     c->tick_inflight = true;
-    c->pending.push_back(re_ctx::PendingCall{ 1, c->frame, re_camera{}, flags, dt });
+    c->pending.push_back(re_ctx::PendingCall{ 1, c->frame, re_camera{}, flags, dt, nullptr, nullptr, 0, nullptr });
     return RE_OK;
 }
 
@@ -1234,10 +1234,13 @@ static int resolve(re_ctx *c) {
         if (!replay.empty()) {
             HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, 2 * sizeof(FrameHeader), c->stream)); c->th_clean = false;
             c->cull_inflight = false;
+            uint32_t *keep_ids = c->ext_out_ids; float *keep_mats = c->ext_out_mats; uint32_t keep_cap = c->ext_out_cap, *keep_cnt = c->ext_out_count;
             for (const auto &pc : replay) {
+                if (pc.kind == 0) { c->ext_out_ids = pc.out_ids; c->ext_out_mats = pc.out_mats; c->ext_out_cap = pc.out_cap; c->ext_out_count = pc.out_count; }   // the buffers that frame was issued with
                 int rc = pc.kind == 0 ? issue_cull(c, &pc.cam, pc.flags | RE_CULL_ASYNC) : issue_tick(c, pc.dt, pc.flags | RE_TICK_ASYNC);
                 if (rc != RE_OK) return rc;
             }
+            c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -1416,6 +1419,12 @@ extern "C" int re_set_output_buffers(re_ctx *c, uint32_t *d_ids, float *d_mats, 
     if (!c) return RE_E_ARG;
     if ((d_ids == nullptr) != (d_mats == nullptr)) return c->fail(RE_E_ARG, "re_set_output_buffers: both pointers or neither");
     c->ext_out_ids = d_ids; c->ext_out_mats = d_mats; c->ext_out_cap = d_ids ? capacity : 0;
+    return RE_OK;
+}
+
+extern "C" int re_set_output_count(re_ctx *c, uint32_t *d_count) {
+    if (!c) return RE_E_ARG;
+    c->ext_out_count = d_count;
     return RE_OK;
 }
 

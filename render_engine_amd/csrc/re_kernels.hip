@@ -467,7 +467,8 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 // render_flow.rs:964-983).  One workgroup; also resets the per-frame counters.
 __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
                                                      uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
-                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec) {
+                                                     InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
+                                                     uint32_t *out_count, uint32_t out_cap) {
     __shared__ uint32_t s_wsum[16], s_wcnt[16];
     if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; } return; }
     __shared__ uint32_t s_carry, s_gcarry;
@@ -505,6 +506,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = fc.n_candidates;
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         *hres = r;                                              // mapped pinned host memory
+        if (out_count) *out_count = s_carry < out_cap ? s_carry : out_cap;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
     for (uint32_t i = threadIdx.x; i < sizeof(TickHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(th)[i] = 0u;
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
                 r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
                 *A.hres = r;                                        // mapped pinned host memory
+                if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
             }
         }
         // next frame's cursors / counters (this frame's header stays readable); on overflow the large path does it

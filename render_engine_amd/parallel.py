@@ -65,3 +65,66 @@ class VisibleAllGather:
         self.last = allgather_packed(self.ids, self.mats, n_written, self.dist)
         torch.cuda.current_stream().synchronize()      # the send slab is rewritten by the next cull
         return self.last
+
+
+class SlabAllGather:
+    """The per-frame exchange without a host round trip: every rank packs its visible instances straight into a
+    fixed-size slab  [count | pad to 64 B | ids[cap] | matrices[cap * 16]]  (the count is written by the pack kernel,
+    re_set_output_count), and one all_gather_into_tensor of the slabs follows the pack in stream order.  Two slabs
+    alternate by frame, so the collective of frame f overlaps the cull of frame f+1; a slab is rewritten only after the
+    collective that read it (two frames earlier) has completed -- enforced on the stream, not on the host.
+    A rank whose visible set exceeds the slab keeps its full result locally (Pipeline results are unaffected); its slab
+    carries the truncated prefix and the header tells the receivers (count == cap means "possibly truncated").
+    xGMI is point to point: the direct all-gather moves each rank's slab over each link once, so the slab is sized
+    for the expected visible set (a few thousand instances), not for the worst case."""
+
+    HEADER_WORDS = 16
+
+    def __init__(self, pipeline, slab_instances, dist, group=None):
+        self.p, self.dist, self.group, self.cap = pipeline, dist, group, int(slab_instances)
+        self.world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        words = self.HEADER_WORDS + self.cap * 17
+        self.slab = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.recv = [torch.zeros(words * self.world, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.work = [None, None]
+        self.frame = 0
+        self.stream = torch.cuda.ExternalStream(pipeline.stream()) if hasattr(torch.cuda, "ExternalStream") else torch.cuda.current_stream()
+
+    def _bind(self, b):
+        base = self.slab[b].data_ptr()
+        self.p.set_output_count(base)
+        self.p.set_output_buffers(base + 4 * self.HEADER_WORDS, base + 4 * (self.HEADER_WORDS + self.cap), self.cap)
+
+    def begin_frame(self):
+        """call before the frame's cull_and_pack: points the pack at this frame's slab"""
+        b = self.frame & 1
+        if self.work[b] is not None:
+            with torch.cuda.stream(self.stream):
+                self.work[b].wait()                      # stream-side: the slab's previous collective has finished
+            self.work[b] = None
+        self._bind(b)
+        return b
+
+    def exchange(self):
+        """call after the frame's (asynchronous) cull_and_pack: enqueues the all-gather behind it"""
+        b = self.frame & 1
+        with torch.cuda.stream(self.stream):
+            self.work[b] = self.dist.all_gather_into_tensor(self.recv[b], self.slab[b], group=self.group, async_op=True)
+        self.frame += 1
+        return b
+
+    def finish(self):
+        for b in (0, 1):
+            if self.work[b] is not None:
+                self.work[b].wait(); self.work[b] = None
+        torch.cuda.synchronize()
+
+    def gathered(self, b):
+        """(ids, matrices, counts) of buffer b in rank order, after finish()"""
+        words = self.HEADER_WORDS + self.cap * 17
+        r = self.recv[b].view(self.world, words)
+        counts = [int(c) for c in r[:, 0].tolist()]
+        ids = torch.cat([r[k, self.HEADER_WORDS:self.HEADER_WORDS + min(counts[k], self.cap)] for k in range(self.world)])
+        mats = torch.cat([r[k, self.HEADER_WORDS + self.cap:].view(torch.float32).view(self.cap, 16)[:min(counts[k], self.cap)] for k in range(self.world)])
+        return ids, mats, counts

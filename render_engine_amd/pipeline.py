@@ -226,6 +226,9 @@ class Pipeline:
     def set_output_buffers(self, ids_ptr, mats_ptr, capacity):
         self._check(self._L.re_set_output_buffers(self._h, ids_ptr, mats_ptr, capacity), "re_set_output_buffers")
 
+    def set_output_count(self, count_ptr):
+        self._check(self._L.re_set_output_count(self._h, count_ptr), "re_set_output_count")
+
     # -- ECS read-back -----------------------------------------------------------------------------
     def read_component(self, entity_id, component):
         if component == _capi.C_FLAGS:
