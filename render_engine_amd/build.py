@@ -17,7 +17,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fgpu-rdc", "-Wall", "-Wno-unused-result",
          # gfx950 hands the first kernel-argument dwords to each wave in SGPRs at launch: k_scan_cull's key pointer and count
          # arrive without a scalar-load round trip in front of the key loads
-         "-mllvm", "-amdgpu-kernarg-preload-count=12"]
+         "-mllvm", "-amdgpu-kernarg-preload-count=14"]
 
 
 def needs_build():

@@ -108,6 +108,7 @@ struct re_ctx {
     DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
     // frame
     uint32_t frame = 0; bool have_cull = false;
+    DevBuf<uint32_t> d_cell_key32, d_chunk_level; bool key32 = false; PBox32Table PB32{};   // compact keys for the stream (worlds of <= 512 sections per axis)
     FrameParams P{}; PBoxTable PB{}; DevBuf<FrameParams> d_params;
 #ifdef RE_EXP_STAMPS
     DevBuf<unsigned long long> d_timeline;
@@ -200,6 +201,11 @@ static RowArrays row_arrays(re_ctx *c) {
 // World-section structure from the per-row section keys (the spatial hash as key-sorted arrays).
 // Bulk semantics of one registration batch followed by BoundingBoxTree::end_of_changes.
 // ------------------------------------------------------------------------------------------------
+static inline uint32_t to_key32(uint64_t k) {
+    if ((k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull) return KEY32_PAD | 0x1FF7FDFFu;      // padding slot
+    return ((uint32_t)key_x(k) << 20) | ((uint32_t)key_z(k) << 10) | (uint32_t)key_y(k);
+}
+
 namespace {
 struct SortRec { uint64_t key; uint64_t sub; uint32_t row; };   // sub = static << 32 | entity id
 using SharedId = SharedIdPub;
@@ -246,17 +252,20 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     // carries the largest key of its level (x = z = y = 0xFFFF: never a world section, outline/atomic <= 32768)
     c->n_real_sections = (uint32_t)keys.size();
     bool has_movers = false; for (uint32_t r = 0; r < n && !has_movers; r++) has_movers = (flags[r] & F_HAS_VEL) != 0;
+    // compact 32-bit stream keys when every section index fits 9 bits; a wave then owns 1024 keys, so level runs are padded to that
+    c->key32 = (c->cfg.outline_length + c->cfg.atomic_length - 1) / c->cfg.atomic_length <= 512u && getenv("RE_EXP_KEY64") == nullptr;
+    const size_t wave_keys = c->key32 ? WAVE_KEYS32 : WAVE_KEYS;
     {
-        std::vector<uint64_t> padded; padded.reserve(keys.size() + MAX_LEVELS * WAVE_KEYS);
+        std::vector<uint64_t> padded; padded.reserve(keys.size() + MAX_LEVELS * WAVE_KEYS32);
         size_t i = 0;
         while (i < keys.size()) {
             uint32_t lv = key_level(keys[i]);
             const size_t run0 = padded.size();
             while (i < keys.size() && key_level(keys[i]) == lv) padded.push_back(keys[i++]);
             // worlds with movers get spare slots per level run (sections created by re-bucket patches live there): ~0.8 %, at least one chunk
-            size_t spare = has_movers ? std::max<size_t>(WAVE_KEYS, (padded.size() - run0) / 128) : 0;
+            size_t spare = has_movers ? std::max<size_t>(wave_keys, (padded.size() - run0) / 128) : 0;
             for (size_t k = 0; k < spare; k++) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
-            while (padded.size() % WAVE_KEYS) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
+            while (padded.size() % wave_keys) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
         }
         keys.swap(padded);
     }
@@ -342,6 +351,16 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->d_cell_key.p, keys_padded.data(), keys_padded.size() * 8, hipMemcpyHostToDevice, st));
+    {   // compact stream keys + the level of every 512-key chunk, when every section index fits 9 bits
+        const size_t nchunks = (keys.size() + wave_keys - 1) / wave_keys;
+        std::vector<uint32_t> k32(((keys.size() + 3) & ~(size_t)3) + 8, KEY32_PAD | 0x1FF7FDFFu), lvl(nchunks + 1, 0);
+        for (size_t i = 0; i < keys.size(); i++) k32[i] = to_key32(keys[i]);
+        for (size_t ch = 0; ch < nchunks; ch++) lvl[ch] = key_level(keys[ch * wave_keys]) & (MAX_LEVELS - 1);
+        HIPCHK(c, c->d_cell_key32.alloc(k32.size(), acct)); HIPCHK(c, c->d_chunk_level.alloc(lvl.size(), acct));
+        HIPCHK(c, hipMemcpyAsync(c->d_cell_key32.p, k32.data(), k32.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_chunk_level.p, lvl.data(), lvl.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     HIPCHK(c, hipMemcpyAsync(c->d_cell_begin.p, begin.data(), (size_t)(ncells + 1) * 4, hipMemcpyHostToDevice, st));
     if (ncells) {
         HIPCHK(c, hipMemcpyAsync(c->d_cell_nlocal.p, nlocal.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
@@ -396,7 +415,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
-    c->nlists = std::max(1u, (((ncells + 1u) >> 1) + 64u * CULL_ITERS - 1u) / (64u * CULL_ITERS));
+    c->nlists = std::max(1u, (uint32_t)((ncells + wave_keys - 1) / wave_keys));       // waves of k_scan_cull
     HIPCHK(c, hipStreamSynchronize(st));
     d_refold.release(nullptr); d_carried.release(nullptr);
     if (!carry) { c->dirty_pending = true; c->have_cull = false; }
@@ -576,7 +595,7 @@ static void fill_packed_boxes(PBox *out, const LevelBox *in, uint32_t maxlevel) 
 // the two candidate boxes is one contiguous run of the key-sorted section array.  At most 4 disjoint ascending spans (see ScanSpans).
 static ScanSpans candidate_spans(re_ctx *c, uint32_t nchunks) {
     ScanSpans SP{}; const FrameParams &P = c->P;
-    const uint32_t per = (uint32_t)(CULL_THREADS / 64) * WAVE_KEYS;
+    const uint32_t per = (uint32_t)(CULL_THREADS / 64) * (c->key32 ? WAVE_KEYS32 : WAVE_KEYS);
     std::vector<std::pair<uint32_t, uint32_t>> sp;                            // [first chunk, end chunk)
     const std::vector<uint64_t> &K = c->base_keys;                            // slot order of the last full build (sorted); sections patched in since sit in padding slots and are only a hint short
     for (uint32_t l = 0; l < P.max_level && l < (uint32_t)MAX_LEVELS; l++) {
@@ -605,6 +624,26 @@ static ScanSpans candidate_spans(re_ctx *c, uint32_t nchunks) {
     return SP;
 }
 
+// The stream filter for the compact 32-bit keys: ONE box per level, the bounding box of the logic and the render candidate box
+// (per-field lower / upper bounds; indices above 511 cannot exist in such a world).  It only has to be conservative: the waves
+// that find a candidate run the exact per-box tests on the full key (section_multiplicity_boxes), so a section of the union that
+// lies in neither box is dropped there and is not counted as a candidate.  Halves the VALU work of the stream.
+static void fill_union_boxes32(PBox32 *out, const LevelBox *a, const LevelBox *b, uint32_t maxlevel) {
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
+        PBox32 p{ 0x1FF7FDFFu, 0u };                                              // empty: lower bound above upper bound in every field
+        uint32_t lo[3] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu }, hi[3] = { 0, 0, 0 }; bool any = false;
+        for (const LevelBox *bx : { &a[l], &b[l] }) {
+            if (l >= maxlevel || !bx->nx || !bx->ny || !bx->nz) continue;
+            const uint32_t base[3] = { bx->bx, bx->bz, bx->by }, n[3] = { bx->nx, bx->nz, bx->ny };     // field order x | z | y
+            if (base[0] > 511u || base[1] > 511u || base[2] > 511u) continue;      // the box starts outside the world
+            for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], base[k]); hi[k] = std::max(hi[k], std::min(base[k] + n[k] - 1u, 511u)); }
+            any = true;
+        }
+        if (any) { p.lo = (lo[0] << 20) | (lo[1] << 10) | lo[2]; p.hi = (hi[0] << 20) | (hi[1] << 10) | hi[2]; }
+        out[l] = p;
+    }
+}
+
 static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     FrameParams &P = c->P;
     make_planes(cam->projection_view, P.planes);
@@ -622,6 +661,7 @@ static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     float cx = cam->direction[0] * half + cam->position[0], cy = cam->direction[1] * half + cam->position[1], cz = cam->direction[2] * half + cam->position[2];
     fill_level_boxes(P.box[1], c->maxlevel, wsl, rmax(cx - half, 0.0f), cx + half, rmax(cy - half, 0.0f), cy + half, rmax(cz - half, 0.0f), cz + half);
     fill_packed_boxes(c->PB.box[0], P.box[0], c->maxlevel); fill_packed_boxes(c->PB.box[1], P.box[1], c->maxlevel);
+    fill_union_boxes32(c->PB32.box, P.box[0], P.box[1], c->maxlevel);
 }
 
 static int finish_tick(re_ctx *c, re_tick_result *out);
@@ -720,17 +760,21 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
-    ScanCullArgs SA; SA.B = c->PB; SA.P = P; SA.P_dev = c->d_params.p;
+    ScanCullArgs SA; SA.B = c->PB; SA.B32 = c->PB32; SA.cell_key64 = c->d_cell_key.p; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p;
     SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
     static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
 #ifdef RE_EXP_STAMPS
-    if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 4, nullptr));
+    if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 8, nullptr));
     SA.timeline = c->d_timeline.p;
 #endif
     const ScanSpans SP = candidate_spans(c, scan_grid);
-    hipExtLaunchKernelGGL(k_scan_cull, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const uint64_t *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
-                          SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], SA);
+    if (c->key32)
+        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+                              SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
+    else
+        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+                              SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
@@ -944,14 +988,17 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
         std::vector<Pair32> *v32[6] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell };
         uint32_t *dst32[6] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p };
-        size_t bytes = p_key.size() * sizeof(Pair64) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + 64;
+        std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
+        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + 96;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
         if (c->d_stage.n < bytes) HIPCHK(c, c->d_stage.alloc(bytes * 2, nullptr));
         std::vector<uint8_t> host(bytes); size_t off = 0;
         auto put = [&](const void *src, size_t nb) { size_t o = off; if (nb) memcpy(host.data() + off, src, nb); off = (off + nb + 15) & ~(size_t)15; return o; };
         const size_t o_key = put(p_key.data(), p_key.size() * sizeof(Pair64)), o_fl = put(vf.data(), vf.size() * sizeof(FlagOp)), o_rf = put(refold.data(), refold.size() * 4);
         size_t o32[6]; for (int k = 0; k < 6; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
+        const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
+        if (!p_key32.empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)p_key32.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key32.size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o_k32), c->d_cell_key32.p);
         if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
         for (int k = 0; k < 6; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
         if (sh_total) HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
@@ -1554,7 +1601,7 @@ extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32
 extern "C" int re_debug_get_timeline(re_ctx *c, unsigned long long *out, uint32_t nwaves) {
     if (!c || !out || !c->d_timeline.p) return RE_E_ARG;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(out, c->d_timeline.p, (size_t)std::min(nwaves, c->nlists) * 32, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->d_timeline.p, (size_t)std::min(nwaves, c->nlists) * 64, hipMemcpyDeviceToHost));
     return RE_OK;
 }
 #endif

@@ -36,6 +36,13 @@ struct LevelBox { uint32_t bx, by, bz, nx, ny, nz; float level_length; uint32_t 
 // inside  <=>  pk_min_u16(pk_sub_u16(word, sub), min) == pk_sub_u16(word, sub) for both words
 struct PBox { uint32_t sub_hi, sub_lo, min_hi, min_lo; };
 struct PBoxTable { PBox box[2][16]; };
+// Compact keys (worlds of at most 512 sections per axis): 32-bit  x:9 | guard | z:9 | guard | y:9 | guard  (x in bits 20-28), bit 31 = padding slot;
+// the level is not in the key (level runs are chunk-aligned: one level word per 512-key chunk).  A box as per-field lower / upper bounds in
+// the same layout: inside <=> the guard bits survive both (v | G) - lo and (hi | G) - v.
+constexpr uint32_t KEY32_GUARDS = 0x20080200u, KEY32_PAD = 0x80000000u;
+struct PBox32 { uint32_t lo, hi; };
+struct PBox32Table { PBox32 box[16]; };  // one box per level: the bounding box of the logic and render candidate boxes (the exact tests follow on the full key)
+constexpr uint32_t WAVE_KEYS32 = 64u * 4u * 2u;  // compact 32-bit keys: the same 512 per wave (2 x 16 B per lane)
 constexpr uint32_t WAVE_KEYS = 64u * 4u * 2u;   // keys one wave of k_scan_cull owns (64 lanes x CULL_ITERS x 2); level runs are padded to it
 
 struct FrameParams {
@@ -93,7 +100,8 @@ struct PackArgs {                           // what k_pack_small needs besides t
     uint32_t *out_count;                    // optional device word: instances written to the output buffers (the all-gather slab header)
 };
 struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull after its two leading scalars (the kernel addresses it explicitly)
-    PBoxTable B;                            // read by every wave; everything below by candidate waves only
+    PBoxTable B; PBox32Table B32;           // read by every wave (one of the two); everything below by candidate waves only
+    const uint64_t *cell_key64;             // the full keys (candidate waves; the stream may run over the compact 32-bit keys)
     FrameParams P; FrameParams *P_dev;
     const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic; const uint8_t *cell_flags; uint32_t *cell_stamp;
     ItemSink K; FrameHeader *hdr; SharedArrays S; const SpecState *spec;
@@ -105,9 +113,11 @@ struct ScanCullArgs {                       // the kernel-argument segment of k_
 // the other chunks follow in key order.  The host puts the x-slabs of the candidate boxes there, so the few long-running
 // candidate waves start at once and finish under the stream instead of after it.
 struct ScanSpans { uint32_t n, start[4], count[4]; };
-constexpr uint32_t SCAN_CULL_ARGS_OFFSET = 48;   // cell_key (8 bytes) + ncells (4) + the 9 span scalars (36), already a multiple of the 8-byte alignment of ScanCullArgs
-__global__ void k_scan_cull(const uint64_t *cell_key, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
-                            uint32_t s3, uint32_t c3, ScanCullArgs A);   // nsp..c3 = ScanSpans as scalars: they arrive preloaded in SGPRs
+constexpr uint32_t SCAN_CULL_ARGS_OFFSET = 56;   // keys (8 bytes) + ncells (4) + the 9 span scalars (36) + chunk_level (8), already a multiple of the 8-byte alignment of ScanCullArgs
+template <bool K32> __global__ void k_scan_cull(const void *keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
+                                                uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A);   // the leading scalars arrive preloaded in SGPRs
+extern template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
+extern template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K);
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots, const SpecState *spec);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,

@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t shard_item_index(uint32_t t, const ShardMap 
     return idx;
 }
 
-constexpr uint32_t EMIT_MAX = WAVE_KEYS / 64u;                 // sections one lane can hold per call (one per 64-candidate round of a list)
+constexpr uint32_t EMIT_MAX = 4u;                              // sections one lane can hold per reservation (rounds of 64 visible sections per slice)
 
 __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t first, uint32_t stride, uint32_t n, uint32_t off, uint32_t lod, uint32_t seg_base, const ItemSink &K) {
     for (uint32_t k = first; k < n; k += stride) {
@@ -269,16 +269,22 @@ __device__ __forceinline__ uint32_t section_multiplicity(uint64_t key, const Fra
 __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
                                                     const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P);
 
+__device__ __forceinline__ void pack_small_body(const uint32_t block_rank, const uint32_t n_blocks, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_dyn);
+
 // The streaming part is lean on purpose: every wave issues its CULL_ITERS x 16-byte key loads immediately and runs the
 // packed tests (~12 VALU per key) against the two boxes of its level held in SGPRs.  Level runs are padded to whole
 // wave chunks on the host, so the level of the first key is the level of every real key of the wave; keys of any other
 // level fail the packed test by themselves.  Frame parameters live in the kernel-argument segment and are read with
 // scalar loads by candidate waves only.
-__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__restrict__ cell_key, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
-                                                            uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, ScanCullArgs A) {
-    __shared__ uint32_t s_cand[CULL_THREADS / 64][WAVE_KEYS];               // per-wave compaction of candidate section indices (no barrier: wave-private)
+template <bool K32>
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                                            uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A) {
+    constexpr uint32_t WK = WAVE_KEYS, NB = WK / 64u, NLD = K32 ? 2u : CULL_ITERS;   // keys per wave; ballots per wave (one per key a lane holds); 16-byte loads per lane
+    // per-wave candidate list (no barrier: wave-private): section index + its key (one word compact, two words full); the visible
+    // sections are compacted in place over its front
+    __shared__ uint32_t s_idx[CULL_THREADS / 64][WK], s_key[CULL_THREADS / 64][K32 ? WK : 2u * WK];
 #ifdef RE_EXP_STAMPS
-    const unsigned long long tl_start = wall_clock64(); unsigned long long tl_keys = tl_start; uint32_t tl_cand = 0;
+    const unsigned long long tl_start = wall_clock64(); unsigned long long tl_keys = tl_start, tl_pred = 0, tl_emit = 0; uint32_t tl_cand = 0;
 #endif
     // workgroup -> key chunk: the candidate spans first (see ScanSpans); all scalar
     uint32_t chunk = blockIdx.x;
@@ -295,36 +301,84 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__re
         }
     }
     const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = chunk * (CULL_THREADS / 64) + wid;
-    const uint32_t npairs = (ncells + 1u) >> 1;                              // key array is padded to an even count with never-candidate keys
-    const uint32_t wave_pair0 = wave * (64u * CULL_ITERS);
-    if (wave_pair0 < npairs) {                                              // wave-uniform
-        const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(cell_key);
-        ulonglong2 kk[CULL_ITERS];
+    // the stream: 512 keys per wave, as 4 x 16 B (full 64-bit keys) or 2 x 16 B (compact 32-bit keys) per lane; one ballot per key a lane holds
+    const uint32_t wave_key0 = wave * WK;
+    if (wave_key0 < ncells) {                                               // wave-uniform
+        uint64_t m[NB]; uint64_t any = 0; uint32_t lv0, qn = 0;
+        uint32_t *q_idx = s_idx[wid], *q_key = s_key[wid];
+        if constexpr (K32) {
+            const uint32_t nquads = (ncells + 3u) >> 2;                      // the compact array is padded to whole quads with padding keys
+            const uint4 *kp = reinterpret_cast<const uint4 *>(keys);
+            uint4 kk[NLD];
 #pragma unroll
-        for (uint32_t it = 0; it < CULL_ITERS; it++) {
-            uint32_t pair = wave_pair0 + it * 64u + lane;
-            kk[it] = kp[pair < npairs ? pair : npairs - 1u];
-        }
-        const uint32_t lv0 = __builtin_amdgcn_readfirstlane(key_level(kk[0].x)) & (MAX_LEVELS - 1);
-        const PBox a0 = A.B.box[0][lv0], b0 = A.B.box[1][lv0];               // uniform index: scalar loads into SGPRs
-        uint64_t m[CULL_ITERS * 2]; uint64_t any = 0;
+            for (uint32_t it = 0; it < NLD; it++) { uint32_t q = (wave_key0 >> 2) + it * 64u + lane; kk[it] = kp[q < nquads ? q : nquads - 1u]; }
+            lv0 = chunk_level[__builtin_amdgcn_readfirstlane(wave)] & (MAX_LEVELS - 1);      // scalar load, in flight together with the keys
+            const PBox32 a0 = A.B32.box[lv0];
+            const uint32_t hig = a0.hi | KEY32_GUARDS;
 #pragma unroll
-        for (uint32_t it = 0; it < CULL_ITERS; it++) {
-            const bool valid = (wave_pair0 + it * 64u + lane) < npairs;
+            for (uint32_t it = 0; it < NLD; it++) {
+                const bool valid = ((wave_key0 >> 2) + it * 64u + lane) < nquads;
+                const uint32_t v4[4] = { kk[it].x, kk[it].y, kk[it].z, kk[it].w };
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                uint64_t key = h ? kk[it].y : kk[it].x;
-                uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
-                bool c = valid && (pk_in_box(hi, lo, a0) || pk_in_box(hi, lo, b0));
-                m[it * 2 + h] = __ballot(c); any |= m[it * 2 + h];
+                for (int h = 0; h < 4; h++) {
+                    const uint32_t v = v4[h];
+                    const uint32_t in = ((v | KEY32_GUARDS) - a0.lo) & (hig - v) & KEY32_GUARDS;      // 5 VALU per key; padding keys carry bit 31
+                    const bool c = valid && in == KEY32_GUARDS && (int32_t)v >= 0;
+                    m[it * 4 + h] = __ballot(c); any |= m[it * 4 + h];
+                }
+            }
+            if (any) {                                                      // wave-uniform: stash the candidates (index, key) while the keys are in registers
+#pragma unroll
+                for (uint32_t it = 0; it < NLD; it++) {
+                    const uint32_t v4[4] = { kk[it].x, kk[it].y, kk[it].z, kk[it].w };
+#pragma unroll
+                    for (uint32_t h = 0; h < 4; h++) {
+                        const uint64_t mk = m[it * 4 + h];
+                        if ((mk >> lane) & 1ull) { const uint32_t pos = qn + mbcnt(mk); q_idx[pos] = wave_key0 + (it * 64u + lane) * 4u + h; q_key[pos] = v4[h]; }
+                        qn += (uint32_t)__popcll(mk);
+                    }
+                }
+            }
+        } else {
+            const uint32_t npairs = (ncells + 1u) >> 1;                      // key array is padded to an even count with never-candidate keys
+            const uint32_t wave_pair0 = wave * (64u * CULL_ITERS);
+            const ulonglong2 *kp = reinterpret_cast<const ulonglong2 *>(keys);
+            ulonglong2 kk[CULL_ITERS];
+#pragma unroll
+            for (uint32_t it = 0; it < CULL_ITERS; it++) {
+                uint32_t pair = wave_pair0 + it * 64u + lane;
+                kk[it] = kp[pair < npairs ? pair : npairs - 1u];
+            }
+            lv0 = __builtin_amdgcn_readfirstlane(key_level(kk[0].x)) & (MAX_LEVELS - 1);
+            const PBox a0 = A.B.box[0][lv0], b0 = A.B.box[1][lv0];           // uniform index: scalar loads into SGPRs
+#pragma unroll
+            for (uint32_t it = 0; it < CULL_ITERS; it++) {
+                const bool valid = (wave_pair0 + it * 64u + lane) < npairs;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint64_t key = h ? kk[it].y : kk[it].x;
+                    uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+                    bool c = valid && (pk_in_box(hi, lo, a0) || pk_in_box(hi, lo, b0));
+                    m[it * 2 + h] = __ballot(c); any |= m[it * 2 + h];
+                }
+            }
+            if (any) {
+#pragma unroll
+                for (uint32_t it = 0; it < CULL_ITERS; it++)
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++) {
+                        const uint64_t mk = m[it * 2 + h], key = h ? kk[it].y : kk[it].x;
+                        if ((mk >> lane) & 1ull) { const uint32_t pos = qn + mbcnt(mk); q_idx[pos] = wave_key0 + (it * 64u + lane) * 2u + h; q_key[2u * pos] = (uint32_t)key; q_key[2u * pos + 1u] = (uint32_t)(key >> 32); }
+                        qn += (uint32_t)__popcll(mk);
+                    }
             }
         }
 #ifdef RE_EXP_STAMPS
         tl_keys = wall_clock64(); tl_cand = any ? 1u : 0u;
 #endif
-        if (any) {                                                          // wave-uniform (scalar) branch: ~5% of the waves
+        if (any) {                                                          // wave-uniform (scalar) branch: ~1% of the waves
             // Candidate waves read the rest of the kernel-argument segment through a pointer the compiler cannot see through, so that
-            // none of those scalar loads is hoisted in front of the key loads of the other 95%.
+            // none of those scalar loads is hoisted in front of the key loads of the other 99%.
             typedef __attribute__((address_space(4))) const char *kernarg_ptr;
             kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ka));
@@ -334,52 +388,69 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__re
             const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic;
             const uint8_t *__restrict__ cell_flags = R.cell_flags; uint32_t *__restrict__ cell_stamp = R.cell_stamp;
             if (lv0 < P.max_level && !R.spec->stale) {                       // (a stale tree cancels the frame: see SpecState)
-            uint32_t *q = s_cand[wid];
-            uint32_t qn = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < CULL_ITERS * 2; k++) {
-                if ((m[k] >> lane) & 1ull) q[qn + mbcnt(m[k])] = (wave_pair0 + (k >> 1) * 64u + lane) * 2u + (k & 1u);
-                qn += (uint32_t)__popcll(m[k]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const LevelBox la = P.box[0][lv0], lb = P.box[1][lv0];          // scalar loads from the kernel-argument segment
-            uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0;
-            uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
-#pragma unroll
-            for (uint32_t j = 0; j < EMIT_MAX; j++) {                       // dense lanes, <= EMIT_MAX rounds of 64 candidates
-                const uint32_t i = j * 64u + lane;
-                rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-                if (j * 64u < qn) {                                         // wave-uniform
-                    const bool on = i < qn;
-                    const uint32_t c = q[on ? i : 0u];
-                    // everything indexed by the section is requested together (one memory round trip), before visibility is known
-                    const uint64_t key = cell_key[c];
-                    const uint8_t f = cell_flags[c];
-                    const Aabb t = cell_tight[c];
-                    const uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c], cb = cell_begin[c];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const LevelBox la = P.box[0][lv0], lb = P.box[1][lv0];      // scalar loads from the kernel-argument segment
+                uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0, nv = 0;
+                // stage A -- pure arithmetic on the keys (no memory round trip): the exact box tests and the two cullers on the section's grid
+                // box; the visible sections (index | multiplicity << 30) are compacted in place over the front of the list
+#pragma unroll 1
+                for (uint32_t base = 0; base < qn; base += 64u) {
+                    const uint32_t i = base + lane; const bool on = i < qn;
+                    const uint32_t idx = q_idx[on ? i : 0u];
+                    uint64_t key;
+                    if constexpr (K32) { const uint32_t v = q_key[on ? i : 0u]; key = pack_key(lv0, (v >> 20) & 0x1FFu, (v >> 10) & 0x1FFu, v & 0x1FFu); }
+                    else { const uint32_t j2 = 2u * (on ? i : 0u); key = (uint64_t)q_key[j2] | ((uint64_t)q_key[j2 + 1u] << 32); }
+                    const bool pad = !K32 && (key & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull;     // compact padding keys never get here (sign bit)
                     bool is_cand = false;
-                    uint32_t mult = (!on || (f & CF_PAD)) ? 0u : section_multiplicity_boxes(key, la, lb, P, &is_cand);
-                    cand_acc += (on && is_cand) ? 1u : 0u;
-                    if (mult) {
-                        cell_stamp[c] = (P.frame << 2) | mult;
-                        vis_map_acc += 1; vis_vec_acc += mult;
-                        float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
-                        bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
-                        bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
-                        rbv[j] = cb + (act ? 0u : nl);
-                        cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
-                        uint32_t mm = P.emit_duplicates ? mult : 1u;
-                        lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
-                    }
+                    const uint32_t mult = (!on || pad) ? 0u : section_multiplicity_boxes(key, la, lb, P, &is_cand);
+                    cand_acc += (on && !pad && is_cand) ? 1u : 0u;
+                    const uint64_t vb = __ballot(mult != 0u);
+                    if (mult) q_idx[nv + mbcnt(vb)] = idx | (mult << 30);   // positions < base + 64: only entries every lane has already read
+                    nv += (uint32_t)__popcll(vb);
                 }
-            }
-            emit_sections_multi(rbv, cntv, lodv, hdr, K, wave);             // one reservation per wave
-            for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
-            if (lane == 0) {                                                // sharded frame counters: fire-and-forget atomics, <= 3 per candidate wave
-                uint32_t *cnt = hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u;
-                if (cand_acc) atomicAdd(cnt + 0, cand_acc);
-                if (vis_map_acc) { atomicAdd(cnt + 1, vis_map_acc); atomicAdd(cnt + 2, vis_vec_acc); }
-            }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef RE_EXP_STAMPS
+                tl_pred = wall_clock64();
+#endif
+                // stage B -- the visible sections only (usually one round of 64): everything indexed by the section in one memory round trip,
+                // then distance, LOD, active / cached-static row ranges, and the instance expansion
+#pragma unroll 1
+                for (uint32_t vbase = 0; vbase < nv; vbase += EMIT_MAX * 64u) {
+                    uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
+#pragma unroll
+                    for (uint32_t j = 0; j < EMIT_MAX; j++) {
+                        const uint32_t i = vbase + j * 64u + lane;
+                        rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
+                        if (vbase + j * 64u < nv) {                         // wave-uniform
+                            const bool on = i < nv;
+                            const uint32_t e = q_idx[on ? i : 0u], c = e & 0x3FFFFFFFu, mult = e >> 30;
+                            const uint8_t f = cell_flags[c];
+                            const Aabb t = cell_tight[c];
+                            const uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c], cb = cell_begin[c];
+                            if (on && !(f & CF_PAD)) {
+                                cell_stamp[c] = (P.frame << 2) | mult;
+                                vis_map_acc += 1; vis_vec_acc += mult;
+                                float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
+                                bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
+                                bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
+                                rbv[j] = cb + (act ? 0u : nl);
+                                cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
+                                uint32_t mm = P.emit_duplicates ? mult : 1u;
+                                lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
+                            }
+                        }
+                    }
+                    emit_sections_multi(rbv, cntv, lodv, hdr, K, wave);     // one reservation per slice of 512 visible sections
+                }
+#ifdef RE_EXP_STAMPS
+                tl_emit = wall_clock64();
+#endif
+                for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
+                if (lane == 0) {                                            // sharded frame counters: fire-and-forget atomics, <= 3 per candidate wave
+                    uint32_t *cnt = hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u;
+                    if (cand_acc) atomicAdd(cnt + 0, cand_acc);
+                    if (vis_map_acc) { atomicAdd(cnt + 1, vis_map_acc); atomicAdd(cnt + 2, vis_vec_acc); }
+                }
             }
         }
     }
@@ -395,17 +466,20 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const uint64_t *__re
         if (blockIdx.x * CULL_THREADS < nsh && !R.spec->stale) {
             const SharedArrays S = R.S; const ItemSink K = R.K;
             for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < nsh; s0 += gridDim.x * CULL_THREADS)
-                cull_shared_section(s0 + threadIdx.x, S, cell_key, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
+                cull_shared_section(s0 + threadIdx.x, S, R.cell_key64, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
         }
         if (blockIdx.x == gridDim.x - 1u && !R.spec->stale) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
             for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
         }
 #ifdef RE_EXP_STAMPS
-        if (R.timeline && lane == 0) { unsigned long long *t = R.timeline + (size_t)wave * 4u; t[0] = tl_start; t[1] = tl_keys; t[2] = wall_clock64(); t[3] = tl_cand; }
+        if (R.timeline && lane == 0) { unsigned long long *t = R.timeline + (size_t)wave * 8u; t[0] = tl_start; t[1] = tl_keys; t[2] = wall_clock64(); t[3] = tl_cand; t[4] = tl_pred; t[5] = tl_emit; }
 #endif
     }
 }
+
+template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
+template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 
 // Shared world sections (render_flow.rs:808-866): emitted once per frame when some linking unique
 // section is visible and active; static members through the unique section that cached them.
@@ -576,13 +650,14 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); c += __shfl_xor(c, d, 64); }
     FrameCounts r; r.n_candidates = a; r.n_vis_map = b; r.n_vis_vec = c; return r;
 }
-__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K) {
-    extern __shared__ uint32_t s_dyn[];                       // [nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill
+// block_rank / n_blocks: this workgroup's place among the workgroups that pack (a launch of its own, or the last workgroups of k_scan_cull);
+// s_dyn: 2 * nslots words of LDS ([nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill)
+__device__ __forceinline__ void pack_small_body(const uint32_t block_rank, const uint32_t n_blocks, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_dyn) {
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
     __shared__ uint32_t s_pos[64], s_row[64];
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (blockIdx.x == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; }
+        if (block_rank == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; }
         return;
     }
     const uint32_t nslots = A.nslots;
@@ -597,9 +672,9 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     const ShardMap sm = load_shard_map(hdr, K.nshards, K.seg_cap);
     const uint32_t T = sm.total;
     const bool overflow = seg_over || T > PACK_SMALL_ITEMS || nslots > LDS_HIST_SLOTS;
-    const uint32_t per = ((T + gridDim.x - 1u) / gridDim.x + 63u) & ~63u;             // contiguous chunk of this workgroup
-    const uint32_t lo = blockIdx.x * per, hi = lo + per < T ? lo + per : T;
-    if (blockIdx.x != 0 && (overflow || lo >= T)) return;
+    const uint32_t per = ((T + n_blocks - 1u) / n_blocks + 63u) & ~63u;             // contiguous chunk of this workgroup
+    const uint32_t lo = block_rank * per, hi = lo + per < T ? lo + per : T;
+    if (block_rank != 0 && (overflow || lo >= T)) return;
     // The first pass (64 instances) of this workgroup's own chunk is requested up front, so its page-scattered gathers travel while the
     // histograms are built.  Chunks are small on purpose: a CU resolves the address translations of scattered rows one after another,
     // so the gathers want many CUs, while the redundant slot counting is contiguous and cheap.
@@ -643,14 +718,14 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
             uint32_t gidx = s_gcarry + wcn + incn - nz;
             if (i < nslots) {
                 s_tot[i] = begin;
-                if (v && blockIdx.x == 0) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
+                if (v && block_rank == 0) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
             }
             __syncthreads();
             if (tid == NT - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
             __syncthreads();
         }
     }
-    if (blockIdx.x == 0) {
+    if (block_rank == 0) {
         if (wid == 0) {
             FrameCounts fc = load_frame_counts(hdr);
             if (lane == 0) {
@@ -662,10 +737,10 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
             }
         }
         // next frame's cursors / counters (this frame's header stays readable); on overflow the large path does it
-        if (!overflow) {
-            for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
-            for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(th)[i] = 0u;       // the tick of this frame starts from zero counters
-        }
+        // also when this pack declines (overflow): frames enqueued behind this one must find clean headers; the redo of this frame
+        // through the large path reads this frame's own header, which stays intact
+        for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
+        for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(th)[i] = 0u;       // the tick of this frame starts from zero counters
     }
     if (overflow) return;
     // ---- this workgroup's chunk: rank inside the group, then move the matrices (4 lanes per instance, one float4 each) ----
@@ -683,6 +758,11 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
         uint32_t pp = s_pos[li];
         if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = first ? pre : reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
     }
+}
+
+__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K) {
+    extern __shared__ uint32_t s_dyn_pack[];
+    pack_small_body(blockIdx.x, gridDim.x, hdr, hdr_next, th, A, K, s_dyn_pack);
 }
 
 // ---------------------------------------------------------------------------------------------

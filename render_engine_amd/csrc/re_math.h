@@ -182,33 +182,33 @@ RE_HD float distance_to_aabb(const Aabb &a, float cx, float cy, float cz) {
 }
 
 // RenderFrustumCuller::aabb_visible (culling/render_frustum_culler.rs:83-118).  planes: 6 x (nx,ny,nz,w).
-// Per plane OR over the 8 corners of !(dist < 0); AND over planes.  The distance is evaluated
-// left to right: ((nx*px + ny*py) + nz*pz) + w.
+// The reference ORs !(dist < 0) over the 8 corners of the box per plane and ANDs over the planes, with
+// dist = ((nx*px + ny*py) + nz*pz) + w evaluated left to right.  Evaluated here ONCE per plane, with the larger of the two
+// products per axis: IEEE multiplication and addition are monotone in each operand, so this distance is >= the rounded distance
+// of every corner, and it IS one of the reference's eight evaluations (the corner that realises the three maxima) -- the OR over
+// the corners equals the test of this one value, bit for bit, whatever the order of min and max in the box (the 2-corner
+// apply_transformation can swap them).  A NaN plane coefficient makes both products of its axis NaN, so the distance is NaN and
+// counts as inside exactly as in the reference.  (Not reproduced: an infinite coefficient against a zero coordinate, where one
+// product is NaN and the other infinite.)  6x fewer operations on the candidate path.
 RE_HD bool frustum_aabb_visible(const float *planes, const Aabb &a) {
     for (int k = 0; k < 6; k++) {
-        float nx = planes[k * 4 + 0], ny = planes[k * 4 + 1], nz = planes[k * 4 + 2], w = planes[k * 4 + 3];
-        float x0 = nx * a.xmin, x1 = nx * a.xmax, y0 = ny * a.ymin, y1 = ny * a.ymax, z0 = nz * a.zmin, z1 = nz * a.zmax;
-        bool any = false;
-        any |= !((((x0 + y0) + z0) + w) < 0.0f);
-        any |= !((((x0 + y0) + z1) + w) < 0.0f);
-        any |= !((((x0 + y1) + z0) + w) < 0.0f);
-        any |= !((((x0 + y1) + z1) + w) < 0.0f);
-        any |= !((((x1 + y0) + z0) + w) < 0.0f);
-        any |= !((((x1 + y0) + z1) + w) < 0.0f);
-        any |= !((((x1 + y1) + z0) + w) < 0.0f);
-        any |= !((((x1 + y1) + z1) + w) < 0.0f);
-        if (!any) return false;
+        const float nx = planes[k * 4 + 0], ny = planes[k * 4 + 1], nz = planes[k * 4 + 2], w = planes[k * 4 + 3];
+        const float xm = fmaxf(nx * a.xmin, nx * a.xmax), ym = fmaxf(ny * a.ymin, ny * a.ymax), zm = fmaxf(nz * a.zmin, nz * a.zmax);
+        const float d = ((xm + ym) + zm) + w;
+        if (d < 0.0f) return false;
     }
     return true;
 }
 
-// LogicFrustumCuller::aabb_in_view (culling/logic_frustum_culler.rs:32-46)
+// LogicFrustumCuller::aabb_in_view (culling/logic_frustum_culler.rs:32-46): min over the 8 corners of |corner - camera| <= lookahead,
+// each distance as norm3 = sqrt((dx*dx + dy*dy) + dz*dz).  The nearest corner is nearest per axis, and squares, sums and sqrt are
+// monotone under rounding, so the minimum over the corners is the one evaluation with the smaller square per axis (f32::min
+// ignores NaN: a NaN camera leaves f32::MAX and the test fails, as here).
 RE_HD bool logic_aabb_in_view(float lookahead, float cx, float cy, float cz, const Aabb &a) {
-    float best = 3.40282347e+38f;
-    const float xs[2] = { a.xmin, a.xmax }, ys[2] = { a.ymin, a.ymax }, zs[2] = { a.zmin, a.zmax };
-    for (int ix = 0; ix < 2; ix++) for (int iy = 0; iy < 2; iy++) for (int iz = 0; iz < 2; iz++)
-        best = rmin(best, norm3(xs[ix] - cx, ys[iy] - cy, zs[iz] - cz));
-    return best <= lookahead;
+    const float x0 = a.xmin - cx, x1 = a.xmax - cx, y0 = a.ymin - cy, y1 = a.ymax - cy, z0 = a.zmin - cz, z1 = a.zmax - cz;
+    const float sx = rmin(x0 * x0, x1 * x1), sy = rmin(y0 * y0, y1 * y1), sz = rmin(z0 * z0, z1 * z1);
+    const float best = sqrtf((sx + sy) + sz);
+    return best <= lookahead;                              // NaN compares false, like f32::MAX <= lookahead
 }
 
 // ModelId::level_of_view_adjusted_model_index: LOD index only (models/model_definitions.rs:31-59)

@@ -319,3 +319,21 @@ def test_async_frames_with_movers_are_replayed(R):
     check_sections(p, w)
     check_entities(R, p, w, ents[:600])
     p.close(); w.close()
+
+
+def test_world_with_more_than_512_sections_per_axis(R):
+    """outline / atomic = 1024: section indices need more than 9 bits, so the stream runs over the full 64-bit keys with the two
+    packed 16-bit box tests instead of the compact 32-bit keys; several frames with ticks and movers"""
+    ents = R.synthetic.mixed_world(3000, seed=33, spread=500.0, atomic=16)
+    ents["vel"] *= 4.0
+    p, w = build_pair(R, ents, atomic=16)
+    check_sections(p, w)
+    for i in range(4):
+        cam = R.Camera((8192 + 15 * i, 8192, 8400 - 20 * i), (0.1 * i, 0, -1), 700.0)
+        check_frame(R, p, w, cam, i % 2 == 1)
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.05)
+        t = p.tick(0.05)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+    check_sections(p, w)
+    check_entities(R, p, w, ents[:300])
+    p.close(); w.close()
