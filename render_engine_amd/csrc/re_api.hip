@@ -778,9 +778,12 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
-        // one workgroup per 64 predicted instances (+25%): every workgroup counts all instances, the matrix gathers want many CUs
-        uint32_t pgrid = std::min(256u, (c->pred_total + c->pred_total / 4u) / 64u + 2u);
-        hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c));
+        // workgroup b packs 64 instances of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length (+50 %),
+        // and never fewer than cover 16 K instances spread evenly would need is not required -- a shard longer than the grid covers
+        // makes the pack decline (overflow) and the frame is redone through the large path
+        uint32_t per_shard = (c->pred_total + c->pred_total / 2u) / CURSOR_SHARDS + 64u;
+        uint32_t pgrid = CURSOR_SHARDS * std::min(32u, (per_shard + 63u) / 64u);
+        hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c), c->n);
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;

@@ -269,8 +269,6 @@ __device__ __forceinline__ uint32_t section_multiplicity(uint64_t key, const Fra
 __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
                                                     const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P);
 
-__device__ __forceinline__ void pack_small_body(const uint32_t block_rank, const uint32_t n_blocks, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_dyn);
-
 // The streaming part is lean on purpose: every wave issues its CULL_ITERS x 16-byte key loads immediately and runs the
 // packed tests (~12 VALU per key) against the two boxes of its level held in SGPRs.  Level runs are padded to whole
 // wave chunks on the host, so the level of the first key is the level of every real key of the wave; keys of any other
@@ -650,57 +648,64 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
     for (int d = 32; d >= 1; d >>= 1) { a += __shfl_xor(a, d, 64); b += __shfl_xor(b, d, 64); c += __shfl_xor(c, d, 64); }
     FrameCounts r; r.n_candidates = a; r.n_vis_map = b; r.n_vis_vec = c; return r;
 }
-// block_rank / n_blocks: this workgroup's place among the workgroups that pack (a launch of its own, or the last workgroups of k_scan_cull);
-// s_dyn: 2 * nslots words of LDS ([nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill)
-__device__ __forceinline__ void pack_small_body(const uint32_t block_rank, const uint32_t n_blocks, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t *s_dyn) {
+// Workgroup b owns the 64 instances [ (b >> 3) * 64, +64 ) of cursor shard b & 7.  Order of the instances inside a group: by shard,
+// then by position in the shard (any order is as good as the reference's hash order).  Nothing a workgroup loads first depends on
+// another load: the cursors, the first 256 slots of every shard (the whole list in the common case) and the workgroup's own 64
+// (row, slot) pairs are requested together -- entries beyond a shard's count are stale but harmless, they are masked once the
+// cursors are known -- and the 64-byte matrices follow one round trip later, in flight while the histograms are built:
+// two dependent memory round trips from launch to store.
+__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows) {
+    extern __shared__ uint32_t s_dyn[];                       // [nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
     __shared__ uint32_t s_pos[64], s_row[64];
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (block_rank == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; }
+        if (blockIdx.x == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; }
         return;
     }
     const uint32_t nslots = A.nslots;
     uint32_t *s_tot = s_dyn, *s_fill = s_dyn + nslots;
-    // raw cursors: a segment that ran over its capacity dropped instances -> the host re-runs the frame through the large path
-    uint32_t raw_items = 0, raw_sec = 0; bool seg_over = false;
+    const uint32_t my_shard = blockIdx.x & (CURSOR_SHARDS - 1u), my_j0 = (blockIdx.x >> 3) * 64u;
+    const uint32_t part = tid & 3u, li = tid >> 2;
+    // ---- round trip 1: everything that needs no other load
+    unsigned long long cur[CURSOR_SHARDS];
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) cur[k] = hdr->cursors[k * 8];
+    uint32_t sl[CURSOR_SHARDS];
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) sl[k] = tid < K.seg_cap ? K.item_slot[k * K.seg_cap + tid] : 0xFFFFFFFFu;
+    uint32_t my_slot = 0xFFFFFFFFu, my_row = 0;
+    if (tid < 64u && my_j0 + tid < K.seg_cap) { const uint32_t ii = my_shard * K.seg_cap + my_j0 + tid; my_slot = K.item_slot[ii]; my_row = K.item_row[ii]; }
+    if (my_row >= nrows) my_row = 0;                          // a stale entry of an earlier world
+    for (uint32_t i = tid; i < 2u * nslots && nslots <= LDS_HIST_SLOTS; i += NT) s_dyn[i] = 0;
+    if (tid == 0) { s_carry = 0; s_gcarry = 0; }
+    if (tid < 64u) s_row[tid] = my_row;
+    __syncthreads();
+    // ---- round trip 2 (requested now, consumed after the histograms): id + matrix of the own instances
+    const uint32_t my_id = tid < 64u ? A.row_id[my_row] : 0u;
+    const float4 pre = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
+    // the cursors are here: counts per shard, capacity checks
+    uint32_t n[CURSOR_SHARDS], raw_items = 0, raw_sec = 0, T = 0; bool seg_over = false;
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
-        unsigned long long cur = k < K.nshards ? hdr->cursors[k * 8] : 0ull;
-        raw_sec += (uint32_t)cur; raw_items += (uint32_t)(cur >> 32); seg_over |= (uint32_t)(cur >> 32) > K.seg_cap;
+        const uint32_t v = (uint32_t)(cur[k] >> 32);
+        raw_sec += (uint32_t)cur[k]; raw_items += v; seg_over |= v > K.seg_cap;
+        n[k] = v < K.seg_cap ? v : K.seg_cap; T += n[k];
     }
-    const ShardMap sm = load_shard_map(hdr, K.nshards, K.seg_cap);
-    const uint32_t T = sm.total;
     const bool overflow = seg_over || T > PACK_SMALL_ITEMS || nslots > LDS_HIST_SLOTS;
-    const uint32_t per = ((T + n_blocks - 1u) / n_blocks + 63u) & ~63u;             // contiguous chunk of this workgroup
-    const uint32_t lo = block_rank * per, hi = lo + per < T ? lo + per : T;
-    if (block_rank != 0 && (overflow || lo >= T)) return;
-    // The first pass (64 instances) of this workgroup's own chunk is requested up front, so its page-scattered gathers travel while the
-    // histograms are built.  Chunks are small on purpose: a CU resolves the address translations of scattered rows one after another,
-    // so the gathers want many CUs, while the redundant slot counting is contiguous and cheap.
-    const uint32_t part = tid & 3u, li = tid >> 2;
-    uint32_t my_slot = 0xFFFFFFFFu, my_row = 0, my_id = 0; float4 pre = {0.f, 0.f, 0.f, 0.f};
+    uint32_t my_n = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) if (k == my_shard) my_n = n[k];
+    const bool have = my_j0 < my_n;                           // this workgroup owns instances
+    if (blockIdx.x != 0 && (overflow || !have)) return;
     if (!overflow) {
-        // all independent requests first: this lane's own item, and the first 8 x 256 slots of the histogram pass
-        if (tid < 64u && lo + tid < hi) { uint32_t ii = shard_item_index(lo + tid, sm, K.seg_cap); my_slot = K.item_slot[ii]; my_row = K.item_row[ii]; }
-        uint32_t sl[8];
+        // histograms: all instances -> s_tot; the instances ordered before this workgroup's chunk -> s_fill
 #pragma unroll
-        for (uint32_t u = 0; u < 8; u++) { uint32_t t = u * NT + tid; sl[u] = t < T ? K.item_slot[shard_item_index(t, sm, K.seg_cap)] : 0xFFFFFFFFu; }
-        for (uint32_t i = tid; i < 2u * nslots; i += NT) s_dyn[i] = 0;
-        if (tid == 0) { s_carry = 0; s_gcarry = 0; }
-        if (tid < 64u) s_row[tid] = my_row;
-        __syncthreads();
-        if (tid < 64u && lo + tid < hi) my_id = A.row_id[my_row];
-        if (lo + li < hi) pre = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
-        for (uint32_t t0 = 0; t0 < T; t0 += NT * 8u) {                     // 8 independent slot loads in flight per lane
-            if (t0) {
-#pragma unroll
-                for (uint32_t u = 0; u < 8; u++) { uint32_t t = t0 + u * NT + tid; sl[u] = t < T ? K.item_slot[shard_item_index(t, sm, K.seg_cap)] : 0xFFFFFFFFu; }
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 8; u++) {
-                uint32_t t = t0 + u * NT + tid;
-                if (sl[u] != 0xFFFFFFFFu) { atomicAdd(&s_tot[sl[u]], 1u); if (t < lo) atomicAdd(&s_fill[sl[u]], 1u); }
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+            if (tid < n[k] && sl[k] != 0xFFFFFFFFu) { atomicAdd(&s_tot[sl[k]], 1u); if (k < my_shard || (k == my_shard && tid < my_j0)) atomicAdd(&s_fill[sl[k]], 1u); }
+            for (uint32_t j = NT + tid; j < n[k]; j += NT) {  // shards longer than the speculative batch
+                const uint32_t s2 = K.item_slot[k * K.seg_cap + j];
+                if (s2 != 0xFFFFFFFFu) { atomicAdd(&s_tot[s2], 1u); if (k < my_shard || (k == my_shard && j < my_j0)) atomicAdd(&s_fill[s2], 1u); }
             }
         }
         __syncthreads();
@@ -718,14 +723,14 @@ __device__ __forceinline__ void pack_small_body(const uint32_t block_rank, const
             uint32_t gidx = s_gcarry + wcn + incn - nz;
             if (i < nslots) {
                 s_tot[i] = begin;
-                if (v && block_rank == 0) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
+                if (v && blockIdx.x == 0) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
             }
             __syncthreads();
             if (tid == NT - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
             __syncthreads();
         }
     }
-    if (block_rank == 0) {
+    if (blockIdx.x == 0) {
         if (wid == 0) {
             FrameCounts fc = load_frame_counts(hdr);
             if (lane == 0) {
@@ -736,33 +741,50 @@ __device__ __forceinline__ void pack_small_body(const uint32_t block_rank, const
                 if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
             }
         }
-        // next frame's cursors / counters (this frame's header stays readable); on overflow the large path does it
-        // also when this pack declines (overflow): frames enqueued behind this one must find clean headers; the redo of this frame
-        // through the large path reads this frame's own header, which stays intact
+        // next frame's cursors / counters (this frame's header stays readable), also when this pack declines (overflow): frames enqueued
+        // behind this one must find clean headers; the redo of this frame through the large path reads this frame's own header
         for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;
         for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(th)[i] = 0u;       // the tick of this frame starts from zero counters
     }
-    if (overflow) return;
-    // ---- this workgroup's chunk: rank inside the group, then move the matrices (4 lanes per instance, one float4 each) ----
-    for (uint32_t t0 = lo; t0 < hi; t0 += 64u) {                           // uniform trip count
-        const bool first = t0 == lo;
-        __syncthreads();                                                   // previous pass done with s_pos / s_row
-        if (tid < 64u) {
-            uint32_t t = t0 + tid, pos = 0xFFFFFFFFu, row = my_row, slot = my_slot;
-            if (!first) { slot = 0xFFFFFFFFu; if (t < hi) { uint32_t ii = shard_item_index(t, sm, K.seg_cap); slot = K.item_slot[ii]; row = K.item_row[ii]; } }
-            if (slot != 0xFFFFFFFFu) pos = s_tot[slot] + atomicAdd(&s_fill[slot], 1u);
-            s_pos[tid] = pos; s_row[tid] = row;
-            if (pos < A.out_cap) A.out_ids[pos] = first ? my_id : A.row_id[row];
+    if (overflow || !have) return;
+    // ---- the own 64 instances: rank inside the group, then id + matrix (4 lanes per instance, one float4 each)
+    if (tid < 64u) {
+        uint32_t pos = 0xFFFFFFFFu;
+        if (my_j0 + tid < my_n && my_slot != 0xFFFFFFFFu) pos = s_tot[my_slot] + atomicAdd(&s_fill[my_slot], 1u);
+        s_pos[tid] = pos;
+        if (pos < A.out_cap) A.out_ids[pos] = my_id;
+    }
+    __syncthreads();
+    {
+        const uint32_t pp = s_pos[li];
+        if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = pre;
+    }
+    // ---- a shard longer than the launch anticipated (the grid is sized from the previous frame): further chunks of this workgroup,
+    // without the speculative loads; the "before this chunk" histogram is rebuilt per chunk
+    const uint32_t stride = (gridDim.x >> 3) * 64u;
+    for (uint32_t j0 = my_j0 + stride; j0 < my_n; j0 += stride) {           // workgroup-uniform
+        __syncthreads();
+        for (uint32_t i = tid; i < nslots; i += NT) s_fill[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+            const uint32_t lim = k < my_shard ? n[k] : (k == my_shard ? j0 : 0u);
+            for (uint32_t j = tid; j < lim; j += NT) { const uint32_t s2 = K.item_slot[k * K.seg_cap + j]; if (s2 != 0xFFFFFFFFu) atomicAdd(&s_fill[s2], 1u); }
         }
         __syncthreads();
-        uint32_t pp = s_pos[li];
-        if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = first ? pre : reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
+        if (tid < 64u) {
+            uint32_t pos = 0xFFFFFFFFu, row = 0;
+            if (j0 + tid < my_n) {
+                const uint32_t ii = my_shard * K.seg_cap + j0 + tid, slot = K.item_slot[ii]; row = K.item_row[ii];
+                if (slot != 0xFFFFFFFFu) pos = s_tot[slot] + atomicAdd(&s_fill[slot], 1u);
+            }
+            s_pos[tid] = pos; s_row[tid] = row;
+            if (pos < A.out_cap) A.out_ids[pos] = A.row_id[row];
+        }
+        __syncthreads();
+        const uint32_t pp = s_pos[li];
+        if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
     }
-}
-
-__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K) {
-    extern __shared__ uint32_t s_dyn_pack[];
-    pack_small_body(blockIdx.x, gridDim.x, hdr, hdr_next, th, A, K, s_dyn_pack);
 }
 
 // ---------------------------------------------------------------------------------------------
