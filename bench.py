@@ -153,11 +153,14 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
         # roofline of the dominant kernel (k_scan_cull): algorithmic bytes per launch, see DESIGN.md "Roofline accounting":
-        # 8 B key per section + 37 B per candidate section (flags, tight AABB, counts, begin) + 4 B stamp per visible section
-        # + 16 B per visible instance (row index and group class read, instance-list entry written)
-        C_sections = stats["n_sections"]
+        # the stream key of every section slot (4 B compact when the world has <= 512 sections per axis, else 8 B) + one level word per
+        # 512-key chunk + 41 B per visible section (flags, tight AABB, counts, begin read; stamp written) + 16 B per visible instance
+        # (row index and group class read, instance-list entry written).  Candidate sections that turn out invisible cost no bytes:
+        # their test runs on the key alone.
+        C_sections = stats["n_section_slots"] if "n_section_slots" in stats else stats["n_sections"]
         n_entries = vis["n_visible_sections"]
-        alg_bytes = 8 * C_sections + 37 * n_cand + 4 * n_entries + 16 * vis["total"]
+        key_bytes = 4 if (16384 + atomic - 1) // atomic <= 512 and not os.environ.get("RE_EXP_KEY64") else 8
+        alg_bytes = key_bytes * C_sections + 4 * ((C_sections + 511) // 512) + 41 * n_entries + 16 * vis["total"]
         k1_mean = float(np.mean(k1_us)) if len(k1_us) else float("nan")
         achieved = alg_bytes / (k1_mean * 1e-6) / 1e9 if k1_mean > 0 else None
         traffic = None
@@ -182,7 +185,7 @@ def main():
                        "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), double-buffered, stream-ordered" % SLAB_INSTANCES},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_scan_cull", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "k_scan_cull", "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
                          "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY},
             "frame_latency_ms_sync": float(np.median(lat) * 1e3),
             "kernel_us_last_frame": tm, "setup_s": t_setup,
