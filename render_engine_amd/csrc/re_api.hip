@@ -70,7 +70,7 @@ struct re_ctx {
     DevBuf<uint32_t> d_id, d_gclass, d_flags, d_row_cell;
     DevBuf<float> d_mat, d_pos, d_rot, d_scale;
     DevBuf<Aabb> d_aabb, d_orig;
-    DevBuf<uint32_t> d_dyn_row; DevBuf<float> d_dyn_vel, d_dyn_acc, d_dyn_rotvel, d_dyn_rotacc;
+    DevBuf<uint32_t> d_dyn_row, d_dyn_cell; DevBuf<float> d_dyn_vel, d_dyn_acc, d_dyn_rotvel, d_dyn_rotacc;
     DevBuf<uint64_t> d_row_key; DevBuf<uint8_t> d_row_nk; DevBuf<SharedRec> d_shrec; DevBuf<uint32_t> d_counter;
     std::vector<uint32_t> h_id, h_flags, h_dyn_row;      // host mirrors of the immutable id column / upload flags / dynamic-row list
     uint32_t n_rebuilds = 0;
@@ -165,7 +165,7 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) {
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
     c->d_id.release(a); c->d_gclass.release(a); c->d_flags.release(a); c->d_row_cell.release(a); c->d_mat.release(a); c->d_pos.release(a); c->d_rot.release(a);
-    c->d_scale.release(a); c->d_aabb.release(a); c->d_orig.release(a); c->d_dyn_row.release(a); c->d_dyn_vel.release(a); c->d_dyn_acc.release(a);
+    c->d_scale.release(a); c->d_aabb.release(a); c->d_orig.release(a); c->d_dyn_row.release(a); c->d_dyn_cell.release(a); c->d_dyn_vel.release(a); c->d_dyn_acc.release(a);
     c->d_dyn_rotvel.release(a); c->d_dyn_rotacc.release(a); c->d_row_key.release(a); c->d_row_nk.release(a); c->d_shrec.release(a); c->d_counter.release(a);
     c->d_cell_key.release(a); c->d_cell_tight.release(a); c->d_cell_begin.release(a); c->d_cell_nlocal.release(a); c->d_cell_nstatic.release(a);
     c->d_cell_stamp.release(a); c->d_rows.release(a); c->d_cell_flags.release(a); c->d_sh_cells.release(a); c->d_sh_owner.release(a); c->d_sh_aabb.release(a);
@@ -195,6 +195,16 @@ extern "C" void re_destroy(re_ctx *c) {
 static RowArrays row_arrays(re_ctx *c) {
     RowArrays R; R.id = c->d_id.p; R.gclass = c->d_gclass.p; R.flags = c->d_flags.p; R.mat = c->d_mat.p; R.aabb = c->d_aabb.p; R.orig = c->d_orig.p;
     R.pos = c->d_pos.p; R.rot = c->d_rot.p; R.scale = c->d_scale.p; return R;
+}
+
+// the dynamic table's copy of row_cell (the tick reads it coalesced instead of gathering row_cell[row])
+static int upload_dyn_cells(re_ctx *c) {
+    if (!c->ndyn) return RE_OK;
+    std::vector<uint32_t> dc(c->ndyn);
+    for (uint32_t j = 0; j < c->ndyn; j++) dc[j] = c->h_row_cell[c->h_dyn_row[j]];
+    if (c->d_dyn_cell.n < c->ndyn) HIPCHK(c, c->d_dyn_cell.alloc(c->ndyn, &c->dev_bytes));
+    HIPCHK(c, hipMemcpy(c->d_dyn_cell.p, dc.data(), (size_t)c->ndyn * 4, hipMemcpyHostToDevice));
+    return RE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,11 +547,14 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     for (const SharedRec &sr : shrec) { std::array<uint64_t, 8> a; memcpy(a.data(), sr.keys, sizeof sr.keys); c->h_row_shared_keys[sr.row] = a; }
     int rc = build_sections(c, row_key, row_nk, shrec, flags);
     if (rc != RE_OK) return rc;
+    rc = upload_dyn_cells(c);
+    if (rc != RE_OK) return rc;
     // frame buffers
     c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
     c->item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
     c->list_cap = std::max(c->ndyn, 1u);
     HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
+    HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 4)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 4));   // the pack reads speculatively past the cursors
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
     HIPCHK(c, c->d_hdr.alloc(2, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_res), sizeof(HostResult), hipHostMallocMapped));
@@ -989,8 +1002,10 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     uint64_t *acct = &c->dev_bytes;
     {
         std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
-        std::vector<Pair32> *v32[6] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell };
-        uint32_t *dst32[6] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p };
+        std::vector<Pair32> p_dyncell;                                       // the dynamic table's copy of row_cell
+        for (const Pair32 &pr : p_rowcell) { auto it = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), pr.idx); if (it != c->h_dyn_row.end() && *it == pr.idx) p_dyncell.push_back(Pair32{ (uint32_t)(it - c->h_dyn_row.begin()), pr.val }); }
+        std::vector<Pair32> *v32[7] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell };
+        uint32_t *dst32[7] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_dyn_cell.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
         size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + 96;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
@@ -998,12 +1013,12 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         std::vector<uint8_t> host(bytes); size_t off = 0;
         auto put = [&](const void *src, size_t nb) { size_t o = off; if (nb) memcpy(host.data() + off, src, nb); off = (off + nb + 15) & ~(size_t)15; return o; };
         const size_t o_key = put(p_key.data(), p_key.size() * sizeof(Pair64)), o_fl = put(vf.data(), vf.size() * sizeof(FlagOp)), o_rf = put(refold.data(), refold.size() * 4);
-        size_t o32[6]; for (int k = 0; k < 6; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
+        size_t o32[7]; for (int k = 0; k < 7; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
         const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
         if (!p_key32.empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)p_key32.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key32.size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o_k32), c->d_cell_key32.p);
         if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
-        for (int k = 0; k < 6; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
+        for (int k = 0; k < 7; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
         if (sh_total) HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
         if (!vf.empty()) hipLaunchKernelGGL(k_flag_ops, dim3(((uint32_t)vf.size() + 255) / 256), dim3(256), 0, st, (uint32_t)vf.size(), reinterpret_cast<const FlagOp *>(c->d_stage.p + o_fl), c->d_cell_flags.p);
         // end_of_changes: tight AABBs of the changed sections (stream order: after the table patches above)
@@ -1207,6 +1222,8 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     std::vector<uint32_t> flags(c->h_flags);
     int rc = build_sections(c, c->h_row_key, c->h_row_nk, shrec, flags, &carry);
     if (rc != RE_OK) return rc;
+    rc = upload_dyn_cells(c);
+    if (rc != RE_OK) return rc;
     c->n_rebuilds++;
     return RE_OK;
 }
@@ -1239,8 +1256,8 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     if (c->ndyn) {
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
         hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
-                           row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
-                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_hth, c->d_spec.p, c->d_hspec);
+                           row_arrays(c), c->d_dyn_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec);
         c->th_clean = false;
     }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
@@ -1270,6 +1287,7 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
 // after it has cancelled itself; patch the tree from that tick's lists, then replay the cancelled calls (which may go stale again).
 static int resolve(re_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tick_inflight && c->ndyn && c->h_th) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 16, hipMemcpyDeviceToHost));   // n_changed, n_rebucket, n_oob of the last tick that ran
     while (c->h_spec && c->h_spec->stale) {
         const uint32_t sf = c->h_spec->stale_frame;
         c->h_spec->stale = 0; HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
@@ -1293,6 +1311,7 @@ static int resolve(re_ctx *c) {
             c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->ndyn) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 16, hipMemcpyDeviceToHost));
     }
     c->pending.clear();
     return RE_OK;

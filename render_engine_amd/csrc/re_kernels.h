@@ -126,9 +126,9 @@ __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint3
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap, const SpecState *spec);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
-                       const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
+                       const uint32_t *dyn_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
-                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th, SpecState *spec, SpecState *h_spec);
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec);
 struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)

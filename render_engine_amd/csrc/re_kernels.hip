@@ -798,47 +798,25 @@ __device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
 }
 
 __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
-                                            float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc, RowArrays R, const uint32_t *__restrict__ row_cell,
+                                            float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc, RowArrays R, const uint32_t *__restrict__ dyn_cell,
                                             const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                             const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb, const FrameParams &P, float dt, uint32_t tick_all,
-                                            uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap);
+                                            uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
+                                            SpecState *spec, SpecState *h_spec);
 
 __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                               float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
-                                              RowArrays R, const uint32_t *__restrict__ row_cell,
+                                              RowArrays R, const uint32_t *__restrict__ dyn_cell,
                                               const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                               const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, TickHeader *h_th,
+                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
                                               SpecState *spec, SpecState *h_spec) {
     if (spec->stale) return;                                   // an earlier tick left the tree stale: this frame is replayed by the host
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap);
-    // the last workgroup to finish publishes the counters into mapped pinned host memory (the counters are device-scope atomics,
-    // already at L2: no fence is needed before the ticket).  Two-level ticket: a single word saturates near 88 atomics/us, which
-    // would cost several microseconds for a few hundred workgroups.
-    __shared__ uint32_t s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t k = blockIdx.x % TICK_TICKET_SHARDS;
-        const uint32_t in_shard = (gridDim.x - 1u - k) / TICK_TICKET_SHARDS + 1u;
-        const uint32_t nshards = gridDim.x < TICK_TICKET_SHARDS ? gridDim.x : TICK_TICKET_SHARDS;
-        uint32_t last = 0;
-        if (atomicAdd(&th->shard[k * 16u], 1u) == in_shard - 1u) last = (atomicAdd(&th->ticket, 1u) == nshards - 1u) ? 1u : 0u;
-        s_last = last;
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        TickHeader r = {};
-        r.n_changed = __hip_atomic_load(&th->n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.n_rebucket = __hip_atomic_load(&th->n_rebucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.n_oob = __hip_atomic_load(&th->n_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.ticket = gridDim.x;
-        h_th->n_changed = r.n_changed; h_th->n_rebucket = r.n_rebucket; h_th->n_oob = r.n_oob; h_th->ticket = r.ticket;
-        if (r.n_rebucket || r.n_oob) {                          // the host must patch the tree (or retire rows) before any later frame may run
-            SpecState sp; sp.stale = 1u; sp.stale_frame = Pp->frame;
-            *spec = sp; *h_spec = sp;
-        }
-    }
+    // No completion ticket: the counters stay in device memory (the host copies the 16 bytes when it synchronises), and a workgroup
+    // that finds a mover or an entity leaving the world raises `stale` itself -- idempotent stores, any number of workgroups may do it.
+    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, dyn_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec);
 }
 
 // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + update_entity_in_tree (:325-351) for one entity whose
@@ -846,7 +824,8 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
 // spatial-hash section differs (entity_exists_in_section, bounding_box_tree_v2.rs:765-782) -- an entry in the re-bucket list.
 __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, uint32_t nfl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
                                                      RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells,
-                                                     uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+                                                     uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
+                                                     SpecState *spec = nullptr, SpecState *h_spec = nullptr, uint32_t frame = 0) {
     // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262)
     Aabb orig = R.orig[r], a;
     float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
@@ -869,6 +848,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     if (oob && !(fl & F_OOB_LOGIC)) {
         uint32_t slot = atomicAdd(&th->n_oob, 1u);
         if (slot < list_cap) oob_rows[slot] = r;
+        if (spec) { SpecState sp; sp.stale = 1u; sp.stale_frame = frame; *spec = sp; *h_spec = sp; }     // the host must retire the row before any later frame runs
         R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
         return;
     }
@@ -888,20 +868,22 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     if (!same) {
         uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
         if (slot < list_cap) mover_rows[slot] = r | (translation_only ? 0x80000000u : 0u);   // bit 31: translation-only mover
+        if (spec) { SpecState sp; sp.stale = 1u; sp.stale_frame = frame; *spec = sp; *h_spec = sp; }     // the host must patch the tree before any later frame runs
     }
 }
 
 __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                             float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
-                                            RowArrays R, const uint32_t *__restrict__ row_cell,
+                                            RowArrays R, const uint32_t *__restrict__ dyn_cell,
                                             const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                             const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                             const FrameParams &P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                            TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+                                            TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec) {
     if (j >= ndyn) return;
-    uint32_t r = dyn_row[j];
+    const uint32_t r = dyn_row[j], rc = dyn_cell[j];           // both coalesced; the flag word and the section stamp are then fetched together
+    const bool unique_cell = rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED);
+    const uint32_t stamp = unique_cell ? cell_stamp[rc] : 0u;    // requested together with the flag word: one round trip decides most entities
     uint32_t fl = R.flags[r];
-    uint32_t rc = row_cell[r];
     // reset_has_changed_component (logic_flow.rs:776-801)
     uint32_t nfl = fl & ~(F_HAS_MOVED | F_HAS_ROTATED);
     bool run = false;
@@ -909,7 +891,7 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
     else if (tick_all) run = rc != ROW_CELL_NONE;
     else if (rc == ROW_CELL_NONE) run = false;
     else if (!(rc & ROW_CELL_SHARED)) {
-        bool vis = (cell_stamp[rc] >> 2) == P.frame;
+        bool vis = (stamp >> 2) == P.frame;
         // visible loop: local (non-static) entities of active visible sections; always-execute entities
         // only when their section is NOT in visible_sections_map (find_always_execute_entities :803-836)
         run = (!(fl & F_STATIC) && vis) || ((fl & F_ALWAYS_EXEC) && !vis);
@@ -974,7 +956,7 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
     if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
     if (rot_set) { R.rot[r * 4 + 0] = rot[0]; R.rot[r * 4 + 1] = rot[1]; R.rot[r * 4 + 2] = rot[2]; R.rot[r * 4 + 3] = rot[3]; }
 
-    place_changed_entity(r, fl, nfl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap);
+    place_changed_entity(r, fl, nfl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec, P.frame);
 }
 
 // section decision (add_entity with add_if_out_bounds = true: the box is clamped) for a list of rows, from their current StaticAABB;
