@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <array>
 #include <set>
@@ -93,7 +94,7 @@ struct re_ctx {
     std::vector<uint64_t> h_row_key; std::vector<uint8_t> h_row_nk; std::vector<uint32_t> h_row_cell, h_gclass;
     std::unordered_map<uint32_t, std::array<uint64_t, 8>> h_row_shared_keys;
     std::vector<SharedIdPub> h_shids; std::vector<uint32_t> h_sh_nact, h_sh_nstat;
-    bool dirty_pending = false;
+    bool dirty_pending = false, timings_pending = false;
     // host mirrors of the section table for incremental patches (see patch_sections)
     std::vector<uint32_t> h_cell_nl, h_cell_ns, h_cell_begin, h_cell_cap, h_rows;   // per slot; h_rows mirrors the row pool
     std::vector<uint64_t> base_keys;                    // slot keys of the last full build (sorted: the lookup base and the span hint)
@@ -717,7 +718,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next)
     // and a handful of hot (model, LOD) groups saturate near 88 atomics/us per address
     hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, c->d_item_slot.p, nshards, seg_cap, c->d_group_count.p, c->nslots, c->d_spec.p);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
-                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p, c->ext_out_count, c->ext_out_ids ? c->ext_out_cap : c->out_cap);
+                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p, c->ext_out_count, c->ext_out_ids ? c->ext_out_cap : c->out_cap, c->frame);
     hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
                        c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->d_spec.p);
     HIPCHK(c, hipGetLastError());
@@ -725,7 +726,19 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next)
 }
 
 static int finish_cull(re_ctx *c, re_visible *out) {
-    { int rc = resolve(c); if (rc != RE_OK) return rc; }
+    // Fast completion: the pack publishes "frame done" into mapped host memory after the group table and the counters; polling that
+    // word costs a PCIe write's latency instead of the driver's stream-synchronise wake-up.  The packed instances are device
+    // resident, and whatever reads them next is ordered behind the pack on the stream.  Not when a tick that may leave the tree
+    // stale is in flight: that needs resolve().
+    bool done = false;
+    if (!(c->tick_inflight && c->ndyn)) {
+        const volatile uint32_t *flag = &c->h_res->done_frame;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !(done = (*flag == c->frame)); spins++)
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;   // long frame: let the driver wait
+        if (done) { std::atomic_thread_fence(std::memory_order_acquire); if (c->h_res->overflow == 2u || (c->h_spec && c->h_spec->stale)) done = false; else c->pending.clear(); }
+    }
+    if (!done) { int rc = resolve(c); if (rc != RE_OK) return rc; }
     c->cull_inflight = false;
     if (c->h_res->overflow == 1) {
         // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
@@ -733,10 +746,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         if (rc != RE_OK) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    if (c->timed_frame) {
-        (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
-        c->t_cull *= 1000.f; c->t_pack *= 1000.f;
-    }
+    c->timings_pending = c->timed_frame;                                      // the events are read in re_get_timings (they may still be in flight here)
     c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
     {   // every instance the cull reserved must have been counted into a group (dead rows excepted): otherwise a cursor segment overflowed
         uint32_t counted = 0; for (uint32_t g = 0; g < c->h_res->n_groups && g < c->nslots; g++) counted += c->h_ranges[g].count;
@@ -769,7 +779,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
     PackArgs A{}; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
-    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count;
+    A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count; A.frame = c->frame;
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
@@ -1239,6 +1249,11 @@ static int absorb_out_of_bounds(re_ctx *c, uint32_t n_oob) {
 }
 
 static int finish_tick(re_ctx *c, re_tick_result *out) {
+    if (!c->ndyn) {                                                           // nothing ticks: whatever re_tick enqueued (clearing the changed-static set) is ordered on the stream
+        c->tick_inflight = false; c->last_tick = re_tick_result{ 0, 0, 0 };
+        if (out) *out = c->last_tick;
+        return RE_OK;
+    }
     int rc = resolve(c);
     if (rc != RE_OK) return rc;
     c->tick_inflight = false;
@@ -1593,6 +1608,11 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
 
 extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *tick_us) {
     if (!c) return RE_E_ARG;
+    if (c->timings_pending) {
+        HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
+        c->t_cull *= 1000.f; c->t_pack *= 1000.f; c->timings_pending = false;
+    }
     if (cull_us) *cull_us = c->t_cull; if (pack_us) *pack_us = c->t_pack; if (tick_us) *tick_us = c->t_tick;
     return RE_OK;
 }

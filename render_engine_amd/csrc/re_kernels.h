@@ -71,6 +71,8 @@ struct SpecState { uint32_t stale, stale_frame; };
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
+    uint32_t done_frame, pad;               // written last (after a system-scope fence): the frame whose results above are complete -- a synchronous
+                                            // call polls this word instead of paying the driver's stream-synchronise latency
     unsigned long long stamps[8];           // development builds (-DRE_EXP_STAMPS): 100 MHz wall-clock stamps of the pack phases
 };
 constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances k_pack_small takes (every workgroup counts all of them); more go through the count/scan/scatter path
@@ -97,6 +99,7 @@ struct PackArgs {                           // what k_pack_small needs besides t
     uint32_t nslots, out_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
     const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; const SpecState *spec;
+    uint32_t frame;                         // this frame's number (HostResult::done_frame)
     uint32_t *out_count;                    // optional device word: instances written to the output buffers (the all-gather slab header)
 };
 struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull after its two leading scalars (the kernel addresses it explicitly)
@@ -122,7 +125,7 @@ __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots, const SpecState *spec);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
-                             uint32_t *out_count, uint32_t out_cap);
+                             uint32_t *out_count, uint32_t out_cap, uint32_t frame);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap, const SpecState *spec);
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,

@@ -540,9 +540,9 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
                                                      uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
                                                      InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
-                                                     uint32_t *out_count, uint32_t out_cap) {
+                                                     uint32_t *out_count, uint32_t out_cap, uint32_t frame) {
     __shared__ uint32_t s_wsum[16], s_wcnt[16];
-    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; } return; }
+    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; __threadfence_system(); hres->done_frame = frame; } return; }
     __shared__ uint32_t s_carry, s_gcarry;
     if (threadIdx.x == 0) { s_carry = 0; s_gcarry = 0; }
     __syncthreads();
@@ -579,6 +579,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         *hres = r;                                              // mapped pinned host memory
         if (out_count) *out_count = s_carry < out_cap ? s_carry : out_cap;
+        __threadfence_system(); hres->done_frame = frame;
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
     for (uint32_t i = threadIdx.x; i < sizeof(TickHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(th)[i] = 0u;
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     __shared__ uint32_t s_pos[64], s_row[64];
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (blockIdx.x == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; }
+        if (blockIdx.x == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; __threadfence_system(); A.hres->done_frame = A.frame; }
         return;
     }
     const uint32_t nslots = A.nslots;
@@ -739,6 +740,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
                 r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
                 *A.hres = r;                                        // mapped pinned host memory
                 if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
+                __threadfence_system(); A.hres->done_frame = A.frame;   // the group table and the counters above are complete
             }
         }
         // next frame's cursors / counters (this frame's header stays readable), also when this pack declines (overflow): frames enqueued
