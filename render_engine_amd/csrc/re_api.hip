@@ -109,6 +109,7 @@ struct re_ctx {
     DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
     // frame
     uint32_t frame = 0; bool have_cull = false;
+    DevBuf<uint32_t> d_rows_gc; std::vector<uint32_t> h_sh_begin;   // group class per row-pool entry; pool offsets of the shared sections' members
     DevBuf<uint32_t> d_cell_key32, d_chunk_level; bool key32 = false; PBox32Table PB32{};   // compact keys for the stream (worlds of <= 512 sections per axis)
     FrameParams P{}; PBoxTable PB{}; DevBuf<FrameParams> d_params;
 #ifdef RE_EXP_STAMPS
@@ -196,6 +197,28 @@ extern "C" void re_destroy(re_ctx *c) {
 static RowArrays row_arrays(re_ctx *c) {
     RowArrays R; R.id = c->d_id.p; R.gclass = c->d_gclass.p; R.flags = c->d_flags.p; R.mat = c->d_mat.p; R.aabb = c->d_aabb.p; R.orig = c->d_orig.p;
     R.pos = c->d_pos.p; R.rot = c->d_rot.p; R.scale = c->d_scale.p; return R;
+}
+
+// group class a row-pool entry carries for row r: hidden while the row is not to be drawn (removed, or made static after the cache froze)
+static inline uint32_t effective_gclass(const re_ctx *c, uint32_t r) {
+    return ((c->h_flags[r] & F_DEAD) || c->h_uncached.count(r)) ? 0xFFFFFFFFu : c->h_gclass[r];
+}
+// pool positions of row r (one: its section's segment or its shared section's) get the row's current effective group class
+static void collect_row_gc(const re_ctx *c, uint32_t r, std::vector<Pair32> &out) {
+    const uint32_t rc = c->h_row_cell[r];
+    if (rc == ROW_CELL_NONE) return;
+    uint32_t b, n;
+    if (rc & ROW_CELL_SHARED) { const uint32_t s2 = rc & ~ROW_CELL_SHARED; if (s2 >= c->h_sh_begin.size()) return; b = c->h_sh_begin[s2]; n = c->h_sh_nact[s2] + c->h_sh_nstat[s2]; }
+    else { b = c->h_cell_begin[rc]; n = c->h_cell_nl[rc] + c->h_cell_ns[rc]; }
+    for (uint32_t i = 0; i < n; i++) if (c->h_rows[b + i] == r) out.push_back(Pair32{ b + i, effective_gclass(c, r) });
+}
+static int upload_row_gc(re_ctx *c, const std::vector<Pair32> &pairs) {
+    if (pairs.empty()) return RE_OK;
+    Pair32 *d = nullptr; HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), pairs.size() * sizeof(Pair32)));
+    HIPCHK(c, hipMemcpyAsync(d, pairs.data(), pairs.size() * sizeof(Pair32), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)pairs.size() + 255) / 256), dim3(256), 0, c->stream, (uint32_t)pairs.size(), d, c->d_rows_gc.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(d);
+    return RE_OK;
 }
 
 // the dynamic table's copy of row_cell (the tick reads it coalesced instead of gathering row_cell[row])
@@ -349,7 +372,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     c->h_cell_key = keys; c->h_row_cell = row_cell; c->h_shids = shids; c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat;
     c->base_keys = keys; c->extra_slots.clear(); c->base_index.clear(); for (size_t i = 0; i < keys.size(); i += 1024) c->base_index.push_back(keys[i]); c->h_cell_nl = nlocal; c->h_cell_ns = nstatic; c->h_cell_begin.assign(begin.begin(), begin.begin() + ncells);
     c->h_cell_cap.resize(ncells); for (uint32_t ci = 0; ci < ncells; ci++) c->h_cell_cap[ci] = nlocal[ci] + nstatic[ci];
-    c->h_rows = rows; c->free_slots.assign(MAX_LEVELS, {});
+    c->h_rows = rows; c->free_slots.assign(MAX_LEVELS, {}); c->h_sh_begin.assign(sh_begin.begin(), sh_begin.begin() + nsh);
     for (uint32_t ci = ncells; ci-- > 0;) if (is_pad(keys[ci])) c->free_slots[key_level(keys[ci]) & (MAX_LEVELS - 1)].push_back(ci);   // popped from the back: lowest slot first
     std::vector<uint64_t> keys_padded(keys); keys_padded.resize((size_t)((ncells + 1) & ~1u) + 2, 0xFFFFFFFFFFFFFFFFull);
     HIPCHK(c, c->d_cell_key.alloc(keys_padded.size(), acct));
@@ -380,6 +403,12 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, hipMemsetAsync(c->d_cell_stamp.p, 0, (size_t)ncells * 4, st));
     }
     if (!rows.empty()) HIPCHK(c, hipMemcpyAsync(c->d_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, st));
+    {
+        std::vector<uint32_t> gc(rows.size());
+        for (size_t i = 0; i < rows.size(); i++) gc[i] = effective_gclass(c, rows[i]);
+        HIPCHK(c, c->d_rows_gc.alloc(c->pool_cap, acct));
+        if (!gc.empty()) HIPCHK(c, hipMemcpy(c->d_rows_gc.p, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
+    }
     if (n) HIPCHK(c, hipMemcpyAsync(c->d_row_cell.p, row_cell.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
     if (nsh) {
         HIPCHK(c, hipMemcpyAsync(c->d_sh_cells.p, sh_cells.data(), (size_t)nsh * 8 * 4, hipMemcpyHostToDevice, st));
@@ -698,7 +727,7 @@ static void fill_visible(re_ctx *c, re_visible *out) {
 }
 
 static ItemSink item_sink(re_ctx *c) {
-    ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.row_gclass = c->d_gclass.p;
+    ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
     K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; return K;
 }
 static SharedArrays shared_arrays(re_ctx *c) {
@@ -1014,22 +1043,27 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
         std::vector<Pair32> p_dyncell;                                       // the dynamic table's copy of row_cell
         for (const Pair32 &pr : p_rowcell) { auto it = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), pr.idx); if (it != c->h_dyn_row.end() && *it == pr.idx) p_dyncell.push_back(Pair32{ (uint32_t)(it - c->h_dyn_row.begin()), pr.val }); }
-        std::vector<Pair32> *v32[7] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell };
-        uint32_t *dst32[7] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_dyn_cell.p };
+        std::vector<Pair32> p_rowsgc; p_rowsgc.reserve(p_rows.size());         // the group class travels with every pool entry written
+        for (const Pair32 &pr : p_rows) p_rowsgc.push_back(Pair32{ pr.idx, effective_gclass(c, pr.val) });
+        std::vector<Pair32> *v32[8] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell, &p_rowsgc };
+        uint32_t *dst32[8] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_dyn_cell.p, c->d_rows_gc.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
-        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + 96;
+        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 128;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
         if (c->d_stage.n < bytes) HIPCHK(c, c->d_stage.alloc(bytes * 2, nullptr));
         std::vector<uint8_t> host(bytes); size_t off = 0;
         auto put = [&](const void *src, size_t nb) { size_t o = off; if (nb) memcpy(host.data() + off, src, nb); off = (off + nb + 15) & ~(size_t)15; return o; };
         const size_t o_key = put(p_key.data(), p_key.size() * sizeof(Pair64)), o_fl = put(vf.data(), vf.size() * sizeof(FlagOp)), o_rf = put(refold.data(), refold.size() * 4);
-        size_t o32[7]; for (int k = 0; k < 7; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
+        size_t o32[8]; for (int k = 0; k < 8; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
         const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
         if (!p_key32.empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)p_key32.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key32.size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o_k32), c->d_cell_key32.p);
         if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
-        for (int k = 0; k < 7; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
-        if (sh_total) HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
+        for (int k = 0; k < 8; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
+        std::vector<uint32_t> sh_gc(sh_total);
+        for (uint32_t i = 0; i < sh_total; i++) sh_gc[i] = effective_gclass(c, c->h_rows[sh_region + i]);
+        if (sh_total) { HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
+                        HIPCHK(c, hipMemcpyAsync(c->d_rows_gc.p + sh_region, sh_gc.data(), (size_t)sh_total * 4, hipMemcpyHostToDevice, st)); }
         if (!vf.empty()) hipLaunchKernelGGL(k_flag_ops, dim3(((uint32_t)vf.size() + 255) / 256), dim3(256), 0, st, (uint32_t)vf.size(), reinterpret_cast<const FlagOp *>(c->d_stage.p + o_fl), c->d_cell_flags.p);
         // end_of_changes: tight AABBs of the changed sections (stream order: after the table patches above)
         if (!refold.empty()) hipLaunchKernelGGL(k_fold_tight_list, dim3(((uint32_t)refold.size() + 255) / 256), dim3(256), 0, st, (uint32_t)refold.size(), reinterpret_cast<const uint32_t *>(c->d_stage.p + o_rf), c->d_cell_key.p,
@@ -1068,7 +1102,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     for (auto &f : freed) c->free_slots[f.first].push_back(f.second);
-    c->nsh = nsh; c->h_shids = shids; sh_nact.resize(nsh); sh_nstat.resize(nsh); c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat;
+    c->nsh = nsh; c->h_shids = shids; sh_nact.resize(nsh); sh_nstat.resize(nsh); c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat; sh_begin.resize(nsh); c->h_sh_begin = sh_begin;
     c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + n_real_delta);
     c->nrows_csr = c->pool_used;
     if (!carry.changed_static.empty()) c->dirty_pending = true;
@@ -1197,13 +1231,17 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     std::vector<uint32_t> reveal;
     for (auto it = c->h_uncached.begin(); it != c->h_uncached.end();) { if (!(c->h_flags[*it] & F_STATIC)) { reveal.push_back(*it); it = c->h_uncached.erase(it); } else ++it; }
     for (uint32_t r : reveal) if (!(c->h_flags[r] & F_DEAD)) HIPCHK(c, hipMemcpyAsync(c->d_gclass.p + r, &c->h_gclass[r], 4, hipMemcpyHostToDevice, st));
+    // (their pool entries are rewritten by the patch / rebuild below with the row's now visible group class: they moved)
     carry.too_many = total > 500;
     // ---- write the result into the resident table; rebuild everything only when its slack is exhausted
     lap("replay");
     {
         int prc = (c->cfg.flags & RE_CFG_FULL_REBUILD) ? 1 : patch_sections(c, carry, arrive, removed_rows);
         lap("patch");
-        if (prc == 0) return RE_OK;
+        if (prc == 0) {
+            std::vector<Pair32> gc; for (uint32_t r : reveal) collect_row_gc(c, r, gc);      // revealed rows that kept their pool position
+            return upload_row_gc(c, gc);
+        }
         if (prc < 0) return prc;
     }
     // full rebuild: key-sorted arrays from the patched per-row decisions, carrying over what the reference leaves untouched.
@@ -1244,8 +1282,9 @@ static int absorb_out_of_bounds(re_ctx *c, uint32_t n_oob) {
     if (!cnt) return RE_OK;
     std::vector<uint32_t> rows(cnt);
     HIPCHK(c, hipMemcpy(rows.data(), c->d_oob.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
-    for (uint32_t r : rows) if (r < c->n) { c->h_flags[r] |= F_DEAD; c->h_oob_ids.push_back(c->h_id[r]); }
-    return RE_OK;
+    std::vector<Pair32> gc;
+    for (uint32_t r : rows) if (r < c->n) { c->h_flags[r] |= F_DEAD; c->h_oob_ids.push_back(c->h_id[r]); collect_row_gc(c, r, gc); }   // the tree keeps the stale entry: stop drawing it
+    return upload_row_gc(c, gc);
 }
 
 static int finish_tick(re_ctx *c, re_tick_result *out) {
@@ -1464,6 +1503,13 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     c->last_tick = re_tick_result{ th.n_changed, th.n_rebucket, th.n_oob };
     if (th.n_rebucket || !pre.empty()) {
         int rc = rebucket(c, th.n_rebucket, &pre);
+        if (rc != RE_OK) return rc;
+    }
+    {   // rows hidden / shown by this batch that kept their place in the row pool
+        std::vector<Pair32> gc;
+        for (uint32_t r : hide) collect_row_gc(c, r, gc);
+        for (uint32_t r : unhide) if (!deleted.count(r)) collect_row_gc(c, r, gc);
+        int rc = upload_row_gc(c, gc);
         if (rc != RE_OK) return rc;
     }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique after the logic flow (pipeline.rs:271)

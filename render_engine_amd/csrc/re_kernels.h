@@ -93,7 +93,7 @@ __global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, con
 struct ItemSink {
     uint32_t *item_row, *item_slot; uint32_t item_cap;
     uint32_t nshards, seg_cap;              // instance list = nshards segments of seg_cap slots, one cursor each
-    const uint32_t *rows, *row_gclass;
+    const uint32_t *rows, *rows_gc;         // the row pool and, entry for entry, the row's group class (0xFFFFFFFF: not drawn -- removed or hidden)
 };
 struct PackArgs {                           // what k_pack_small needs besides the item list
     uint32_t nslots, out_cap;

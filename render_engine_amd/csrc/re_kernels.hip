@@ -163,12 +163,15 @@ __device__ __forceinline__ uint32_t shard_item_index(uint32_t t, const ShardMap 
 
 constexpr uint32_t EMIT_MAX = 4u;                              // sections one lane can hold per reservation (rounds of 64 visible sections per slice)
 
-__device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t first, uint32_t stride, uint32_t n, uint32_t off, uint32_t lod, uint32_t seg_base, const ItemSink &K) {
+// row0 / gc0: entry rb of the pool, fetched by the caller ahead of the cursor atomic (k == 0 when first == 0)
+__device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t first, uint32_t stride, uint32_t n, uint32_t off, uint32_t lod, uint32_t seg_base, const ItemSink &K,
+                                            bool have0 = false, uint32_t row0 = 0, uint32_t gc0 = 0) {
     for (uint32_t k = first; k < n; k += stride) {
         uint32_t t = off + k;
         if (t < K.seg_cap) {
-            uint32_t row = K.rows[rb + (k % cnt)];
-            uint32_t gc = K.row_gclass[row];
+            const uint32_t e = rb + (k % cnt);
+            const bool pre = have0 && e == rb;
+            const uint32_t row = pre ? row0 : K.rows[e], gc = pre ? gc0 : K.rows_gc[e];
             K.item_row[seg_base + t] = row; K.item_slot[seg_base + t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
         }
     }
@@ -183,6 +186,10 @@ __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MA
     for (uint32_t j = 0; j < EMIT_MAX; j++) { uint32_t n = cnt[j] * ((lodm[j] >> 8) & 3u); mine += n; nsec += n ? 1u : 0u; }
     uint64_t mask = __ballot(mine > 0);
     if (!mask) return;
+    // the first pool entry of every section is requested before the reservation: its round trip overlaps the atomic's
+    uint32_t row0[EMIT_MAX], gc0[EMIT_MAX];
+#pragma unroll
+    for (uint32_t j = 0; j < EMIT_MAX; j++) { const bool on = cnt[j] != 0; row0[j] = on ? K.rows[rb[j]] : 0u; gc0[j] = on ? K.rows_gc[rb[j]] : 0u; }
     uint32_t incl = wave_incl_scan(mine), incs = wave_incl_scan(nsec);
     uint32_t tot = __shfl(incl, 63, 64), tots = __shfl(incs, 63, 64);
     const uint32_t shard = K.nshards > 1u ? (shard_hint & (CURSOR_SHARDS - 1u)) : 0u;      // wave-uniform (list / section-block index)
@@ -195,7 +202,7 @@ __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MA
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) {
         const uint32_t m = (lodm[j] >> 8) & 3u, lod = lodm[j] & 7u, n = cnt[j] * m;
-        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K);
+        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K, true, row0[j], gc0[j]);
         uint64_t wide = __ballot(n > WIDE);
         while (wide) {                                          // wave-cooperative expansion of crowded sections
             int src = __ffsll((long long)wide) - 1; wide &= wide - 1;
