@@ -108,7 +108,7 @@ typedef struct {
                                          visible_sections_vec (CullResult::extend, visible_world_flow.rs:31-35, pipeline.rs:228);
                                          default 0 = each visible instance once (the visible-ID *set*) */
 #define RE_CULL_ASYNC           0x2u  /* enqueue only; results are valid after re_wait() */
-#define RE_CULL_FORCE_LARGE_PACK 0x4u /* always use the multi-kernel pack (count/scan/scatter) instead of the single-workgroup pack */
+#define RE_CULL_FORCE_LARGE_PACK 0x4u /* always use the multi-kernel pack (count/scan/scatter) instead of k_pack_small */
 
 /* One (ModelId, sortable) group of the packed buffer == ModelRenderingInformation.instance_location
  * entry (render_flow.rs:964-983). */

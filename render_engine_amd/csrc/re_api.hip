@@ -282,7 +282,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         std::set_union(keys.begin(), keys.end(), lk.begin(), lk.end(), std::back_inserter(merged));
         keys.swap(merged);
     }
-    // pad every level run to whole wave chunks of k_cull_sections (so the level is uniform inside a wave); a pad slot
+    // pad every level run to whole wave chunks of k_scan_cull (so the level is uniform inside a wave); a pad slot
     // carries the largest key of its level (x = z = y = 0xFFFF: never a world section, outline/atomic <= 32768)
     c->n_real_sections = (uint32_t)keys.size();
     bool has_movers = false; for (uint32_t r = 0; r < n && !has_movers; r++) has_movers = (flags[r] & F_HAS_VEL) != 0;
@@ -1693,8 +1693,6 @@ extern "C" int re_debug_get_timeline(re_ctx *c, unsigned long long *out, uint32_
     return RE_OK;
 }
 #endif
-extern "C" int re_debug_get_stamps(re_ctx *c, unsigned long long *out8) { if (!c || !c->h_res || !out8) return RE_E_ARG; memcpy(out8, c->h_res->stamps, 64); return RE_OK; }
-
 extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {
     if (!c || !c->h_res || !n_candidates) return RE_E_ARG;
     *n_candidates = c->h_res->n_candidates; return RE_OK;

@@ -73,7 +73,6 @@ struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
     uint32_t done_frame, pad;               // written last (after a system-scope fence): the frame whose results above are complete -- a synchronous
                                             // call polls this word instead of paying the driver's stream-synchronise latency
-    unsigned long long stamps[8];           // development builds (-DRE_EXP_STAMPS): 100 MHz wall-clock stamps of the pack phases
 };
 constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances k_pack_small takes (every workgroup counts all of them); more go through the count/scan/scatter path
 struct SharedArrays {                       // shared world sections (bounding_box_tree_v2.rs:113-155, 253-316)

@@ -156,7 +156,7 @@ def test_kinematics_one_tick_all_branches(R):
 
 
 def test_pack_paths_agree(R):
-    """single-workgroup pack, multi-kernel pack, and the overflow hand-over between them"""
+    """small pack (k_pack_small), multi-kernel pack, and the overflow hand-over between them"""
     ents = R.synthetic.mixed_world(6000, seed=7, spread=700.0)
     p, w = build_pair(R, ents)
     cam_small = R.Camera((8192, 8192, 9300), (0, 0, -1), 700.0)
