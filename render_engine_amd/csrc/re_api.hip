@@ -920,6 +920,24 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     auto fop = [&](uint32_t slot) -> FlagOp & { auto it = fops.find(slot); if (it == fops.end()) { FlagOp f{}; f.idx = slot; f.and_mask = 0xFF; f.or_mask = 0; it = fops.emplace(slot, f).first; } return it->second; };
     std::vector<uint32_t> refold; std::set<uint32_t> created; std::vector<std::pair<uint32_t, uint32_t>> freed;   // (level, slot): reusable from the next patch on
     int32_t n_real_delta = 0;
+    // ---- capacity check BEFORE anything is touched (a patch that gave up half-way would leave the mirrors ahead of the device):
+    // free slots per level for the sections to create, row-pool room for every segment that may be relocated + the shared region
+    {
+        uint32_t need_slots[MAX_LEVELS] = {}; uint64_t need_pool = 0;
+        for (uint64_t K : affected) {
+            const int32_t slot = find_slot(c, K);
+            uint32_t size = 0;
+            if (slot >= 0) for (uint32_t i = 0, b = c->h_cell_begin[slot], e = c->h_cell_nl[slot] + c->h_cell_ns[slot]; i < e; i++) { uint32_t r = c->h_rows[b + i]; if (c->h_row_nk[r] == 1 && c->h_row_key[r] == K) size++; }
+            auto ar = arrive.find(K);
+            if (ar != arrive.end()) size += (uint32_t)ar->second.size();     // upper bound (an arriving row may already be counted)
+            if (size == 0 && !linked.count(K)) continue;
+            if (slot < 0) need_slots[key_level(K) & (MAX_LEVELS - 1)]++;
+            if (slot < 0 || size > c->h_cell_cap[slot]) need_pool += std::max(4u, size * 2u);
+        }
+        for (const SharedRec &sr : shrec) { (void)sr; need_pool += 1; }
+        for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) if (need_slots[l] > c->free_slots[l].size()) return 1;
+        if ((uint64_t)c->pool_used + need_pool > c->pool_cap) return 1;
+    }
     for (uint32_t r : removed_rows) if (c->h_row_cell[r] != ROW_CELL_NONE) { c->h_row_cell[r] = ROW_CELL_NONE; p_rowcell.push_back(Pair32{ r, ROW_CELL_NONE }); }
     for (uint64_t K : affected) {
         int32_t slot = find_slot(c, K);
@@ -942,7 +960,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         }
         if (slot < 0) {
             const uint32_t lv = key_level(K) & (MAX_LEVELS - 1);
-            if (c->free_slots[lv].empty()) return 1;
+            if (c->free_slots[lv].empty()) return c->fail(RE_E_STATE, "patch_sections: free-slot accounting");
             slot = (int32_t)c->free_slots[lv].back(); c->free_slots[lv].pop_back();
             c->h_cell_key[slot] = K; c->extra_slots[K] = (uint32_t)slot; c->h_cell_cap[slot] = 0; c->h_cell_begin[slot] = 0;
             p_key.push_back(Pair64{ (uint32_t)slot, 0, K }); p_stamp.push_back(Pair32{ (uint32_t)slot, 0 });
@@ -954,7 +972,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         if (size > c->h_cell_cap[slot]) {
             relocated = true;
             const uint32_t cap = std::max(4u, size * 2u);
-            if ((uint64_t)c->pool_used + cap > c->pool_cap) return 1;
+            if ((uint64_t)c->pool_used + cap > c->pool_cap) return c->fail(RE_E_STATE, "patch_sections: row-pool accounting");
             c->h_cell_begin[slot] = c->pool_used; c->h_cell_cap[slot] = cap; c->pool_used += cap;
             if (c->h_rows.size() < c->pool_used) c->h_rows.resize(c->pool_used, 0);
             p_begin.push_back(Pair32{ (uint32_t)slot, c->h_cell_begin[slot] });
@@ -972,7 +990,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     lap("B cells");
     // ---- C. shared sections: members in one fresh region at the end of the pool, table arrays re-uploaded whole
     uint32_t sh_total = 0; for (uint32_t s2 = 0; s2 < nsh; s2++) sh_total += (uint32_t)(sh_act[s2].size() + sh_sta[s2].size());
-    if ((uint64_t)c->pool_used + sh_total > c->pool_cap) return 1;
+    if ((uint64_t)c->pool_used + sh_total > c->pool_cap) return c->fail(RE_E_STATE, "patch_sections: row-pool accounting (shared region)");
     std::vector<int32_t> sh_cells((size_t)nsh * 8 + 8, -1); std::vector<uint32_t> sh_begin(nsh + 1, 0), sh_nact(nsh + 1, 0), sh_nstat(nsh + 1, 0);
     std::unordered_map<uint32_t, std::vector<uint32_t>> cell_links;
     const uint32_t sh_region = c->pool_used;

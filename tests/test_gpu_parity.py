@@ -337,3 +337,44 @@ def test_world_with_more_than_512_sections_per_axis(R):
     check_sections(p, w)
     check_entities(R, p, w, ents[:300])
     p.close(); w.close()
+
+
+@pytest.mark.parametrize("seed", [3, 11, 29, 57, 101, 202])
+def test_soak_random_frames(R, seed):
+    """a longer randomized run: movers, spinners, user change batches (every kind), cameras that jump around, synchronous and
+    asynchronous frames mixed -- section table, entities and the rendered set are compared with the oracle every few frames.
+    Exercises the in-place table patches (slot reuse, relocated row segments, emptied and re-created sections, shared-section churn)."""
+    rng = np.random.default_rng(seed)
+    ents = R.synthetic.mixed_world(2500 + 500 * (seed % 4), seed=seed, spread=350.0 + 60.0 * (seed % 5))
+    ents["vel"] *= 8.0
+    p, w = build_pair(R, ents)
+    frozen = set(int(i) for i in ents["id"][(ents["flags"] & R.F_STATIC) != 0])
+    cam = R.Camera((8192, 8192, 8500), (0, 0, -1), 1000.0)
+    for f in range(48):
+        pos = (8192 + rng.uniform(-300, 300), 8192 + rng.uniform(-200, 200), 8192 + rng.uniform(-100, 500))
+        d = rng.uniform(-1, 1, 3); d[2] -= 1.5
+        cam = R.Camera(pos, tuple(d / np.linalg.norm(d)), float(rng.choice([600.0, 1000.0, 2500.0])))
+        oc = oracle_camera(cam)
+        asynchronous = bool(f % 3)
+        if asynchronous:
+            p.cull_and_pack(cam, asynchronous=True, copy=False); p.tick(0.04, asynchronous=True)
+            w.cull(oc); w.render(oc); w.tick(oc, 0.04)
+        else:
+            check_frame(R, p, w, cam, bool(f % 2))
+            n_o, oob_o = w.tick(oc, 0.04)
+            t = p.tick(0.04)
+            assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        if f % 4 == 1:
+            ch = random_changes(R, ents, rng, 60, frozen)
+            n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT))
+            g = p.apply_changes(ch)
+            assert g["n_changed"] == n_a and g["n_out_of_bounds"] == len(oob_a)
+        if f % 6 == 5:
+            p.wait()
+            check_sections(p, w)
+            assert p.stats()["n_shared_sections"] == w.L.ro_num_shared(w.h)
+    p.wait()
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::5])
+    check_frame(R, p, w, cam, True)
+    p.close(); w.close()
