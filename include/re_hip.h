@@ -72,6 +72,7 @@ typedef struct {
 
 #define RE_CFG_DEFAULT 0u
 #define RE_CFG_FULL_REBUILD 0x1u  /* testing: after section changes rebuild the whole section table instead of patching it in place */
+#define RE_CFG_TIGHT_SLACK  0x2u  /* testing: almost no spare slots / row-pool slack, so patches and full rebuilds alternate */
 
 /* Entities, struct-of-arrays, host pointers; copied during the call.  Optional arrays may be
  * NULL when no entity carries the corresponding flag. */

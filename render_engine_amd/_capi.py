@@ -47,6 +47,7 @@ class Visible(C.Structure):
 
 
 CFG_FULL_REBUILD = 0x1
+CFG_TIGHT_SLACK = 0x2
 CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP = 0, 1, 2, 3
 
 

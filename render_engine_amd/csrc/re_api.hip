@@ -297,7 +297,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
             const size_t run0 = padded.size();
             while (i < keys.size() && key_level(keys[i]) == lv) padded.push_back(keys[i++]);
             // worlds with movers get spare slots per level run (sections created by re-bucket patches live there): ~0.8 %, at least one chunk
-            size_t spare = has_movers ? std::max<size_t>(wave_keys, (padded.size() - run0) / 128) : 0;
+            size_t spare = (has_movers && !(c->cfg.flags & RE_CFG_TIGHT_SLACK)) ? std::max<size_t>(wave_keys, (padded.size() - run0) / 128) : 0;
             for (size_t k = 0; k < spare; k++) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
             while (padded.size() % wave_keys) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
         }
@@ -378,7 +378,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     HIPCHK(c, c->d_cell_key.alloc(keys_padded.size(), acct));
     HIPCHK(c, c->d_cell_tight.alloc(ncells, acct)); HIPCHK(c, c->d_cell_begin.alloc(ncells + 1, acct)); HIPCHK(c, c->d_cell_nlocal.alloc(ncells, acct));
     HIPCHK(c, c->d_cell_nstatic.alloc(ncells, acct)); HIPCHK(c, c->d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, c->d_cell_flags.alloc(ncells, acct));
-    c->pool_used = (uint32_t)rows.size(); c->pool_cap = c->pool_used + c->pool_used / 4u + 65536u;      // slack: re-bucket patches append relocated segments
+    c->pool_used = (uint32_t)rows.size(); c->pool_cap = c->pool_used + ((c->cfg.flags & RE_CFG_TIGHT_SLACK) ? 96u : c->pool_used / 4u + 65536u);      // slack: re-bucket patches append relocated segments
     HIPCHK(c, c->d_rows.alloc(c->pool_cap, acct)); HIPCHK(c, c->d_row_cell.alloc(n, acct));
     HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
     HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));

@@ -339,15 +339,16 @@ def test_world_with_more_than_512_sections_per_axis(R):
     p.close(); w.close()
 
 
-@pytest.mark.parametrize("seed", [3, 11, 29, 57, 101, 202])
-def test_soak_random_frames(R, seed):
+@pytest.mark.parametrize("seed,atomic,tight", [(3, 64, False), (11, 64, True), (29, 64, False), (57, 16, False), (101, 64, True), (202, 16, True)])
+def test_soak_random_frames(R, seed, atomic, tight):
     """a longer randomized run: movers, spinners, user change batches (every kind), cameras that jump around, synchronous and
     asynchronous frames mixed -- section table, entities and the rendered set are compared with the oracle every few frames.
     Exercises the in-place table patches (slot reuse, relocated row segments, emptied and re-created sections, shared-section churn)."""
     rng = np.random.default_rng(seed)
-    ents = R.synthetic.mixed_world(2500 + 500 * (seed % 4), seed=seed, spread=350.0 + 60.0 * (seed % 5))
+    ents = R.synthetic.mixed_world(2500 + 500 * (seed % 4), seed=seed, spread=350.0 + 60.0 * (seed % 5), atomic=atomic)
     ents["vel"] *= 8.0
-    p, w = build_pair(R, ents)
+    # atomic 16: more than 512 sections per axis -> full 64-bit stream keys; tight: hardly any slack -> patches and full rebuilds alternate
+    p, w = build_pair(R, ents, atomic=atomic, flags=R._capi.CFG_TIGHT_SLACK if tight else 0)
     frozen = set(int(i) for i in ents["id"][(ents["flags"] & R.F_STATIC) != 0])
     cam = R.Camera((8192, 8192, 8500), (0, 0, -1), 1000.0)
     for f in range(48):
