@@ -200,7 +200,11 @@ int re_set_output_count(re_ctx *ctx, uint32_t *d_count);
  * re_cull_pack): like Pipeline::execute it clears the changed-static-section set afterwards (pipeline.rs:271).
  * The reference's static render cache is a snapshot the logic phase never refreshes: an entity made static by a change is
  * therefore not drawn until it wakes up again (modelled), and a static entity of the snapshot that is woken, deleted or
- * rewritten keeps being drawn with its old bytes (needs ghost instances: RE_E_UNSUPPORTED for now). */
+ * rewritten keeps being drawn with its old bytes.  The latter is a ghost instance: a copy of {id, matrix} taken at the first
+ * such change and parked behind the static rows of the section whose cache entry holds the entity (its own section, or the
+ * linking section that cached its shared section); it is drawn whenever that section's cached static data is, also after the
+ * section was emptied and re-created.  Ghosts live beyond the entity columns, max(2048, n/8) of them per upload
+ * (RE_E_CAPACITY beyond that; the batch is then refused whole). */
 #define RE_CHANGE_MODIFY       0u  /* ModifyRequest: component = RE_C_POSITION .. RE_C_ROTATION_ACC, value = the new component */
 #define RE_CHANGE_DELETE       1u  /* DeleteRequest (:156-172) */
 #define RE_CHANGE_MAKE_STATIC  2u  /* MakeObjectStatic (:112-122) */

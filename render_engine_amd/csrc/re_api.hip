@@ -55,6 +55,7 @@ struct Carry {
     std::vector<SharedIdPub> shids; std::vector<Aabb> sh_aabb; std::vector<int32_t> sh_owner_key_idx; std::vector<uint64_t> sh_owner_key; std::vector<uint8_t> sh_cached;
     std::set<uint64_t> changed_cells, changed_static; std::vector<SharedIdPub> changed_shared; std::set<SharedIdPub> changed_shared_set;
     bool too_many = false;
+    std::set<uint64_t> ghost_touched;                   // sections that received a ghost instance: their row segment is rewritten, nothing else changes
 };
 
 struct re_ctx {
@@ -103,6 +104,10 @@ struct re_ctx {
     std::unordered_map<uint64_t, uint32_t> extra_slots;  // sections created since, key -> slot
     std::vector<std::vector<uint32_t>> free_slots;       // per level: padding / emptied slots a new section of that level may take
     uint32_t pool_used = 0, pool_cap = 0, n_patches = 0;
+    // ghost instances (snapshot copies of the frozen static render cache): rows n .. n + n_ghost of the id / matrix columns
+    uint32_t ghost_cap = 0, n_ghost = 0; std::vector<uint32_t> h_ghost_gc; std::map<uint64_t, std::vector<uint32_t>> ghost_map;   // per section key: its ghost rows
+    DevBuf<uint32_t> d_cell_nghost; std::vector<uint32_t> h_cell_ng;
+    std::set<uint64_t> dormant_cached;                  // sections with ghosts that were cached when they were emptied: the reference's cache entry outlives the section and shows again when the section is re-created
     std::set<uint32_t> h_uncached;                       // rows made static after the static render cache froze: in the tree's static sets, not drawn
     // groups
     uint32_t ngclass = 0, nslots = 0;
@@ -201,6 +206,7 @@ static RowArrays row_arrays(re_ctx *c) {
 
 // group class a row-pool entry carries for row r: hidden while the row is not to be drawn (removed, or made static after the cache froze)
 static inline uint32_t effective_gclass(const re_ctx *c, uint32_t r) {
+    if (r >= c->n) return c->h_ghost_gc[r - c->n];                            // a ghost instance keeps the group class it was cloned with
     return ((c->h_flags[r] & F_DEAD) || c->h_uncached.count(r)) ? 0xFFFFFFFFu : c->h_gclass[r];
 }
 // pool positions of row r (one: its section's segment or its shared section's) get the row's current effective group class
@@ -305,7 +311,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     }
     auto is_pad = [](uint64_t k) { return (k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull; };
     const uint32_t ncells = (uint32_t)keys.size();
-    std::vector<uint32_t> begin(ncells + 1, 0), nlocal(ncells, 0), nstatic(ncells, 0), rows; rows.reserve(n);
+    std::vector<uint32_t> begin(ncells + 1, 0), nlocal(ncells, 0), nstatic(ncells, 0), nghost(ncells, 0), rows; rows.reserve(n);
     std::vector<uint32_t> row_cell(n, ROW_CELL_NONE);
     {
         size_t i = 0;
@@ -315,6 +321,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
                 if (recs[i].sub >> 32) nstatic[ci]++; else nlocal[ci]++;
                 rows.push_back(recs[i].row); row_cell[recs[i].row] = ci; i++;
             }
+            if (!c->ghost_map.empty()) { auto g = c->ghost_map.find(keys[ci]); if (g != c->ghost_map.end()) { nghost[ci] = (uint32_t)g->second.size(); for (uint32_t gr : g->second) rows.push_back(gr); } }
         }
         begin[ncells] = (uint32_t)rows.size();
     }
@@ -352,11 +359,15 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         bool existed = old != carry->keys.end() && *old == keys[ci];
         bool changed = carry->changed_cells.count(keys[ci]) != 0;
         uint8_t f = existed ? (uint8_t)(carry->flags[old - carry->keys.begin()] & (CF_STATIC_SECTION | CF_STATIC_CACHED | CF_STATIC_DIRTY)) : (uint8_t)0;
+        if (!existed && c->dormant_cached.erase(keys[ci])) f |= CF_STATIC_CACHED;   // a re-created section whose cache entry (ghosts) survived it
         if (changed || !existed) f = (uint8_t)((f & ~CF_STATIC_SECTION) | (loop1(ci) ? CF_STATIC_SECTION : 0));
         if (carry->changed_static.count(keys[ci])) f |= CF_STATIC_DIRTY;
         cflags[ci] = f;
         if (existed && !changed) { refold[ci] = 0; carried_tight[ci] = carry->tight[old - carry->keys.begin()]; }
     }
+    if (carry && !c->ghost_map.empty())                                      // sections that disappear with this rebuild while their cache entry holds ghosts
+        for (size_t i = 0; i < carry->keys.size(); i++)
+            if ((carry->flags[i] & CF_STATIC_CACHED) && c->ghost_map.count(carry->keys[i]) && !std::binary_search(keys.begin(), keys.end(), carry->keys[i])) c->dormant_cached.insert(carry->keys[i]);
     std::vector<uint32_t> sh_order(nsh); for (uint32_t s = 0; s < nsh; s++) sh_order[s] = s;
     std::sort(sh_order.begin(), sh_order.end(), [&](uint32_t a, uint32_t b) { return shids[a] < shids[b]; });   // canonical id order
     for (uint32_t s : sh_order) {
@@ -371,7 +382,8 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     c->ncells = ncells; c->nsh = nsh; c->nrows_csr = (uint32_t)rows.size();
     c->h_cell_key = keys; c->h_row_cell = row_cell; c->h_shids = shids; c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat;
     c->base_keys = keys; c->extra_slots.clear(); c->base_index.clear(); for (size_t i = 0; i < keys.size(); i += 1024) c->base_index.push_back(keys[i]); c->h_cell_nl = nlocal; c->h_cell_ns = nstatic; c->h_cell_begin.assign(begin.begin(), begin.begin() + ncells);
-    c->h_cell_cap.resize(ncells); for (uint32_t ci = 0; ci < ncells; ci++) c->h_cell_cap[ci] = nlocal[ci] + nstatic[ci];
+    c->h_cell_cap.resize(ncells); for (uint32_t ci = 0; ci < ncells; ci++) c->h_cell_cap[ci] = nlocal[ci] + nstatic[ci] + nghost[ci];
+    c->h_cell_ng = nghost;
     c->h_rows = rows; c->free_slots.assign(MAX_LEVELS, {}); c->h_sh_begin.assign(sh_begin.begin(), sh_begin.begin() + nsh);
     for (uint32_t ci = ncells; ci-- > 0;) if (is_pad(keys[ci])) c->free_slots[key_level(keys[ci]) & (MAX_LEVELS - 1)].push_back(ci);   // popped from the back: lowest slot first
     std::vector<uint64_t> keys_padded(keys); keys_padded.resize((size_t)((ncells + 1) & ~1u) + 2, 0xFFFFFFFFFFFFFFFFull);
@@ -399,6 +411,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     if (ncells) {
         HIPCHK(c, hipMemcpyAsync(c->d_cell_nlocal.p, nlocal.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_cell_nstatic.p, nstatic.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, c->d_cell_nghost.alloc(ncells, acct)); HIPCHK(c, hipMemcpyAsync(c->d_cell_nghost.p, nghost.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_cell_flags.p, cflags.data(), (size_t)ncells, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(c->d_cell_stamp.p, 0, (size_t)ncells * 4, st));
     }
@@ -519,7 +532,8 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->ndyn = (uint32_t)dyn_row.size();
     c->ngclass = (uint32_t)gkeys.size(); c->nslots = c->ngclass * 8u;
     hipStream_t st = c->stream;
-    HIPCHK(c, c->d_id.alloc(n, acct)); HIPCHK(c, c->d_gclass.alloc(n, acct)); HIPCHK(c, c->d_flags.alloc(n, acct)); HIPCHK(c, c->d_mat.alloc((size_t)n * 16, acct));
+    c->ghost_cap = std::max(2048u, n / 8u);   // ghost instances of the frozen static cache (68 bytes each) c->n_ghost = 0; c->h_ghost_gc.clear(); c->ghost_map.clear(); c->dormant_cached.clear();
+    HIPCHK(c, c->d_id.alloc((size_t)n + c->ghost_cap, acct)); HIPCHK(c, c->d_gclass.alloc(n, acct)); HIPCHK(c, c->d_flags.alloc(n, acct)); HIPCHK(c, c->d_mat.alloc(((size_t)n + c->ghost_cap) * 16, acct));
     HIPCHK(c, c->d_pos.alloc((size_t)n * 3, acct)); HIPCHK(c, c->d_rot.alloc((size_t)n * 4, acct)); HIPCHK(c, c->d_scale.alloc((size_t)n * 3, acct));
     HIPCHK(c, c->d_aabb.alloc(n, acct)); HIPCHK(c, c->d_orig.alloc(n, acct));
     HIPCHK(c, c->d_row_key.alloc(n, acct)); HIPCHK(c, c->d_row_nk.alloc(n, acct)); HIPCHK(c, c->d_shrec.alloc(n, acct)); HIPCHK(c, c->d_counter.alloc(4, acct));
@@ -582,7 +596,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     // frame buffers
     c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
     c->item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
-    c->list_cap = std::max(c->ndyn, 1u);
+    c->list_cap = std::max(std::max(c->ndyn, std::min(n, 65536u)), 1u);   // movers of one tick (dynamic rows) or of one change batch (any row)
     HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
     HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 4)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 4));   // the pack reads speculatively past the cursors
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
@@ -780,7 +794,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     {   // every instance the cull reserved must have been counted into a group (dead rows excepted): otherwise a cursor segment overflowed
         uint32_t counted = 0; for (uint32_t g = 0; g < c->h_res->n_groups && g < c->nslots; g++) counted += c->h_ranges[g].count;
         if (counted != c->h_res->total) return c->fail(RE_E_STATE, "group table inconsistent (%u vs %u)", counted, c->h_res->total);
-        if (c->h_res->n_items > c->h_res->total + c->n_dead) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
+        if (c->h_res->n_items > c->h_res->total + c->n_dead + (uint32_t)c->h_uncached.size()) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
     }
     if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
     fill_visible(c, out);
@@ -813,7 +827,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
     ScanCullArgs SA; SA.B = c->PB; SA.B32 = c->PB32; SA.cell_key64 = c->d_cell_key.p; SA.P = P; SA.P_dev = c->d_params.p;
-    SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p;
+    SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p; SA.cell_nghost = c->d_cell_nghost.p;
     SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
     static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
 #ifdef RE_EXP_STAMPS
@@ -835,7 +849,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         // makes the pack decline (overflow) and the frame is redone through the large path
         uint32_t per_shard = (c->pred_total + c->pred_total / 2u) / CURSOR_SHARDS + 64u;
         uint32_t pgrid = CURSOR_SHARDS * std::min(32u, (per_shard + 63u) / 64u);
-        hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c), c->n);
+        hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c), c->n + c->ghost_cap);
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;
@@ -913,9 +927,11 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     lap("A shared");
     // ---- B. unique sections that may change: changed ones, newly linked ones, formerly linked ones
     std::set<uint64_t> affected(carry.changed_cells.begin(), carry.changed_cells.end());
+    affected.insert(carry.ghost_touched.begin(), carry.ghost_touched.end());
+    auto ghosts_of = [&](uint64_t K) -> const std::vector<uint32_t> * { auto g = c->ghost_map.find(K); return g == c->ghost_map.end() ? nullptr : &g->second; };
     for (uint64_t k : linked) if (find_slot(c, k) < 0) affected.insert(k);
     for (const SharedIdPub &id : c->h_shids) for (uint32_t k = 0; k < id.nk; k++) if (!linked.count(id.keys[k])) affected.insert(id.keys[k]);
-    std::vector<Pair64> p_key; std::vector<Pair32> p_begin, p_nl, p_ns, p_rows, p_rowcell, p_stamp;
+    std::vector<Pair64> p_key; std::vector<Pair32> p_begin, p_nl, p_ns, p_ng, p_rows, p_rowcell, p_stamp;
     std::map<uint32_t, FlagOp> fops;                                          // one merged op per slot
     auto fop = [&](uint32_t slot) -> FlagOp & { auto it = fops.find(slot); if (it == fops.end()) { FlagOp f{}; f.idx = slot; f.and_mask = 0xFF; f.or_mask = 0; it = fops.emplace(slot, f).first; } return it->second; };
     std::vector<uint32_t> refold; std::set<uint32_t> created; std::vector<std::pair<uint32_t, uint32_t>> freed;   // (level, slot): reusable from the next patch on
@@ -931,6 +947,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             auto ar = arrive.find(K);
             if (ar != arrive.end()) size += (uint32_t)ar->second.size();     // upper bound (an arriving row may already be counted)
             if (size == 0 && !linked.count(K)) continue;
+            if (const auto *g = ghosts_of(K)) size += (uint32_t)g->size();
             if (slot < 0) need_slots[key_level(K) & (MAX_LEVELS - 1)]++;
             if (slot < 0 || size > c->h_cell_cap[slot]) need_pool += std::max(4u, size * 2u);
         }
@@ -952,7 +969,8 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             if (slot < 0) continue;
             const uint32_t lv = key_level(K) & (MAX_LEVELS - 1);
             const uint64_t padk = pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu);
-            c->h_cell_key[slot] = padk; c->h_cell_nl[slot] = 0; c->h_cell_ns[slot] = 0; freed.push_back({ lv, (uint32_t)slot }); c->extra_slots.erase(K);
+            if (ghosts_of(K)) { uint8_t f0 = 0; HIPCHK(c, hipMemcpy(&f0, c->d_cell_flags.p + slot, 1, hipMemcpyDeviceToHost)); if (f0 & CF_STATIC_CACHED) c->dormant_cached.insert(K); }
+            c->h_cell_key[slot] = padk; c->h_cell_nl[slot] = 0; c->h_cell_ns[slot] = 0; c->h_cell_ng[slot] = 0; p_ng.push_back(Pair32{ (uint32_t)slot, 0 }); freed.push_back({ lv, (uint32_t)slot }); c->extra_slots.erase(K);
             p_key.push_back(Pair64{ (uint32_t)slot, 0, padk }); p_nl.push_back(Pair32{ (uint32_t)slot, 0 }); p_ns.push_back(Pair32{ (uint32_t)slot, 0 });
             FlagOp &f = fop((uint32_t)slot); f.and_mask = 0; f.or_mask = (uint8_t)(CF_PAD | CF_STATIC_SECTION);
             n_real_delta--;
@@ -965,8 +983,12 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             c->h_cell_key[slot] = K; c->extra_slots[K] = (uint32_t)slot; c->h_cell_cap[slot] = 0; c->h_cell_begin[slot] = 0;
             p_key.push_back(Pair64{ (uint32_t)slot, 0, K }); p_stamp.push_back(Pair32{ (uint32_t)slot, 0 });
             FlagOp &f = fop((uint32_t)slot); f.and_mask = 0; f.or_mask = 0;
+            if (c->dormant_cached.erase(K)) f.or_mask |= CF_STATIC_CACHED;          // its cache entry (now ghosts only) is reachable again
             created.insert((uint32_t)slot); n_real_delta++;
         }
+        const std::vector<uint32_t> *gh = ghosts_of(K);                        // snapshot copies parked in this section, behind its static rows
+        const uint32_t nmem = (uint32_t)mem.size(), ng = gh ? (uint32_t)gh->size() : 0u;
+        if (gh) mem.insert(mem.end(), gh->begin(), gh->end());
         const uint32_t size = (uint32_t)mem.size();
         bool relocated = false;
         if (size > c->h_cell_cap[slot]) {
@@ -977,13 +999,14 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             if (c->h_rows.size() < c->pool_used) c->h_rows.resize(c->pool_used, 0);
             p_begin.push_back(Pair32{ (uint32_t)slot, c->h_cell_begin[slot] });
         }
-        uint32_t nl = 0; for (uint32_t r : mem) if (!(c->h_flags[r] & F_STATIC)) nl++;
-        c->h_cell_nl[slot] = nl; c->h_cell_ns[slot] = size - nl;
-        p_nl.push_back(Pair32{ (uint32_t)slot, nl }); p_ns.push_back(Pair32{ (uint32_t)slot, size - nl });
+        uint32_t nl = 0; for (uint32_t i = 0; i < nmem; i++) if (!(c->h_flags[mem[i]] & F_STATIC)) nl++;
+        c->h_cell_nl[slot] = nl; c->h_cell_ns[slot] = nmem - nl;
+        p_nl.push_back(Pair32{ (uint32_t)slot, nl }); p_ns.push_back(Pair32{ (uint32_t)slot, nmem - nl });
+        if (c->h_cell_ng[slot] != ng || created.count((uint32_t)slot)) { c->h_cell_ng[slot] = ng; p_ng.push_back(Pair32{ (uint32_t)slot, ng }); }
         for (uint32_t i = 0; i < size; i++) {
             const uint32_t pos = c->h_cell_begin[slot] + i, r = mem[i];
             if (c->h_rows[pos] != r || relocated) { c->h_rows[pos] = r; p_rows.push_back(Pair32{ pos, r }); }
-            if (c->h_row_cell[r] != (uint32_t)slot) { c->h_row_cell[r] = (uint32_t)slot; p_rowcell.push_back(Pair32{ r, (uint32_t)slot }); }
+            if (i < nmem && c->h_row_cell[r] != (uint32_t)slot) { c->h_row_cell[r] = (uint32_t)slot; p_rowcell.push_back(Pair32{ r, (uint32_t)slot }); }
         }
         if (carry.changed_cells.count(K) || created.count((uint32_t)slot)) refold.push_back((uint32_t)slot);
     }
@@ -1063,21 +1086,21 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         for (const Pair32 &pr : p_rowcell) { auto it = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), pr.idx); if (it != c->h_dyn_row.end() && *it == pr.idx) p_dyncell.push_back(Pair32{ (uint32_t)(it - c->h_dyn_row.begin()), pr.val }); }
         std::vector<Pair32> p_rowsgc; p_rowsgc.reserve(p_rows.size());         // the group class travels with every pool entry written
         for (const Pair32 &pr : p_rows) p_rowsgc.push_back(Pair32{ pr.idx, effective_gclass(c, pr.val) });
-        std::vector<Pair32> *v32[8] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell, &p_rowsgc };
-        uint32_t *dst32[8] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_dyn_cell.p, c->d_rows_gc.p };
+        std::vector<Pair32> *v32[9] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell, &p_rowsgc, &p_ng };
+        uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_dyn_cell.p, c->d_rows_gc.p, c->d_cell_nghost.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
-        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 128;
+        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
         if (c->d_stage.n < bytes) HIPCHK(c, c->d_stage.alloc(bytes * 2, nullptr));
         std::vector<uint8_t> host(bytes); size_t off = 0;
         auto put = [&](const void *src, size_t nb) { size_t o = off; if (nb) memcpy(host.data() + off, src, nb); off = (off + nb + 15) & ~(size_t)15; return o; };
         const size_t o_key = put(p_key.data(), p_key.size() * sizeof(Pair64)), o_fl = put(vf.data(), vf.size() * sizeof(FlagOp)), o_rf = put(refold.data(), refold.size() * 4);
-        size_t o32[8]; for (int k = 0; k < 8; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
+        size_t o32[9]; for (int k = 0; k < 9; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
         const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
         if (!p_key32.empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)p_key32.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key32.size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o_k32), c->d_cell_key32.p);
         if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
-        for (int k = 0; k < 8; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
+        for (int k = 0; k < 9; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
         std::vector<uint32_t> sh_gc(sh_total);
         for (uint32_t i = 0; i < sh_total; i++) sh_gc[i] = effective_gclass(c, c->h_rows[sh_region + i]);
         if (sh_total) { HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
@@ -1140,7 +1163,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
 // pre: tree operations an apply_change batch performs inline, before the kinematic re-adds (MakeObjectStatic / WakeUpRequest:
 // remove + add with the other static flag into the same section; DeleteRequest: remove only), in list order.
 struct TreeOp { uint32_t row; uint8_t kind; };                          // kind: 1 = make static, 2 = wake up, 3 = remove
-static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre = nullptr) {
+static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre = nullptr, const std::set<uint64_t> *ghost_touched = nullptr) {
     hipStream_t st = c->stream;
     static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
     auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
@@ -1163,6 +1186,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         HIPCHK(c, hipMemcpyAsync(nkeys.data(), d_keys.p, (size_t)M * 64, hipMemcpyDeviceToHost, st));
     }
     Carry carry;
+    if (ghost_touched) carry.ghost_touched = *ghost_touched;
     if (M) HIPCHK(c, hipStreamSynchronize(st));
     lap("assign");
     d_list.release(nullptr); d_nk.release(nullptr); d_keys.release(nullptr);
@@ -1423,14 +1447,37 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     auto normalized = [](const float *v) { std::array<float, 4> o; float nn = norm3(v[0], v[1], v[2]); o[0] = v[0] / nn; o[1] = v[1] / nn; o[2] = v[2] / nn; o[3] = v[3]; return o; };
     // The static render cache of the reference is a snapshot that the logic phase can never refresh (render_flow.rs:549-594 reads
     // changed_static_unique, which pipeline.rs:271 clears before the next render): a cached static entity that is woken, deleted,
-    // moved or rewritten stays in the picture with its old bytes, and an entity made static later is never drawn.  The second case
-    // is modelled (the row keeps its place in the static sets but its group class is hidden); the first needs ghost instances and
-    // is refused for now.
+    // moved or rewritten stays in the picture with its old bytes, and an entity made static later is never drawn.  Both are
+    // modelled: the first as a ghost instance parked in the caching section, the second by hiding the row's group class.
     std::map<uint32_t, bool> is_static;                                       // static bit as the batch evolves (the host mirror changes during the replay)
     auto stat = [&](uint32_t r) -> bool & { auto it = is_static.find(r); if (it == is_static.end()) it = is_static.emplace(r, (c->h_flags[r] & F_STATIC) != 0).first; return it->second; };
     std::set<uint32_t> hide, unhide; bool new_rotvel = false;
     auto uncached = [&](uint32_t r) { return (c->h_uncached.count(r) && !unhide.count(r)) || hide.count(r); };
-    const char *frozen = "re_apply_changes: entity %u is a static entity of the frozen static render cache; changing it needs ghost instances (not supported yet)";
+    // First touch of a static entity that the frozen cache holds: plan a ghost instance (a copy of id + matrix as they are now,
+    // parked behind the static rows of the section that cached it) and from then on treat the entity as one made static after the
+    // freeze: hidden while it stays static.  The cache keeps drawing the copy whatever happens to the entity.
+    std::vector<std::pair<uint32_t, uint64_t>> ghosts;                        // (row, key of the caching section)
+    std::set<uint32_t> ghosted; std::set<uint64_t> shared_ghost_owners;      // sections that park a ghost of a shared section's static member
+    std::vector<int32_t> sh_owner_h; std::vector<uint8_t> sh_cached_h, cell_flags_h;
+    auto plan_ghost = [&](uint32_t r) -> int {
+        if (ghosted.count(r)) return RE_OK;
+        ghosted.insert(r); hide.insert(r);
+        if (c->h_row_nk[r] == 1) {                                              // cached by its own section -- unless that lay beyond the draw distance when the cache froze (an empty entry)
+            if (cell_flags_h.empty() && c->ncells) { cell_flags_h.resize(c->ncells); HIPCHK(c, hipMemcpy(cell_flags_h.data(), c->d_cell_flags.p, c->ncells, hipMemcpyDeviceToHost)); }
+            const uint32_t slot = c->h_row_cell[r];
+            if (slot < cell_flags_h.size() && (cell_flags_h[slot] & CF_STATIC_CACHED)) ghosts.push_back({ r, c->h_row_key[r] });
+            return RE_OK;
+        }
+        if (c->h_row_nk[r] > 1) {                                              // a shared section's static members are cached by one of its linking sections
+            if (sh_owner_h.empty() && c->nsh) {
+                sh_owner_h.resize(c->nsh); sh_cached_h.resize(c->nsh);
+                HIPCHK(c, hipMemcpy(sh_owner_h.data(), c->d_sh_owner.p, (size_t)c->nsh * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(sh_cached_h.data(), c->d_sh_cached.p, c->nsh, hipMemcpyDeviceToHost));
+            }
+            const uint32_t s2 = c->h_row_cell[r] & ~ROW_CELL_SHARED;
+            if (s2 < sh_owner_h.size() && sh_cached_h[s2] && sh_owner_h[s2] >= 0) { ghosts.push_back({ r, c->h_cell_key[sh_owner_h[s2]] }); shared_ghost_owners.insert(c->h_cell_key[sh_owner_h[s2]]); }
+        }
+        return RE_OK;
+    };
     for (uint32_t i = 0; i < n; i++) {
         const re_change &ch = changes[i];
         uint32_t r = 0;
@@ -1453,14 +1500,14 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
                         break;
                     default: return c->fail(RE_E_ARG, "re_apply_changes: component %u cannot be modified (change %u)", ch.component, i);
                 }
-                if ((pos || rot || scl) && stat(r) && !uncached(r)) return c->fail(RE_E_UNSUPPORTED, frozen, ch.entity_id);
+                if ((pos || rot || scl) && stat(r) && !uncached(r)) { int rc = plan_ghost(r); if (rc != RE_OK) return rc; }
                 writes[{ r, ch.component }] = v;
                 if (pos && !rot && !scl) { if (!kin.count(r)) trans.insert(r); }
                 else if (pos || rot || scl) { kin.insert(r); trans.erase(r); }
                 break;
             }
             case RE_CHANGE_DELETE:
-                if (stat(r) && !uncached(r)) return c->fail(RE_E_UNSUPPORTED, frozen, ch.entity_id);
+                if (stat(r) && !uncached(r)) { int rc = plan_ghost(r); if (rc != RE_OK) return rc; }
                 pre.push_back({ r, 3 }); kin.erase(r); trans.erase(r); deleted.insert(r);
                 flag_op(r, 0, F_DEAD);
                 break;
@@ -1469,14 +1516,25 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
                 if (!stat(r)) { stat(r) = true; if (unhide.count(r)) unhide.erase(r); else hide.insert(r); }
                 break;
             case RE_CHANGE_WAKE_UP:
-                if (stat(r) && !uncached(r)) return c->fail(RE_E_UNSUPPORTED, frozen, ch.entity_id);
+                if (stat(r) && !uncached(r)) { int rc = plan_ghost(r); if (rc != RE_OK) return rc; }
                 pre.push_back({ r, 2 }); flag_op(r, F_STATIC, 0);
                 if (stat(r)) { stat(r) = false; if (hide.count(r)) hide.erase(r); else unhide.insert(r); }
                 break;
             default: return c->fail(RE_E_ARG, "re_apply_changes: unknown change kind %u (change %u)", ch.kind, i);
         }
     }
+    if (trans.size() + kin.size() > c->list_cap) return c->fail(RE_E_CAPACITY, "re_apply_changes: %zu moved entities exceed the mover list (%u); split the batch", trans.size() + kin.size(), c->list_cap);
+    if (c->n_ghost + ghosts.size() > c->ghost_cap) return c->fail(RE_E_CAPACITY, "re_apply_changes: more than %u ghost instances of the frozen static cache", c->ghost_cap);
     // ---- the list is valid: from here on the context changes
+    std::set<uint64_t> ghost_touched;
+    if (!ghosts.empty()) {
+        std::vector<Pair32> cl; cl.reserve(ghosts.size());
+        for (auto &g : ghosts) { const uint32_t gr = c->n + c->n_ghost++; cl.push_back(Pair32{ g.first, gr }); c->h_ghost_gc.push_back(c->h_gclass[g.first]); c->ghost_map[g.second].push_back(gr); ghost_touched.insert(g.second); }
+        Pair32 *d = nullptr; HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), cl.size() * sizeof(Pair32)));
+        HIPCHK(c, hipMemcpyAsync(d, cl.data(), cl.size() * sizeof(Pair32), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_clone_rows, dim3(((uint32_t)cl.size() * 4u + 255) / 256), dim3(256), 0, st, (uint32_t)cl.size(), d, c->d_id.p, c->d_mat.p);   // before any component write of this batch
+        HIPCHK(c, hipStreamSynchronize(st)); (void)hipFree(d);
+    }
     if (new_rotvel) c->has_rotvel = true;
     for (auto &kv : flag_ops) c->h_flags[kv.first] = (c->h_flags[kv.first] & (kv.second.first | F_STATIC)) | (kv.second.second & ~F_STATIC);   // the static bit follows the tree replay
     for (uint32_t r : hide) c->h_uncached.insert(r);
@@ -1494,7 +1552,6 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     std::vector<uint32_t> list; list.reserve(trans.size() + kin.size());
     for (uint32_t r : trans) list.push_back(r | 0x80000000u);
     for (uint32_t r : kin) list.push_back(r);
-    if (list.size() > c->list_cap) return c->fail(RE_E_CAPACITY, "re_apply_changes: %zu moved entities exceed the mover list (%u)", list.size(), c->list_cap);
     TickHeader th{};
     if (!ops.empty() || !list.empty()) {
         DevBuf<WriteOp> d_ops; DevBuf<uint32_t> d_list;
@@ -1519,12 +1576,30 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     if (th.n_oob) { int rc = absorb_out_of_bounds(c, th.n_oob); if (rc != RE_OK) return rc; }
     c->n_dead += th.n_oob + (uint32_t)deleted.size();
     c->last_tick = re_tick_result{ th.n_changed, th.n_rebucket, th.n_oob };
-    if (th.n_rebucket || !pre.empty()) {
-        int rc = rebucket(c, th.n_rebucket, &pre);
+    // (Before the tree replay: a section emptied by this very batch must carry the flag into its dormant entry.)
+    // A ghost of a shared section's static member is drawn whenever the section that cached it is -- also when that section's own
+    // static entities were NOT cached (it lay beyond the draw distance when the cache froze: an empty entry plus the shared members).
+    // The ghost sits behind the section's static rows and is emitted with them, so such a section is flagged as cached and its own
+    // static rows are hidden instead: the same picture, and a later wake-up of one of them shows it again like any hidden row.
+    std::vector<uint32_t> newly_hidden;
+    for (uint64_t K : shared_ghost_owners) {
+        const int32_t os = find_slot(c, K);
+        if (os < 0) continue;                                                  // (cannot happen: the owner links the shared section)
+        uint8_t f = 0; HIPCHK(c, hipMemcpy(&f, c->d_cell_flags.p + os, 1, hipMemcpyDeviceToHost));
+        if (f & CF_STATIC_CACHED) continue;
+        f |= CF_STATIC_CACHED; HIPCHK(c, hipMemcpy(c->d_cell_flags.p + os, &f, 1, hipMemcpyHostToDevice));
+        for (uint32_t i = c->h_cell_nl[os], e = c->h_cell_nl[os] + c->h_cell_ns[os], b = c->h_cell_begin[os]; i < e; i++) {
+            const uint32_t r = c->h_rows[b + i];
+            if (c->h_uncached.insert(r).second) { newly_hidden.push_back(r); const uint32_t none = 0xFFFFFFFFu; HIPCHK(c, hipMemcpy(c->d_gclass.p + r, &none, 4, hipMemcpyHostToDevice)); }
+        }
+    }
+    if (th.n_rebucket || !pre.empty() || !ghost_touched.empty()) {
+        int rc = rebucket(c, th.n_rebucket, &pre, &ghost_touched);
         if (rc != RE_OK) return rc;
     }
     {   // rows hidden / shown by this batch that kept their place in the row pool
         std::vector<Pair32> gc;
+        for (uint32_t r : newly_hidden) collect_row_gc(c, r, gc);
         for (uint32_t r : hide) collect_row_gc(c, r, gc);
         for (uint32_t r : unhide) if (!deleted.count(r)) collect_row_gc(c, r, gc);
         int rc = upload_row_gc(c, gc);

@@ -105,7 +105,7 @@ struct ScanCullArgs {                       // the kernel-argument segment of k_
     PBoxTable B; PBox32Table B32;           // read by every wave (one of the two); everything below by candidate waves only
     const uint64_t *cell_key64;             // the full keys (candidate waves; the stream may run over the compact 32-bit keys)
     FrameParams P; FrameParams *P_dev;
-    const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic; const uint8_t *cell_flags; uint32_t *cell_stamp;
+    const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic, *cell_nghost; const uint8_t *cell_flags; uint32_t *cell_stamp;
     ItemSink K; FrameHeader *hdr; SharedArrays S; const SpecState *spec;
 #ifdef RE_EXP_STAMPS
     unsigned long long *timeline;           // development builds: [wave] = {start, keys arrived, end} 100 MHz stamps
@@ -145,6 +145,7 @@ struct Pair32 { uint32_t idx, val; };
 struct Pair64 { uint32_t idx, pad; uint64_t val; };
 struct FlagOp { uint32_t idx; uint8_t and_mask, or_mask, pad[2]; };
 __global__ void k_scatter32(uint32_t m, const Pair32 *pairs, uint32_t *dst);
+__global__ void k_clone_rows(uint32_t m, const Pair32 *src_dst, uint32_t *row_id, float *row_mat);   // ghost instances: (source row, ghost row)
 __global__ void k_scatter64(uint32_t m, const Pair64 *pairs, uint64_t *dst);
 __global__ void k_flag_ops(uint32_t m, const FlagOp *ops, uint8_t *flags);
 __global__ void k_fold_tight_list(uint32_t m, const uint32_t *slots, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,

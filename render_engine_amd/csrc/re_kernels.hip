@@ -390,7 +390,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
             const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
             const FrameParams &P = R.P;
             const ItemSink K = R.K; FrameHeader *hdr = R.hdr;
-            const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic;
+            const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic, *__restrict__ cell_nghost = R.cell_nghost;
             const uint8_t *__restrict__ cell_flags = R.cell_flags; uint32_t *__restrict__ cell_stamp = R.cell_stamp;
             if (lv0 < P.max_level && !R.spec->stale) {                       // (a stale tree cancels the frame: see SpecState)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
                             const uint32_t e = q_idx[on ? i : 0u], c = e & 0x3FFFFFFFu, mult = e >> 30;
                             const uint8_t f = cell_flags[c];
                             const Aabb t = cell_tight[c];
-                            const uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c], cb = cell_begin[c];
+                            const uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c] + cell_nghost[c], cb = cell_begin[c];   // ghosts: snapshot copies the cached data still holds, stored behind the static rows
                             if (on && !(f & CF_PAD)) {
                                 cell_stamp[c] = (P.frame << 2) | mult;
                                 vis_map_acc += 1; vis_vec_acc += mult;
@@ -739,6 +739,10 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
         }
     }
     if (blockIdx.x == 0) {
+        // the host polls done_frame while this kernel runs: every wave's InstanceRange stores must have left for host memory before
+        // lane 0 publishes it (a workgroup barrier alone does not wait for the other waves' stores in flight)
+        __threadfence_system();
+        __syncthreads();
         if (wid == 0) {
             FrameCounts fc = load_frame_counts(hdr);
             if (lane == 0) {
@@ -1041,6 +1045,15 @@ __global__ __launch_bounds__(256) void k_fold_tight_masked(uint32_t ncells, cons
 }
 
 // ---- incremental patches of the resident section table (re-bucket of movers, host-assisted bookkeeping) ----
+// A ghost instance: the id and the 64 matrix bytes the reference's static render cache still holds for an entity that has since been
+// woken, deleted or rewritten (render_flow.rs:549-594 is a snapshot; pipeline.rs:271 keeps the logic phase from refreshing it).
+__global__ __launch_bounds__(256) void k_clone_rows(uint32_t m, const Pair32 *__restrict__ src_dst, uint32_t *__restrict__ row_id, float *__restrict__ row_mat) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * 4u) return;
+    const Pair32 p = src_dst[i >> 2];
+    reinterpret_cast<float4 *>(row_mat + (size_t)p.val * 16)[i & 3u] = reinterpret_cast<const float4 *>(row_mat + (size_t)p.idx * 16)[i & 3u];
+    if ((i & 3u) == 0) row_id[p.val] = row_id[p.idx];
+}
 __global__ __launch_bounds__(256) void k_scatter32(uint32_t m, const Pair32 *__restrict__ pairs, uint32_t *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) dst[pairs[i].idx] = pairs[i].val;

@@ -34,8 +34,12 @@ def assert_render_equal(gpu, cpu):
     gr = np.sort(gpu["groups"], order="begin")
     assert int(gr["begin"][0]) == 0 if len(gr) else True
     assert np.all(gr["begin"][1:] == gr["begin"][:-1] + gr["count"][:-1])
-    # matrices: bit-exact per instance (instances of one entity carry the same matrix)
-    og = np.argsort(gpu["ids"], kind="stable"); oc = np.argsort(cpu["ids"], kind="stable")
+    # matrices: bit-exact per instance.  An entity can appear more than once with different bytes (a ghost of the frozen static cache
+    # next to the live entity), so instances are ordered by (id, matrix bits) on both sides.
+    def order(ids, mats):
+        bits = np.ascontiguousarray(mats, np.float32).view(np.uint32).reshape(len(ids), 16)
+        return np.lexsort(tuple(bits[:, k] for k in range(15, -1, -1)) + (ids,))
+    og, oc = order(gpu["ids"], gpu["mats"]), order(cpu["ids"], cpu["mats"])
     np.testing.assert_array_equal(gpu["ids"][og], cpu["ids"][oc])
     np.testing.assert_array_equal(gpu["mats"][og], cpu["mats"][oc])
 

@@ -229,7 +229,8 @@ def test_truncation_reports(R):
 
 def random_changes(R, ents, rng, n, frozen, centre=(8192.0, 8192.0, 8192.0)):
     """a batch of user-logic change requests touching every kind and component.  `frozen`: ids of entities that were static when
-    the static render cache froze (first render): only MakeObjectStatic may name them (see re_apply_changes)."""
+    the static render cache froze (first render) that the batch must leave alone apart from MakeObjectStatic (empty: none -- waking,
+    moving or deleting them leaves ghost instances in the cache, see re_apply_changes)."""
     C = R._capi
     ch = np.zeros(n, R.CHANGE_DT)
     ids = ents["id"]; fl = ents["flags"]
@@ -266,7 +267,7 @@ def test_apply_changes_parity(R):
     rng = np.random.default_rng(5)
     cams = [R.Camera((8192 + 40 * i, 8192, 8500 - 30 * i), (0.05 * i, 0, -1), 1200.0) for i in range(5)]
     alive = ents
-    frozen = set(int(i) for i in ents["id"][(ents["flags"] & R.F_STATIC) != 0])
+    frozen = set()                                           # static entities of the frozen cache are fair game: ghost instances
     for f, cam in enumerate(cams):
         check_frame(R, p, w, cam, f % 2 == 1)
         n_o, oob_o = w.tick(oracle_camera(cam), 0.016)
@@ -285,11 +286,56 @@ def test_apply_changes_parity(R):
         check_sections(p, w)
         check_entities(R, p, w, ents)
     check_frame(R, p, w, cams[0], True)
-    # a static entity of the frozen cache cannot be woken, moved or deleted (ghost instances are not modelled): refused, state untouched
-    bad = np.zeros(1, R.CHANGE_DT); bad[0] = (R._capi.CHANGE_WAKE_UP, sorted(frozen)[0], 0, 0, (0, 0, 0, 0))
-    with pytest.raises(R.RenderEngineError):
-        p.apply_changes(bad)
     check_frame(R, p, w, cams[1], False)
+    p.close(); w.close()
+
+
+def test_frozen_static_cache_ghosts(R):
+    """the static render cache is a snapshot taken at the first render (render_flow.rs:549-594; pipeline.rs:271 clears the
+    changed set): a cached static entity that is deleted, woken or moved stays in the picture with its old matrix; the section that
+    cached it keeps drawing it after being emptied and re-created; an entity made static later is not drawn at all"""
+    C = R._capi
+    ents = R.synthetic.lattice_world(cells_per_axis=10, first_cell=124, straddler_fraction=0.05)
+    p, w = build_pair(R, ents)
+    cam = R.Camera((8192 + 120, 8192 + 100, 8192 + 900), (0, 0, -1), 2500.0)
+    g0, _ = check_frame(R, p, w, cam, False)                   # the freeze
+    assert g0["total"] > 500
+    def frame(dups=False):
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.016); t = p.tick(0.016)
+        assert t["n_changed"] == n_o
+        return check_frame(R, p, w, cam, dups)[0]
+    def apply(rows):
+        ch = np.zeros(len(rows), R.CHANGE_DT)
+        for i, r in enumerate(rows): ch[i] = r
+        n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT)); g = p.apply_changes(ch)
+        assert g["n_changed"] == n_a and g["n_out_of_bounds"] == len(oob_a)
+        check_sections(p, w)
+    drawn = sorted(int(i) for i in g0["ids"][:g0["total"]])
+    dele, woke, moved, mover = drawn[0:20], drawn[20:40], drawn[40:60], drawn[60:70]
+    # 1. delete / wake up / move away (the sections of `moved` become empty and disappear)
+    apply([(C.CHANGE_DELETE, i, 0, 0, (0, 0, 0, 0)) for i in dele] + [(C.CHANGE_WAKE_UP, i, 0, 0, (0, 0, 0, 0)) for i in woke]
+          + [(C.CHANGE_MODIFY, i, C.C_POSITION, 0, (8192.0 + 3 * k, 8192.0, 9500.0, 0)) for k, i in enumerate(moved)])
+    g1 = frame()
+    ids1 = g1["ids"][:g1["total"]].tolist()
+    assert all(ids1.count(i) <= 1 for i in dele)                # deleted: at most the ghost (none where the delete emptied the section: no section, no cache lookup)
+    assert all(ids1.count(i) == 2 for i in woke)                # woken: the ghost and the live active entity
+    # 2. other entities move into the emptied sections: those sections exist again and their cache entries (the ghosts) show again
+    home = {int(e["id"]): e["pos"] for e in ents[np.isin(ents["id"], moved)]}
+    apply([(C.CHANGE_WAKE_UP, i, 0, 0, (0, 0, 0, 0)) for i in mover]
+          + [(C.CHANGE_MODIFY, i, C.C_POSITION, 0, tuple(home[moved[k]]) + (0,)) for k, i in enumerate(mover)])
+    g2 = frame(True)
+    ids2 = g2["ids"][:g2["total"]].tolist()
+    assert sum(ids2.count(i) >= 1 for i in moved[:len(mover)]) >= 7     # (a straddler among them was cached by another section)
+    # 3. back to static: never drawn live again (hidden rows), the ghosts stay
+    apply([(C.CHANGE_MAKE_STATIC, i, 0, 0, (0, 0, 0, 0)) for i in woke + mover])
+    g3 = frame()
+    ids3 = g3["ids"][:g3["total"]].tolist()
+    assert all(ids3.count(i) == 1 for i in woke)
+    # 4. and awake once more, rotated and scaled
+    apply([(C.CHANGE_WAKE_UP, i, 0, 0, (0, 0, 0, 0)) for i in woke[:10]] + [(C.CHANGE_MODIFY, i, C.C_SCALE, 0, (2.0, 2.0, 2.0, 0)) for i in woke[:10]]
+          + [(C.CHANGE_MODIFY, i, C.C_ROTATION, 0, (0.0, 1.0, 0.0, 0.7)) for i in dele[:5] + woke[5:15]])
+    for dups in (False, True): frame(dups)
+    check_entities(R, p, w, ents[::7])
     p.close(); w.close()
 
 
@@ -349,7 +395,7 @@ def test_soak_random_frames(R, seed, atomic, tight):
     ents["vel"] *= 8.0
     # atomic 16: more than 512 sections per axis -> full 64-bit stream keys; tight: hardly any slack -> patches and full rebuilds alternate
     p, w = build_pair(R, ents, atomic=atomic, flags=R._capi.CFG_TIGHT_SLACK if tight else 0)
-    frozen = set(int(i) for i in ents["id"][(ents["flags"] & R.F_STATIC) != 0])
+    frozen = set()
     cam = R.Camera((8192, 8192, 8500), (0, 0, -1), 1000.0)
     for f in range(48):
         pos = (8192 + rng.uniform(-300, 300), 8192 + rng.uniform(-200, 200), 8192 + rng.uniform(-100, 500))
