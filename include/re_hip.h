@@ -60,6 +60,8 @@ extern "C" {
 #define RE_F_USER        0x800u  /* the user entity (flows/pipeline.rs:125-151): TransformationMatrix stays identity, StaticAABB = OriginalAABB
                                    * translated by Position; added to the tree as a non-static entity */
 
+#define RE_F_CAN_COLLIDE 0x1000u /* CanCauseCollisions (EntityTransformationBuilder.can_cause_collision, exports/entity_transformer.rs:66-69) */
+
 typedef struct re_ctx re_ctx;
 
 typedef struct {
@@ -213,6 +215,23 @@ typedef struct re_change { uint32_t kind, entity_id, component, reserved; float 
 /* out: n_changed = entities whose matrix/AABB were recomputed, n_rebucket = of those, entities that changed section,
  * n_out_of_bounds = entities removed because they left the world */
 int re_apply_changes(re_ctx *ctx, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out /*nullable*/);
+
+/* Collision broad phase of the frame == LogicFlow::handle_collisions (flows/logic_flow.rs:452-651) up to the collision-logic
+ * callbacks: which (this_entity, other_entity) pairs the reference would hand to the CollisionFunction of this_entity's type.
+ * Call order of a frame as in LogicFlow::execute (:230-244): re_cull_pack, re_collide, re_tick -- the tests read this frame's
+ * StaticAABBs (update_positions only queues the kinematic changes).
+ *   moved entities  = the entities the tick of this frame processes that carry Velocity or VelocityRotation and
+ *                     RE_F_CAN_COLLIDE (once per listing of their world section in visible_sections_vec), plus the RE_F_USER entity;
+ *   per world section holding one: the sections related to it (BoundingBoxTree::find_related_entities,
+ *                     bounding_box_tree_v2.rs:950-1048: ancestors and descendants, transitively) whose AABB is within 200 units
+ *                     of the camera, and their shared sections within 200 units;
+ *   AABB overlap (closed intervals) of the moved entity with the non-static entities of those sections / all entities of those
+ *                     shared sections: (moved, other), and (other, moved) too when other is not itself a moved entity.
+ * The pairs come in no particular order (the reference's order depends on thread timing); as a multiset they equal the reference
+ * with moved_entities taken in ascending EntityId (that order decides which entity the Shared arm of :488-498 drops).
+ * *n_total = number of invocations; the first `capacity` are written to `pairs` (host memory). */
+typedef struct { uint32_t this_entity, other_entity; } re_collision;
+int re_collide(re_ctx *ctx, uint32_t flags /*0*/, re_collision *pairs, uint32_t capacity, uint32_t *n_total);
 
 /* ECS read-back for user logic (LogicFunction reads components through &ECS, exports/logic_components.rs:15-18) */
 int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst);

@@ -16,6 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "libre_oracle.so")
 F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
 F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
+F_CAN_COLLIDE = 0x1000
 
 AABB_DT = np.dtype([("xmin", "f4"), ("xmax", "f4"), ("ymin", "f4"), ("ymax", "f4"), ("zmin", "f4"), ("zmax", "f4")])
 ENTITY_DT = np.dtype([
@@ -129,6 +130,10 @@ def lib():
     L.ro_frame_tick.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_float, C.c_uint32, C.c_void_p, u32p]
     L.ro_apply_changes.restype = C.c_uint32
     L.ro_apply_changes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p]
+    L.ro_frame_collide.restype = C.c_uint32; L.ro_frame_collide.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
+    L.ro_related_sections.restype = C.c_uint32; L.ro_related_sections.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.ro_find_related.restype = C.c_uint32
+    L.ro_find_related.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, u32p, C.c_uint32, C.c_void_p, u32p]
     _lib = L
     return L
 
@@ -309,6 +314,29 @@ class World:
         oob = np.zeros(cap, np.uint32); noob = C.c_uint32()
         n = self.L.ro_apply_changes(self.h, ch.ctypes.data, len(ch), 1 if end_of_frame else 0, cap, oob.ctypes.data, C.byref(noob))
         return n, oob[:min(noob.value, cap)].copy()
+
+    def collide(self, cam, cap=None):
+        """handle_collisions of this frame (after cull, before tick): array [n, 2] of (this_entity, other_entity) invocations"""
+        if cap is None:
+            cap = self.L.ro_frame_collide(self.h, C.byref(cam), 0, None)
+        pairs = np.zeros((max(cap, 1), 2), np.uint32)
+        n = self.L.ro_frame_collide(self.h, C.byref(cam), cap, pairs.ctypes.data)
+        return pairs[:min(n, cap)].copy()
+
+    def related_sections(self, key):
+        n = self.L.ro_related_sections(self.h, int(key), 0, None)
+        out = np.zeros(max(n, 1), np.uint64)
+        self.L.ro_related_sections(self.h, int(key), n, out.ctypes.data)
+        return sorted(int(k) for k in out[:n])
+
+    def find_related(self, key, cap=4096):
+        """(unique section keys, [shared section key tuples]) of find_related_entities([key])"""
+        uk = np.zeros(cap, np.uint64); sk = np.zeros(cap * 9, np.uint64); nu, ns = C.c_uint32(), C.c_uint32()
+        self.L.ro_find_related(self.h, int(key), cap, uk.ctypes.data, C.byref(nu), cap * 9, sk.ctypes.data, C.byref(ns))
+        shared, o = [], 0
+        for _ in range(ns.value):
+            nk = int(sk[o]); shared.append(tuple(int(k) for k in sk[o + 1:o + 1 + nk])); o += 1 + nk
+        return [int(k) for k in uk[:nu.value]], shared
 
     def tick(self, cam, dt, cap=4096):
         oob = np.zeros(cap, np.uint32); noob = C.c_uint32()

@@ -1307,6 +1307,168 @@ uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt, uint32_t cap
     return napplied;
 }
 
+/* =======================================================================================
+ * Collision broad phase: LogicFlow::handle_collisions (flows/logic_flow.rs:452-651) over
+ * BoundingBoxTree::find_related_entities (bounding_box_tree_v2.rs:950-1048)
+ * ======================================================================================= */
+/* a strictly above d: parent = level + 1, index / 2 (UniqueWorldSectionId::higher_level_world_section :46-64) */
+static int key_is_ancestor(uint64_t a, uint64_t d) {
+    uint32_t la = KEY_LEVEL(a), ld = KEY_LEVEL(d);
+    if (la <= ld || la - ld > 16) return 0;
+    uint32_t s = la - ld;
+    return (KEY_X(d) >> s) == KEY_X(a) && (KEY_Z(d) >> s) == KEY_Z(a) && (KEY_Y(d) >> s) == KEY_Y(a);
+}
+/* related_world_sections[key] (:334): register_created_section_with_others (:1219-1296) links a created section with every
+ * existing child section (all levels below) and every existing parent section (all levels above), both ways; removing a
+ * section unlinks both ways (:925-936).  So the list of a section is: the existing sections that are its ancestors or
+ * descendants.  Stated by that definition (the reference walks 8^level child ids per creation). */
+uint32_t ro_related_sections(const ro_world *w, uint64_t key, uint32_t cap, uint64_t *out) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < w->ncells_alloc; i++) {
+        const cell_t *c = &w->cells[i];
+        if (!c->used) continue;
+        if (key_is_ancestor(c->key, key) || key_is_ancestor(key, c->key)) { if (n < cap && out) out[n] = c->key; n++; }
+    }
+    return n;
+}
+typedef struct { int32_t *cells; uint32_t ncells; int32_t *shared; uint32_t nshared; } related_t;
+/* find_related_entities_internal (:966-1048): worklist over related_world_sections with a processed set; every section popped
+ * contributes its local_entities, and each of its shared sections once (both branches of the in-view test push the same result) */
+static void find_related(const ro_world *w, uint64_t start, related_t *r, uint8_t *cell_seen, uint8_t *shared_seen) {
+    uint64_t *stack = (uint64_t *)malloc(sizeof(uint64_t) * 64); uint32_t sn = 0, scap = 64;
+    r->ncells = r->nshared = 0;
+    stack[sn++] = start;
+    uint64_t *rel = (uint64_t *)malloc(sizeof(uint64_t) * ((size_t)w->ncells_live + 1));
+    while (sn) {
+        uint64_t x = stack[--sn];
+        int32_t ci = cell_find(w, x);
+        if (ci < 0 || cell_seen[ci]) continue;                            /* processed_world_sections.insert (:980-983) */
+        cell_seen[ci] = 1; r->cells[r->ncells++] = ci;
+        const cell_t *cell = &w->cells[ci];
+        for (uint32_t k = 0; k < cell->shared.n; k++) {
+            int32_t si = (int32_t)cell->shared.v[k];
+            if (shared_seen[si]) continue;                                /* processed_shared_sections (:1003) */
+            shared_seen[si] = 1; r->shared[r->nshared++] = si;
+        }
+        uint32_t nr = ro_related_sections(w, x, w->ncells_live, rel);     /* :1044 */
+        for (uint32_t k = 0; k < nr; k++) { if (sn == scap) { scap *= 2; stack = (uint64_t *)realloc(stack, sizeof(uint64_t) * scap); } stack[sn++] = rel[k]; }
+    }
+    for (uint32_t i = 0; i < r->ncells; i++) cell_seen[r->cells[i]] = 0;
+    for (uint32_t i = 0; i < r->nshared; i++) shared_seen[r->shared[i]] = 0;
+    free(stack); free(rel);
+}
+/* the find_related_entities of one section, for the known-answer test of the reference (:2220-2303): unique section keys, then
+ * for every shared section its number of keys followed by the keys */
+uint32_t ro_find_related(const ro_world *w, uint64_t key, uint32_t cap, uint64_t *unique_keys, uint32_t *n_unique, uint32_t shared_cap, uint64_t *shared_keys, uint32_t *n_shared) {
+    related_t r; r.cells = (int32_t *)malloc(sizeof(int32_t) * (w->ncells_alloc + 1)); r.shared = (int32_t *)malloc(sizeof(int32_t) * (w->nshared_alloc + 1));
+    uint8_t *cs = (uint8_t *)calloc(w->ncells_alloc + 1, 1), *ss = (uint8_t *)calloc(w->nshared_alloc + 1, 1);
+    find_related(w, key, &r, cs, ss);
+    for (uint32_t i = 0; i < r.ncells && i < cap; i++) unique_keys[i] = w->cells[r.cells[i]].key;
+    uint32_t o = 0;
+    for (uint32_t i = 0; i < r.nshared; i++) {
+        const shared_t *sh = &w->shared[r.shared[i]];
+        if (o + 9 > shared_cap) break;
+        shared_keys[o++] = (uint64_t)sh->nkeys;
+        for (int k = 0; k < sh->nkeys; k++) shared_keys[o++] = sh->keys[k];
+    }
+    *n_unique = r.ncells; *n_shared = r.nshared;
+    free(r.cells); free(r.shared); free(cs); free(ss);
+    return r.ncells + r.nshared;
+}
+static int aabb_intersect(ro_aabb a, ro_aabb b) {                         /* StaticAABB::intersect (aabb.rs:68-73), closed intervals (range.rs:71) */
+    return a.xmin <= b.xmax && a.xmax >= b.xmin && a.ymin <= b.ymax && a.ymax >= b.ymin && a.zmin <= b.zmax && a.zmax >= b.zmin;
+}
+typedef struct { uint64_t key; u32vec moved; } relevant_t;
+/* One handle_collisions pass with the state of this frame (after ro_frame_cull, BEFORE ro_frame_tick applies the kinematic
+ * changes: update_positions only queues them, so the collision tests read this frame's StaticAABBs, logic_flow.rs:230,243).
+ * Output: the (this_entity, other_entity) arguments of every collision-logic invocation (apply_collision_only_to_self), as a
+ * multiset -- the reference's order depends on thread timing.  The one place where that order changes the RESULT is the
+ * Shared arm of the section map (:488-498): the moved entity that creates a section's entry through a Shared lookup is not
+ * pushed into it.  moved_entities is taken in ascending EntityId (a section listed twice in visible_sections_vec pushes its
+ * entities twice, in a row), the user entity last (:236-240), which fixes that choice.
+ * Returns the total number of invocations; the first cap are written to pairs (2 ids each). */
+uint32_t ro_frame_collide(ro_world *w, const ro_camera *cam, uint32_t cap, uint32_t *pairs) {
+    u32vec moved = { 0 };
+    int32_t user = -1;
+    /* update_positions (:308-358): apply_kinematics pushes every processed entity that carries Velocity or VelocityRotation
+     * (entity_moved is set by the component's presence, :380-441) and CanCauseCollisions (:443-446) */
+#define MOVES(e) ((e)->alive && ((e)->flags & (RO_F_HAS_VEL | RO_F_HAS_ROTVEL)) && ((e)->flags & RO_F_CAN_COLLIDE))
+    uint32_t pass = ++w->pass_id;
+    for (uint32_t i = 0; i < w->vis_n; i++) {                              /* active_world_sections keeps the duplicates of the vec (:216-223) */
+        int32_t ci = cell_find(w, w->vis_vec[i]);
+        if (ci < 0 || w->cells[ci].is_static_section) continue;
+        const cell_t *cell = &w->cells[ci];
+        for (uint32_t k = 0; k < cell->local.n; k++) if (MOVES(&w->ents[cell->local.v[k]])) u32vec_push(&moved, cell->local.v[k]);
+        for (uint32_t s = 0; s < cell->shared.n; s++) {
+            shared_t *sh = &w->shared[cell->shared.v[s]];
+            if (sh->stamp == pass) continue;
+            sh->stamp = pass;
+            if (ro_logic_aabb_in_view(w->lookahead, w->campos, sh->aabb) || ro_frustum_aabb_visible(w->planes, sh->aabb))
+                for (uint32_t k = 0; k < sh->ents.n; k++) if (MOVES(&w->ents[sh->ents.v[k]])) u32vec_push(&moved, sh->ents.v[k]);
+        }
+    }
+    for (uint32_t i = 0; i < w->always_exec.n; i++) {                      /* always_execute_entities (:357, 803-836) */
+        uint32_t id = w->always_exec.v[i];
+        const ent_t *e = &w->ents[id];
+        if (!e->alive || !(e->flags & RO_F_ALWAYS_EXEC) || e->lookup == 0) continue;
+        int seen = 0;
+        if (e->lookup == 1) seen = u64set_has(&w->vis_map, e->ukey);
+        else { const shared_t *sh = &w->shared[e->shared]; for (int k = 0; k < sh->nkeys && !seen; k++) seen = u64set_has(&w->vis_map, sh->keys[k]); }
+        if (!seen && MOVES(e)) u32vec_push(&moved, id);
+    }
+    if (moved.n) qsort(moved.v, moved.n, sizeof(uint32_t), cmp_u32);
+    for (uint32_t id = 0; id < w->ents_cap; id++) if (w->ents[id].alive && (w->ents[id].flags & RO_F_USER)) { user = (int32_t)id; break; }
+    if (user >= 0) u32vec_push(&moved, (uint32_t)user);                    /* UserAlwaysCausesCollisions (pipeline.rs:136, logic_flow.rs:236-240) */
+    uint8_t *is_moved = (uint8_t *)calloc(w->ents_cap + 1, 1);            /* moved_entities_map (:476) */
+    for (uint32_t i = 0; i < moved.n; i++) is_moved[moved.v[i]] = 1;
+    /* relevant_world_sections (:479-514), entries in creation order */
+    relevant_t *rel = NULL; uint32_t nrel = 0, rel_cap = 0; kmap relmap; km_init(&relmap, 256);
+    for (uint32_t i = 0; i < moved.n; i++) {
+        const ent_t *e = &w->ents[moved.v[i]];
+        uint64_t keys[8]; int nk = 0, is_shared = e->lookup == 2;
+        if (e->lookup == 1) { keys[0] = e->ukey; nk = 1; }
+        else if (e->lookup == 2) { const shared_t *sh = &w->shared[e->shared]; nk = sh->nkeys; memcpy(keys, sh->keys, sizeof(uint64_t) * (size_t)nk); }
+        for (int k = 0; k < nk; k++) {
+            int32_t ri = km_get(&relmap, keys[k]);
+            if (ri >= 0) { u32vec_push(&rel[ri].moved, moved.v[i]); continue; }
+            if (nrel == rel_cap) { rel_cap = rel_cap ? rel_cap * 2 : 64; rel = (relevant_t *)realloc(rel, rel_cap * sizeof(relevant_t)); }
+            memset(&rel[nrel], 0, sizeof(relevant_t)); rel[nrel].key = keys[k];
+            if (!is_shared) u32vec_push(&rel[nrel].moved, moved.v[i]);    /* Unique: vec![*entity] (:509); Shared: Vec::new() (:494) */
+            km_put(&relmap, keys[k], (int32_t)nrel++);
+        }
+    }
+    related_t r; r.cells = (int32_t *)malloc(sizeof(int32_t) * (w->ncells_alloc + 1)); r.shared = (int32_t *)malloc(sizeof(int32_t) * (w->nshared_alloc + 1));
+    uint8_t *cs = (uint8_t *)calloc(w->ncells_alloc + 1, 1), *ss = (uint8_t *)calloc(w->nshared_alloc + 1, 1);
+    u32vec self = { 0 }, both = { 0 };
+    uint32_t total = 0;
+#define EMIT(a, b) do { if (total < cap && pairs) { pairs[2 * total] = (a); pairs[2 * total + 1] = (b); } total++; } while (0)
+    for (uint32_t ri = 0; ri < nrel; ri++) {
+        find_related(w, rel[ri].key, &r, cs, ss);                          /* :546 */
+        self.n = both.n = 0;
+        for (uint32_t i = 0; i < r.ncells; i++) {
+            const cell_t *c = &w->cells[r.cells[i]];
+            if (ro_distance_to_aabb(c->aabb, cam->pos) > 200.0f) continue;  /* :553-558 */
+            for (uint32_t k = 0; k < c->local.n; k++) { uint32_t o = c->local.v[k]; if (!w->ents[o].alive) continue; u32vec_push(is_moved[o] ? &self : &both, o); }
+        }
+        for (uint32_t i = 0; i < r.nshared; i++) {
+            const shared_t *sh = &w->shared[r.shared[i]];
+            if (ro_distance_to_aabb(sh->aabb, cam->pos) > 200.0f) continue; /* :561-566 */
+            for (uint32_t k = 0; k < sh->ents.n; k++) { uint32_t o = sh->ents.v[k]; if (!w->ents[o].alive) continue; u32vec_push(is_moved[o] ? &self : &both, o); }
+        }
+        for (uint32_t m = 0; m < rel[ri].moved.n; m++) {                   /* collision_fn (:619-650) */
+            uint32_t me = rel[ri].moved.v[m];
+            ro_aabb a = w->ents[me].aabb;
+            for (uint32_t k = 0; k < self.n; k++) { if (self.v[k] == me) continue; if (aabb_intersect(a, w->ents[self.v[k]].aabb)) EMIT(me, self.v[k]); }
+            for (uint32_t k = 0; k < both.n; k++) if (aabb_intersect(a, w->ents[both.v[k]].aabb)) { EMIT(me, both.v[k]); EMIT(both.v[k], me); }
+        }
+    }
+#undef EMIT
+#undef MOVES
+    for (uint32_t ri = 0; ri < nrel; ri++) free(rel[ri].moved.v);
+    free(rel); km_free(&relmap); free(r.cells); free(r.shared); free(cs); free(ss); free(self.v); free(both.v); free(moved.v); free(is_moved);
+    return total;
+}
+
 /* apply_change (helper_things/entity_change_helpers.rs:32-189) for the change kinds that touch this path, in list order:
  * ModifyRequest of one component (apply_entity_change_requests :276-323; a request of several components is the same as its
  * components one after another: the classification only accumulates), DeleteRequest (:156-172), MakeObjectStatic (:112-122),

@@ -54,6 +54,7 @@ typedef struct { float xmin, xmax, ymin, ymax, zmin, zmax; } ro_aabb;
 #define RO_F_HAS_MOVED   0x200u  /* HasMoved marker (output) */
 #define RO_F_USER        0x800u  /* the user entity (flows/pipeline.rs:125-144): identity TransformationMatrix, StaticAABB = OriginalAABB translated */
 #define RO_F_HAS_ROTATED 0x400u  /* HasRotated marker (output) */
+#define RO_F_CAN_COLLIDE 0x1000u /* CanCauseCollisions (EntityTransformationBuilder.can_cause_collision, entity_transformer.rs:66-69) */
 
 /* One entity as EntityTransformationBuilder would be filled (exports/entity_transformer.rs:12-29) */
 typedef struct {
@@ -167,6 +168,14 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
  * requests were applied; oob_ids (cap) receives entities rejected by add_entity. */
 uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt,
                        uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
+/* collision broad phase (logic_flow.rs:452-651): call after ro_frame_cull and before ro_frame_tick of the same frame.
+ * Returns the number of collision-logic invocations; the first cap (this_entity, other_entity) pairs go to pairs. */
+uint32_t ro_frame_collide(ro_world *w, const ro_camera *cam, uint32_t cap, uint32_t *pairs);
+/* related_world_sections[key] (bounding_box_tree_v2.rs:334): the existing ancestor and descendant sections */
+uint32_t ro_related_sections(const ro_world *w, uint64_t key, uint32_t cap, uint64_t *out);
+/* find_related_entities of one section (:950-1048): unique section keys; shared sections as {nkeys, keys...} records */
+uint32_t ro_find_related(const ro_world *w, uint64_t key, uint32_t cap, uint64_t *unique_keys, uint32_t *n_unique,
+                         uint32_t shared_cap, uint64_t *shared_keys, uint32_t *n_shared);
 
 /* FrameChange::EntityChange entries that touch this path (objects/entity_change_request.rs; applied by
  * helper_things/entity_change_helpers.rs:32-189).  component: 0 Position, 1 Rotation(axis,angle), 2 Scale, 3 Velocity,

@@ -9,6 +9,7 @@ RE_OK = 0
 F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
 F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
+F_CAN_COLLIDE = 0x1000
 CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK = 0x1, 0x2, 0x4
 TICK_ALL_DYNAMIC, TICK_ASYNC = 0x1, 0x2
 (C_POSITION, C_ROTATION, C_SCALE, C_VELOCITY, C_ACCELERATION, C_ROTATION_VEL, C_ROTATION_ACC,
@@ -74,7 +75,7 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_collide", "re_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
@@ -106,6 +107,7 @@ def load():
     L.re_cull_pack.restype = C.c_int; L.re_cull_pack.argtypes = [vp, C.POINTER(CameraC), C.c_uint32, C.POINTER(Visible)]
     L.re_tick.restype = C.c_int; L.re_tick.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(TickResult)]
     L.re_wait.restype = C.c_int; L.re_wait.argtypes = [vp, C.POINTER(Visible), C.POINTER(TickResult)]
+    L.re_collide.restype = C.c_int; L.re_collide.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.re_apply_changes.restype = C.c_int; L.re_apply_changes.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(TickResult)]
     L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]
     L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]

@@ -107,6 +107,9 @@ struct re_ctx {
     // ghost instances (snapshot copies of the frozen static render cache): rows n .. n + n_ghost of the id / matrix columns
     uint32_t ghost_cap = 0, n_ghost = 0; std::vector<uint32_t> h_ghost_gc; std::map<uint64_t, std::vector<uint32_t>> ghost_map;   // per section key: its ghost rows
     DevBuf<uint32_t> d_cell_nghost; std::vector<uint32_t> h_cell_ng;
+    // collision broad phase (re_collide): lists allocated at the first call
+    uint32_t user_row = ROW_CELL_NONE; DevBuf<ColHeader> d_col_hdr; DevBuf<ColRegion> d_col_region; DevBuf<uint32_t> d_col_high; DevBuf<ColShared> d_col_shared; DevBuf<ColMoved> d_col_moved;
+    DevBuf<uint8_t> d_row_moved; DevBuf<unsigned long long> d_col_tab; DevBuf<uint2> d_col_pairs; uint32_t col_moved_cap = 0, col_tab_size = 0, col_pair_cap = 0; float t_collide = 0.f;
     std::set<uint64_t> dormant_cached;                  // sections with ghosts that were cached when they were emptied: the reference's cache entry outlives the section and shows again when the section is re-created
     std::set<uint32_t> h_uncached;                       // rows made static after the static render cache froze: in the tree's static sets, not drawn
     // groups
@@ -528,6 +531,8 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
         for (uint32_t r = 1; r < n; r++) if (c->id_rows[r].first == c->id_rows[r - 1].first) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity id %u", c->id_rows[r].first);
     }
     c->h_flags = flags; c->h_dyn_row = dyn_row; c->has_rotvel = false;
+    c->user_row = ROW_CELL_NONE; for (uint32_t r = 0; r < n; r++) if (flags[r] & F_USER) { c->user_row = r; break; }
+    c->d_row_moved.release(nullptr); c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->col_moved_cap = 0;
     for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
     c->ndyn = (uint32_t)dyn_row.size();
     c->ngclass = (uint32_t)gkeys.size(); c->nslots = c->ngclass * 8u;
@@ -1611,6 +1616,65 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
         c->dirty_pending = false;
     }
     if (out) *out = c->last_tick;
+    return RE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// re_collide == LogicFlow::handle_collisions (flows/logic_flow.rs:452-651): the broad phase and the AABB tests; the collision
+// logic of the entity types (CollisionFunction callbacks) stays with the caller, which gets the argument pairs.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t COL_REGION_CAP = 1u << 16, COL_SHARED_CAP = 1u << 14;
+extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32_t capacity, uint32_t *n_total) {
+    (void)flags;
+    if (!c) return RE_E_ARG;
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_collide: no world uploaded");
+    if (!c->have_cull) return c->fail(RE_E_STATE, "re_collide: the collision pass works on the visibility query of the frame; call re_cull_pack first");
+    if (capacity && !pairs) return c->fail(RE_E_ARG, "re_collide: capacity without a buffer");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc = c->cull_inflight ? finish_cull(c, nullptr) : resolve(c); if (rc != RE_OK) return rc; }
+    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    hipStream_t st = c->stream;
+    if (!c->d_col_hdr.p) {
+        HIPCHK(c, c->d_col_hdr.alloc(1, nullptr)); HIPCHK(c, c->d_col_region.alloc(COL_REGION_CAP, nullptr)); HIPCHK(c, c->d_col_high.alloc(COL_REGION_CAP, nullptr));
+        HIPCHK(c, c->d_col_shared.alloc(COL_SHARED_CAP, nullptr));
+    }
+    if (!c->col_moved_cap) {
+        c->col_moved_cap = (uint32_t)std::min<uint64_t>(((uint64_t)c->ndyn + 1u) * 8u, 1u << 20);
+        c->col_tab_size = 64; while (c->col_tab_size < 2u * c->col_moved_cap) c->col_tab_size <<= 1;
+        HIPCHK(c, c->d_col_moved.alloc(c->col_moved_cap, nullptr)); HIPCHK(c, c->d_col_tab.alloc((size_t)c->col_tab_size * 2, nullptr)); HIPCHK(c, c->d_row_moved.alloc(std::max(c->n, 1u), nullptr));
+    }
+    const uint32_t want = std::max(capacity, 1u << 12);
+    if (want > c->col_pair_cap) { c->d_col_pairs.release(nullptr); HIPCHK(c, c->d_col_pairs.alloc(want, nullptr)); c->col_pair_cap = want; }
+    hipEvent_t e0 = c->ev[3], e1 = c->ev[4];
+    HIPCHK(c, hipEventRecord(e0, st));
+    HIPCHK(c, hipMemsetAsync(c->d_col_hdr.p, 0, sizeof(ColHeader), st));
+    HIPCHK(c, hipMemsetAsync(c->d_row_moved.p, 0, std::max(c->n, 1u), st));
+    HIPCHK(c, hipMemsetAsync(c->d_col_tab.p, 0xFF, (size_t)c->col_tab_size * 16, st));
+    unsigned long long *tab_key = c->d_col_tab.p, *tab_min = c->d_col_tab.p + c->col_tab_size;
+    const uint32_t user_cell = c->user_row != ROW_CELL_NONE ? c->h_row_cell[c->user_row] : ROW_CELL_NONE;
+    if (c->ncells) hipLaunchKernelGGL(k_col_region, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_key.p, c->d_cell_tight.p, c->d_params.p, c->cfg.atomic_length,
+                                      c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP);
+    if (c->nsh) hipLaunchKernelGGL(k_col_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_aabb.p, c->d_sh_cells.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_cell_key.p,
+                                   c->d_params.p, c->d_col_hdr.p, c->d_col_shared.p, COL_SHARED_CAP);
+    hipLaunchKernelGGL(k_col_tops, dim3(COL_REGION_CAP / 256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP);
+    hipLaunchKernelGGL(k_col_moved, dim3((c->ndyn + 1 + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_cell.p, c->user_row, user_cell, row_arrays(c), c->d_cell_key.p,
+                       c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_row_moved.p,
+                       tab_key, tab_min, c->col_tab_size - 1u);
+    hipLaunchKernelGGL(k_col_pairs, dim3(1024), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_col_region.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP,
+                       row_arrays(c), c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_row_moved.p, tab_key, tab_min,
+                       c->col_tab_size - 1u, c->d_col_pairs.p, c->col_pair_cap);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(e1, st));
+    ColHeader h{};
+    HIPCHK(c, hipMemcpyAsync(&h, c->d_col_hdr.p, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&c->t_collide, e0, e1); c->t_collide *= 1000.f;
+    if (h.n_region > COL_REGION_CAP || h.n_high > COL_REGION_CAP) return c->fail(RE_E_CAPACITY, "re_collide: %u world sections around the camera exceed the region list (%u)", h.n_region, COL_REGION_CAP);
+    if (h.n_shared > COL_SHARED_CAP) return c->fail(RE_E_CAPACITY, "re_collide: %u shared sections within the collision distance exceed the list (%u)", h.n_shared, COL_SHARED_CAP);
+    if (h.n_moved > c->col_moved_cap) return c->fail(RE_E_CAPACITY, "re_collide: %u (section, moved entity) entries exceed the list (%u)", h.n_moved, c->col_moved_cap);
+    const uint32_t nw = std::min(std::min(h.n_pairs, capacity), c->col_pair_cap);
+    if (nw) HIPCHK(c, hipMemcpy(pairs, c->d_col_pairs.p, (size_t)nw * sizeof(re_collision), hipMemcpyDeviceToHost));
+    if (n_total) *n_total = h.n_pairs;
     return RE_OK;
 }
 

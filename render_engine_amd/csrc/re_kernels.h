@@ -10,7 +10,7 @@ namespace re {
 // entity flag bits (== RE_F_* of include/re_hip.h) + internal
 constexpr uint32_t F_STATIC = 0x001, F_HAS_VEL = 0x002, F_HAS_ACC = 0x004, F_HAS_ROT = 0x008, F_HAS_ROTVEL = 0x010,
                    F_HAS_ROTACC = 0x020, F_HAS_SCALE = 0x040, F_ALWAYS_EXEC = 0x080, F_OOB_LOGIC = 0x100,
-                   F_HAS_MOVED = 0x200, F_HAS_ROTATED = 0x400, F_USER = 0x800, F_DEAD = 0x80000000u;
+                   F_HAS_MOVED = 0x200, F_HAS_ROTATED = 0x400, F_USER = 0x800, F_CAN_COLLIDE = 0x1000, F_DEAD = 0x80000000u;
 // world-section flag bits
 constexpr uint8_t CF_STATIC_SECTION = 1;   // member of static_world_sections (bounding_box_tree_v2.rs:1133-1213)
 constexpr uint8_t CF_STATIC_CACHED = 2;    // its static entities are in the render cache (render_flow.rs:549-594)
@@ -131,6 +131,24 @@ __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, c
                        const uint32_t *dyn_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec);
+// collision broad phase (re_collide.hip)
+constexpr float COLLISION_DISTANCE = 200.0f;           // handle_collisions keeps sections within this distance of the camera (logic_flow.rs:553-566)
+struct ColHeader { uint32_t n_region, n_high, n_shared, n_moved, n_pairs, pad[3]; };
+struct ColRegion { uint64_t key, top; uint32_t slot, near; };            // an existing section around the camera; top: its topmost existing ancestor
+struct ColShared { uint64_t top[8]; uint32_t s, nk; };                    // a shared section within the distance; top[k]: topmost ancestor of its k-th linking section
+struct ColMoved { uint64_t key; unsigned long long order; uint32_t row, info; };   // (section, moved entity); info bit 0: Shared lookup, bits 1-2: listings
+__global__ void k_col_region(uint32_t ncells, const uint64_t *cell_key, const Aabb *cell_tight, const FrameParams *P, uint32_t atomic, ColHeader *hdr, ColRegion *region,
+                             uint32_t region_cap, uint32_t *high, uint32_t high_cap);
+__global__ void k_col_shared(uint32_t nsh, const Aabb *sh_aabb, const int32_t *sh_cells, const uint32_t *sh_nact, const uint32_t *sh_nstat, const uint64_t *cell_key,
+                             const FrameParams *P, ColHeader *hdr, ColShared *out, uint32_t cap);
+__global__ void k_col_tops(ColHeader *hdr, ColRegion *region, uint32_t region_cap, const uint32_t *high, uint32_t high_cap, ColShared *shared, uint32_t shared_cap);
+__global__ void k_col_moved(uint32_t ndyn, const uint32_t *dyn_row, const uint32_t *dyn_cell, uint32_t user_row, uint32_t user_cell, RowArrays R, const uint64_t *cell_key,
+                            const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells, const Aabb *sh_aabb, const FrameParams *P, ColHeader *hdr,
+                            ColMoved *moved, uint32_t moved_cap, uint8_t *row_moved, unsigned long long *tab_key, unsigned long long *tab_min, uint32_t tab_mask);
+__global__ void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, const ColRegion *region, uint32_t region_cap, const ColShared *shared, uint32_t shared_cap,
+                            RowArrays R, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat,
+                            const uint32_t *rows, const uint8_t *row_moved, const unsigned long long *tab_key, const unsigned long long *tab_min, uint32_t tab_mask,
+                            uint2 *pairs, uint32_t pair_cap);
 struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)

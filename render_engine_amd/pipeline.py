@@ -218,6 +218,17 @@ class Pipeline:
         self._check(self._L.re_apply_changes(self._h, ch.ctypes.data, len(ch), 0, C.byref(tr)), "re_apply_changes")
         return dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
 
+    def collide(self, capacity=None):
+        """LogicFlow::handle_collisions (flows/logic_flow.rs:452-651) of the frame, between cull_and_pack and tick: array [n, 2] of
+        the (this_entity, other_entity) arguments of every collision-logic invocation, in no particular order"""
+        n = C.c_uint32()
+        if capacity is None:
+            self._check(self._L.re_collide(self._h, 0, None, 0, C.byref(n)), "re_collide")
+            capacity = n.value
+        pairs = np.zeros((max(capacity, 1), 2), np.uint32)
+        self._check(self._L.re_collide(self._h, 0, pairs.ctypes.data, capacity, C.byref(n)), "re_collide")
+        return pairs[:min(n.value, capacity)].copy(), n.value
+
     def wait(self, copy=False):
         vis = _capi.Visible(); tr = _capi.TickResult()
         self._check(self._L.re_wait(self._h, C.byref(vis), C.byref(tr)), "re_wait")

@@ -339,6 +339,73 @@ def test_frozen_static_cache_ghosts(R):
     p.close(); w.close()
 
 
+def sorted_pairs(a):
+    a = np.asarray(a, np.uint32).reshape(-1, 2)
+    return a[np.lexsort((a[:, 1], a[:, 0]))]
+
+
+def collision_world(R, n, seed, spread, atomic=64):
+    ents = R.synthetic.mixed_world(n, seed=seed, spread=spread, atomic=atomic)
+    u = R.synthetic.uniform(seed, np.arange(n, dtype=np.uint64), 77)
+    ents["flags"][u < 0.7] |= R.F_CAN_COLLIDE
+    return ents
+
+
+@pytest.mark.parametrize("seed,n,spread,atomic", [(5, 2500, 160.0, 64), (9, 4000, 260.0, 64), (13, 1500, 150.0, 16)])
+def test_collision_broad_phase_parity(R, seed, n, spread, atomic):
+    """re_collide == LogicFlow::handle_collisions (flows/logic_flow.rs:452-651): the (this, other) pairs of every collision-logic
+    invocation as a multiset, frame after frame with ticks (movers change sections), user change batches and a roaming camera;
+    dense clusters so that unique sections of several levels, shared sections and the related-section closure all take part"""
+    ents = collision_world(R, n, seed, spread, atomic)
+    ents["vel"] *= 3.0
+    p, w = build_pair(R, ents, atomic=atomic)
+    rng = np.random.default_rng(seed)
+    total = 0
+    for f in range(10):
+        pos = (8192 + rng.uniform(-spread, spread) * 0.6, 8192 + rng.uniform(-spread, spread) * 0.6, 8192 + rng.uniform(-0.3, 1.2) * spread)
+        d = rng.uniform(-1, 1, 3); d[2] -= 1.2
+        cam = R.Camera(pos, tuple(d / np.linalg.norm(d)), float(rng.choice([400.0, 1500.0])))
+        oc = oracle_camera(cam)
+        check_frame(R, p, w, cam, bool(f % 2))
+        want = sorted_pairs(w.collide(oc))
+        got, n_total = p.collide()
+        assert n_total == len(want), (f, n_total, len(want))
+        np.testing.assert_array_equal(sorted_pairs(got), want, err_msg=f"frame {f}")
+        total += n_total
+        if f == 3:                                                   # truncation reports the total and fills what fits
+            part, n2 = p.collide(capacity=min(7, n_total))
+            assert n2 == n_total and len(part) == min(7, n_total)
+        n_o, oob_o = w.tick(oc, 0.05); t = p.tick(0.05)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        if f % 3 == 2:
+            ch = random_changes(R, ents, rng, 40, set())
+            w.apply_changes(ch.view(ro.CHANGE_DT)); p.apply_changes(ch)
+    assert total > 50
+    p.close(); w.close()
+
+
+def test_collision_user_entity_and_lattice(R):
+    """the user entity always causes collisions (UserAlwaysCausesCollisions, pipeline.rs:136, logic_flow.rs:236-240); config-3 style
+    world (one entity per section, spinners) around it"""
+    ents = R.synthetic.lattice_world(cells_per_axis=12, first_cell=122, spinner_every=3, straddler_fraction=0.1)
+    ents["flags"][(ents["flags"] & R.F_HAS_ROTVEL) != 0] |= R.F_CAN_COLLIDE
+    user = ents[:1].copy()
+    user["id"] = 9_000_000; user["flags"] = R.F_USER; user["pos"] = (8192 + 32, 8192 + 32, 8192 + 32); user["original"] = (-30, 30, -30, 30, -30, 30)   # inside section (128,128,128), whose entity (id 942) is a spinner
+    ents = np.concatenate([ents, user])
+    p, w = build_pair(R, ents)
+    for i in range(3):
+        cam = R.Camera((8192 + 40 + 20 * i, 8192 + 40, 8192 + 40), (0, 0, -1), 1000.0)
+        oc = oracle_camera(cam)
+        check_frame(R, p, w, cam, False)
+        want = sorted_pairs(w.collide(oc))
+        got, n_total = p.collide()
+        assert n_total == len(want) and n_total > 0
+        np.testing.assert_array_equal(sorted_pairs(got), want)
+        assert [9_000_000, 942] in want.tolist() and [942, 9_000_000] in want.tolist()
+        w.tick(oc, 0.016); p.tick(0.016)
+    p.close(); w.close()
+
+
 def test_async_frames_with_movers_are_replayed(R):
     """frames of a world with movers enqueued without waiting (speculation): a tick that finds section changes cancels the frames
     behind it and the library replays them on the patched tree -- the end state equals the frame-by-frame reference"""

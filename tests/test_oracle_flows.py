@@ -159,3 +159,77 @@ def test_static_cache_first_sight_quirk():
     w2 = ro.World(16384, 64); w2.register(to_oracle(ents))
     w2.cull(near_cam); assert w2.render(near_cam)["total"] > 0
     w.close(); w2.close()
+
+
+def _ent(i, pos, half, flags, vel=(0, 0, 0)):
+    e = np.zeros(1, ro.ENTITY_DT)[0]
+    e["id"] = i; e["flags"] = flags
+    e["original"] = (-half, half, -half, half, -half, half)
+    e["pos"] = pos; e["scale"] = (1, 1, 1); e["rot_axis"] = (1, 0, 0); e["vel"] = vel
+    return e
+
+
+def test_collision_pass_hand_case():
+    """handle_collisions (flows/logic_flow.rs:452-651) on a case worked out by hand.  One level-0 world section next to the camera
+    (listed twice in visible_sections_vec: logic box and frustum, so its moved entities are pushed twice, :214-223, 443-446):
+      1 mover, large, CanCauseCollisions         -- the moved entity
+      2 at rest (no Velocity), touches 1         -- (1,2) and (2,1): both collision functions run (:640-647)
+      3 mover with CanCauseCollisions, touches 1 -- (1,3) from 1's pass and (3,1) from 3's pass, each only-to-self (:625-637)
+      4 static, touches 1                        -- static_entities are not searched (find_related_entities returns local_entities)
+      5 at rest, apart                           -- no overlap
+      6 mover WITHOUT CanCauseCollisions, touches 1 -- not a moved entity: treated like 2
+      7 at rest, touches 1 only along a face (closed intervals, range.rs:71)
+    """
+    F = ro
+    w = ro.World(16384, 64)
+    mv = F.F_HAS_VEL | F.F_CAN_COLLIDE
+    ents = np.array([
+        _ent(1, (8210, 8210, 8210), 5.0, mv, (1, 0, 0)),
+        _ent(2, (8216, 8210, 8210), 2.0, 0),
+        _ent(3, (8204, 8210, 8210), 2.0, mv, (0, 1, 0)),
+        _ent(4, (8210, 8216, 8210), 2.0, F.F_STATIC),
+        _ent(5, (8240, 8240, 8240), 2.0, 0),
+        _ent(6, (8210, 8204, 8210), 2.0, F.F_HAS_VEL, (0, 0, 1)),
+        _ent(7, (8210, 8210, 8217), 2.0, 0),
+    ], ro.ENTITY_DT)
+    assert w.register(ents) == 0
+    cam = oracle_camera(Camera((8210, 8210, 8290), (0, 0, -1), 1000.0))
+    vis = w.cull(cam)
+    key = ro.pack_key(0, 8210 // 64, 8210 // 64, 8210 // 64)
+    assert (vis == key).sum() == 2
+    pairs = sorted(map(tuple, w.collide(cam).tolist()))
+    once = [(1, 2), (2, 1), (1, 3), (3, 1), (1, 6), (6, 1), (1, 7), (7, 1)]
+    assert pairs == sorted(once * 2)
+    # farther than 200 units from the section: nothing is tested (:553-558), although the section is still visible
+    cam_far = oracle_camera(Camera((8210, 8210, 8210 + 64 + 260), (0, 0, -1), 1000.0))
+    assert key in set(w.cull(cam_far).tolist())
+    assert len(w.collide(cam_far)) == 0
+    w.close()
+
+
+def test_collision_shared_first_touch_and_related_sections():
+    """a moved entity stored under a Shared lookup that is the first to touch a world section creates the section's entry WITHOUT
+    being pushed into it (logic_flow.rs:488-498), so alone it collides with nothing; a second moved entity in the same sections
+    then does.  A large entity one level up is found through related_world_sections (the parent section)."""
+    F = ro
+    mv = F.F_HAS_VEL | F.F_CAN_COLLIDE
+    base = [
+        _ent(10, (8256, 8210, 8210), 4.0, mv, (1, 0, 0)),          # straddles x = 8256: shared section of two level-0 sections
+        _ent(11, (8250, 8210, 8210), 3.0, 0),                        # at rest in the left section, touches 10
+        _ent(12, (8256, 8256, 8256), 50.0, 0),                       # level-1 section (parent of both), touches 10
+    ]
+    w = ro.World(16384, 64)
+    assert w.register(np.array(base, ro.ENTITY_DT)) == 0
+    assert w.lookup(10)[0] == 2 and w.lookup(12)[0] == 1 and ro.unpack_key(w.lookup(12)[1][0])[0] == 1
+    cam = oracle_camera(Camera((8240, 8210, 8290), (0, 0, -1), 1000.0))
+    w.cull(cam)
+    assert len(w.collide(cam)) == 0                                  # 10 created both entries and is in neither
+    w.close()
+    w = ro.World(16384, 64)
+    assert w.register(np.array(base + [_ent(20, (8256, 8212, 8212), 3.0, mv, (0, 1, 0))], ro.ENTITY_DT)) == 0   # same shared section, larger id
+    w.cull(cam)
+    pairs = sorted(map(tuple, w.collide(cam).tolist()))
+    # 20 is pushed into both sections' entries (10 created them): per section, 20 against 10 (moved: only-to-self), 11 and 12 (at rest: both ways)
+    per_section = [(20, 10), (20, 11), (11, 20), (20, 12), (12, 20)]
+    assert pairs == sorted(per_section * 2)
+    w.close()

@@ -62,6 +62,8 @@ def check_state(w, exp):
             assert k == 1 and ro.unpack_key(keys[0]) == tuple(ids)
         else:
             assert k == 2 and [ro.unpack_key(x) for x in keys] == [tuple(i) for i in ids]
+    for kstr, rel in exp.get("related", {}).items():               # related_world_sections (check_related_world_sections :1527-1543)
+        assert w.related_sections(key_of([int(v) for v in kstr.split(",")])) == sorted(key_of(r) for r in rel)
     # every other entity has no lookup entry
     for eid in range(8):
         if str(eid) not in exp["lookup"]:
@@ -80,4 +82,24 @@ def test_tree_sequences_known_answers(seq):
             w.tree_remove(op[1])
         else:
             check_state(w, op[1])
+    w.close()
+
+
+def test_find_related_entities_known_answer():
+    """find_related_entities (:2220-2303): from any section of the relationship the search reaches every section of it -- through
+    the parent (2,0,0,0) also the sibling (1,1,0,0), which exists only as a link of the shared section -- and the shared section
+    once; the unrelated section finds itself alone"""
+    F = G["find_related"]
+    w = ro.World(G["outline"], G["atomic"])
+    for i, box in enumerate(F["adds"]):
+        assert w.tree_add(i, box) == 0
+    w.end_of_changes()
+    for q in F["queries"]:
+        for start in q["from"]:
+            uniq, shared = w.find_related(key_of(start))
+            assert sorted(uniq) == sorted(key_of([int(v) for v in k.split(",")]) for k in q["unique"])
+            for k, ents in q["unique"].items():
+                local, static = w.cell_entities(key_of([int(v) for v in k.split(",")]))
+                assert sorted(local.tolist()) == ents
+            assert sorted(shared) == sorted(tuple(key_of(i) for i in s["ids"]) for s in q["shared"])
     w.close()
