@@ -190,6 +190,7 @@ struct FrameResult {
     uint32_t visible_sections = 0, visible_sections_vec = 0, instances = 0;
     std::vector<re_instance_range> groups;                  // (LOD-adjusted ModelId, render system, sortable) -> InstanceRange
     std::vector<EntityId> entity_ids; std::vector<float> matrices;   // host copies (filled when execute(.., copy = true))
+    std::vector<re_collision> collisions;                            // (this_entity, other_entity) of every collision-logic invocation (execute(.., collide = true))
     re_tick_result tick{};
 };
 
@@ -247,7 +248,7 @@ class Pipeline {
     // Pipeline::register_user_entity + create_user_entity_instance (flows/pipeline.rs:125-174)
     EntityId register_user_entity(TVec3 camera_pos, StaticAABB original_aabb, ModelId model_id) {
         EntityId e = create_entity(); Row &r = rows_[e];
-        r.model = model_id; r.original = original_aabb; r.pos = camera_pos; r.flags = RE_F_USER | RE_F_HAS_VEL | RE_F_HAS_ACC; r.placed = true;
+        r.model = model_id; r.original = original_aabb; r.pos = camera_pos; r.flags = RE_F_USER | RE_F_HAS_VEL | RE_F_HAS_ACC | RE_F_CAN_COLLIDE; r.placed = true;   // CanCauseCollisions + UserAlwaysCausesCollisions (pipeline.rs:135-136)
         uploaded_ = false; return e;
     }
     void write_sortable_component(EntityId e, uint32_t sortable_index) { row(e).sortable = sortable_index; uploaded_ = false; }   // ecs.rs:202-205
@@ -255,7 +256,9 @@ class Pipeline {
     void write_out_of_bounds_logic(EntityId e) { row(e).flags |= RE_F_OOB_LOGIC; uploaded_ = false; }                           // the entity type has OutOfBoundsLogic
 
     // Pipeline::execute (flows/pipeline.rs:212-276) for this path: both visibility queries + render gather, then the kinematic tick
-    FrameResult execute(const Camera &camera, float delta_time, bool copy = false, bool emit_duplicates = false) {
+    // collide: also run the collision phase of LogicFlow::execute (logic_flow.rs:243) between the visibility queries and the tick; the
+    // caller dispatches FrameResult::collisions to the CollisionFunction of each this_entity's type
+    FrameResult execute(const Camera &camera, float delta_time, bool copy = false, bool emit_duplicates = false, bool collide = false) {
         upload_if_needed();
         re_camera cam{};
         Mat4 pv = detail::mul(camera.get_projection_matrix(), camera.get_view_matrix());
@@ -272,6 +275,11 @@ class Pipeline {
         if (copy && vis.n_written) {
             out.entity_ids.resize(vis.n_written); out.matrices.resize((size_t)vis.n_written * 16); uint32_t n = 0;
             check(re_copy_visible(ctx_, out.entity_ids.data(), out.matrices.data(), vis.n_written, &n), "re_copy_visible");
+        }
+        if (collide) {
+            uint32_t n = 0; check(re_collide(ctx_, 0u, nullptr, 0u, &n), "re_collide");
+            out.collisions.resize(n);
+            if (n) check(re_collide(ctx_, 0u, out.collisions.data(), n, &n), "re_collide");
         }
         check(re_tick(ctx_, delta_time, 0u, &out.tick), "re_tick");
         return out;
@@ -335,6 +343,7 @@ inline void EntityTransformationBuilder::apply_choices(StaticAABB original_aabb,
     check_invariants();
     Pipeline::Row &r = pipeline.row(entity_id_);
     r.original = original_aabb; r.placed = true; r.flags &= (RE_F_ALWAYS_EXEC | RE_F_OOB_LOGIC);
+    if (can_collide_) r.flags |= RE_F_CAN_COLLIDE;                  // entity_transformer.rs:66-69
     if (is_static_) r.flags |= RE_F_STATIC;
     r.pos = translation_->v;
     if (velocity_) { r.vel = velocity_->v; r.flags |= RE_F_HAS_VEL; }
@@ -343,7 +352,7 @@ inline void EntityTransformationBuilder::apply_choices(StaticAABB original_aabb,
     if (rotation_velocity_) { r.rotvel = *rotation_velocity_; r.flags |= RE_F_HAS_ROTVEL; }
     if (rotation_acceleration_) { r.rotacc = *rotation_acceleration_; r.flags |= RE_F_HAS_ROTACC; }
     if (scale_) { r.scale = scale_->v; r.flags |= RE_F_HAS_SCALE; }
-    (void)light_; (void)can_collide_;                           // lights and the collision phase are outside this path
+    (void)light_;                                               // lights are outside this path
     pipeline.uploaded_ = false;
 }
 

@@ -74,16 +74,16 @@ int main(int argc, char **argv) {
         if (e.kind == 0) {
             EntityId id = pipeline.register_user_entity(vec3(e.p[0], e.p[1], e.p[2]), box, ModelId{ e.model, 0 });
             if (id != i) return fail("user entity id");
-            d.flags = RO_F_USER | RO_F_HAS_VEL | RO_F_HAS_ACC;
+            d.flags = RO_F_USER | RO_F_HAS_VEL | RO_F_HAS_ACC | RO_F_CAN_COLLIDE;
         } else {
             pipeline.register_model_instances(ModelId{ e.model, 0 }, 1, box, [&](Pipeline &p, const std::vector<EntityId> &created, StaticAABB aabb) {
-                EntityTransformationBuilder b(created[0], false, std::nullopt, false);
+                EntityTransformationBuilder b(created[0], false, std::nullopt, /*can_cause_collision=*/e.kind == 1);   // the asteroids collide (asteroid.rs)
                 b.with_translation(Position::new_(vec3(e.p[0], e.p[1], e.p[2]))).with_scale(Scale::new_(vec3(e.s, e.s, e.s)));
                 if (e.kind == 1) b.with_rotation(Rotation::new_(vec3(e.rot[0], e.rot[1], e.rot[2]), e.rot[3])).with_rotation_velocity(VelocityRotation::new_(vec3(e.rv[0], e.rv[1], e.rv[2]), e.rv[3]));
                 b.apply_choices(aabb, p);
                 if (e.sortable) p.write_sortable_component(created[0], e.sortable);
             });
-            d.flags = RO_F_HAS_SCALE | (e.kind == 1 ? (RO_F_HAS_ROT | RO_F_HAS_ROTVEL) : 0u);
+            d.flags = RO_F_HAS_SCALE | (e.kind == 1 ? (RO_F_HAS_ROT | RO_F_HAS_ROTVEL | RO_F_CAN_COLLIDE) : 0u);
             d.scale[0] = d.scale[1] = d.scale[2] = e.s;
             if (e.kind == 1) { d.rot_axis[0] = e.rot[0]; d.rot_axis[1] = e.rot[1]; d.rot_axis[2] = e.rot[2]; d.rot_angle = e.rot[3]; d.rotvel_axis[0] = e.rv[0]; d.rotvel_axis[1] = e.rv[1]; d.rotvel_axis[2] = e.rv[2]; d.rotvel = e.rv[3]; }
         }
@@ -98,9 +98,20 @@ int main(int argc, char **argv) {
 
     const uint32_t cap = 4096;
     std::vector<uint32_t> oids(cap); std::vector<float> omats((size_t)cap * 16); std::vector<ro_group> ogroups(256); std::vector<uint64_t> okeys(cap);
+    size_t n_collisions = 0;
     for (int frame = 0; frame < 8; frame++) {
-        FrameResult fr = pipeline.execute(camera, 1.0f / 60.0f, /*copy=*/true);
+        FrameResult fr = pipeline.execute(camera, 1.0f / 60.0f, /*copy=*/true, /*emit_duplicates=*/false, /*collide=*/true);
         uint32_t nvec = ro_frame_cull(w, &oc, cap, okeys.data());
+        {   // the collision phase, between the visibility queries and the tick (logic_flow.rs:230-244)
+            std::vector<uint32_t> op((size_t)cap * 2);
+            uint32_t nc = ro_frame_collide(w, &oc, cap, op.data());
+            if (nc != fr.collisions.size()) return fail("collision count");
+            std::vector<std::pair<uint32_t, uint32_t>> a, b;
+            for (uint32_t i = 0; i < nc; i++) { a.push_back({ op[2 * i], op[2 * i + 1] }); b.push_back({ fr.collisions[i].this_entity, fr.collisions[i].other_entity }); }
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+            if (a != b) return fail("collision pairs differ");
+            n_collisions += nc;
+        }
         uint32_t ng = 0, total = ro_frame_render(w, &oc, 0, cap, oids.data(), omats.data(), (uint32_t)ogroups.size(), ogroups.data(), &ng);
         uint32_t noob = 0, ochanged = ro_frame_tick(w, &oc, 1.0f / 60.0f, 0, nullptr, &noob);
         if (fr.visible_sections_vec != nvec) return fail("visible_sections_vec length");
@@ -131,6 +142,6 @@ int main(int argc, char **argv) {
         for (uint32_t i = 0; i < total; i++) if (oids[i] == wormhole && std::memcmp(&omats[(size_t)i * 16], tm.m.data(), 64) != 0) return fail("wormhole matrix after apply_change");
     }
     ro_world_free(w);
-    std::printf("OK %zu entities, 9 frames bit-exact\n", ents.size());
+    std::printf("OK %zu entities, 9 frames bit-exact, %zu collision invocations\n", ents.size(), n_collisions);
     return 0;
 }
