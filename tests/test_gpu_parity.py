@@ -452,7 +452,7 @@ def test_world_with_more_than_512_sections_per_axis(R):
     p.close(); w.close()
 
 
-@pytest.mark.parametrize("seed,atomic,tight", [(3, 64, False), (11, 64, True), (29, 64, False), (57, 16, False), (101, 64, True), (202, 16, True)])
+@pytest.mark.parametrize("seed,atomic,tight", [(3, 64, False), (11, 64, True), (29, 64, False), (57, 16, False), (101, 64, True), (202, 16, True), (303, 64, False), (404, 16, False), (505, 64, True)])
 def test_soak_random_frames(R, seed, atomic, tight):
     """a longer randomized run: movers, spinners, user change batches (every kind), cameras that jump around, synchronous and
     asynchronous frames mixed -- section table, entities and the rendered set are compared with the oracle every few frames.
