@@ -70,7 +70,7 @@ def deferred_lighting(pos, nrm, alb, lights_struct, idx=None):
 
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or \
-            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("re_oracle.c", "re_oracle.h")):
+            os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("re_oracle.c", "re_cpu_soa.c", "re_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -134,6 +134,11 @@ def lib():
     L.ro_related_sections.restype = C.c_uint32; L.ro_related_sections.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     L.ro_find_related.restype = C.c_uint32
     L.ro_find_related.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, u32p, C.c_uint32, C.c_void_p, u32p]
+    L.soa_build.restype = C.c_void_p
+    L.soa_build.argtypes = [C.c_uint32] + [C.c_void_p] * 7 + [C.c_uint32, C.c_uint32, C.c_int]
+    L.soa_free.argtypes = [C.c_void_p]
+    L.soa_frame.restype = C.c_uint32
+    L.soa_frame.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, u32p, u32p, C.c_void_p]
     _lib = L
     return L
 
@@ -342,3 +347,52 @@ class World:
         oob = np.zeros(cap, np.uint32); noob = C.c_uint32()
         n = self.L.ro_frame_tick(self.h, C.byref(cam), np.float32(dt), cap, oob.ctypes.data, C.byref(noob))
         return n, oob[:min(noob.value, cap)].copy()
+
+
+class SoaWorld:
+    """the "optimised CPU" row (re_cpu_soa.c): sorted keys + SoA + OpenMP for worlds of static entities in unique sections.
+    Built from an entity array and the oracle World that holds the same entities (matrices, AABBs and section keys are taken
+    from it, so both agree by construction on everything except the data structures and the traversal)."""
+
+    def __init__(self, world, ents, threads=1):
+        self.L = lib()
+        n = len(ents)
+        keys = np.zeros(n, np.uint64); boxes = np.zeros(n, AABB_DT); mats = np.zeros((n, 16), np.float32)
+        _soa_fill(world, ents, keys, boxes, mats)
+        ids = np.ascontiguousarray(ents["id"], np.uint32); model = np.ascontiguousarray(ents["model_index"], np.uint32)
+        rs = np.ascontiguousarray(ents["render_system"], np.uint32); srt = np.ascontiguousarray(ents["sortable"], np.uint32)
+        self.h = self.L.soa_build(n, keys.ctypes.data, boxes.ctypes.data, ids.ctypes.data, model.ctypes.data, rs.ctypes.data, srt.ctypes.data, mats.ctypes.data,
+                                  world.outline, world.atomic, threads)
+        self.nsec = len(np.unique(keys)); self.mark = np.zeros(self.nsec + 1, np.uint8)
+
+    def frame(self, cam, cap=0, gcap=4096):
+        ids = np.zeros(max(cap, 1), np.uint32); mats = np.zeros((max(cap, 1), 16), np.float32); groups = np.zeros(gcap, GROUP_DT)
+        ng, nvec = C.c_uint32(), C.c_uint32()
+        total = self.L.soa_frame(self.h, C.byref(cam), cap, ids.ctypes.data if cap else None, mats.ctypes.data if cap else None, gcap, groups.ctypes.data,
+                                 C.byref(ng), C.byref(nvec), self.mark.ctypes.data)
+        return dict(total=total, ids=ids[:min(total, cap)], mats=mats[:min(total, cap)], groups=groups[:ng.value].copy(), n_visible_vec=nvec.value)
+
+    def close(self):
+        if self.h:
+            self.L.soa_free(self.h); self.h = None
+
+
+def _soa_fill(world, ents, keys, boxes, mats):
+    """section key, StaticAABB and TransformationMatrix of every entity.  Static, translation-only entities inside one section
+    (the lattice configs): the matrix is the translation, the AABB is OriginalAABB + position (apply_transformation of the two
+    corners), the key follows from the AABB minimum -- checked against the oracle on a sample."""
+    a = world.atomic
+    pos = np.ascontiguousarray(ents["pos"], np.float32)
+    org = np.ascontiguousarray(ents["original"]).view(np.float32).reshape(len(ents), 6)
+    mats[:] = 0; mats[:, 0] = mats[:, 5] = mats[:, 10] = mats[:, 15] = 1; mats[:, 12:15] = pos
+    for k, (lo, hi) in enumerate(((0, 1), (2, 3), (4, 5))):
+        boxes[("xmin", "ymin", "zmin")[k]] = org[:, lo] * np.float32(1.0) + pos[:, k]
+        boxes[("xmax", "ymax", "zmax")[k]] = org[:, hi] * np.float32(1.0) + pos[:, k]
+    cx = np.floor(boxes["xmin"] / a).astype(np.uint64); cy = np.floor(boxes["ymin"] / a).astype(np.uint64); cz = np.floor(boxes["zmin"] / a).astype(np.uint64)
+    assert (np.floor(boxes["xmax"] / a) == cx).all() and (np.floor(boxes["ymax"] / a) == cy).all() and (np.floor(boxes["zmax"] / a) == cz).all(), "SoaWorld: entities must lie inside one level-0 section"
+    keys[:] = (cx << np.uint64(32)) | (cz << np.uint64(16)) | cy
+    step = max(1, len(ents) // 64)
+    for e in ents[::step]:
+        kind, ks = world.lookup(int(e["id"])); st = world.entity(int(e["id"]))
+        i = int(np.nonzero(ents["id"] == e["id"])[0][0])
+        assert kind == 1 and ks[0] == int(keys[i]) and (st["mat"] == mats[i]).all() and (st["aabb"] == np.array([boxes[i][f] for f in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")], np.float32)).all()

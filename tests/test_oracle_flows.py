@@ -233,3 +233,25 @@ def test_collision_shared_first_touch_and_related_sections():
     per_section = [(20, 10), (20, 11), (11, 20), (20, 12), (12, 20)]
     assert pairs == sorted(per_section * 2)
     w.close()
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_optimised_cpu_row_matches_the_oracle(threads):
+    """the "optimised CPU" baseline of bench.py (oracle/re_cpu_soa.c: sorted keys, SoA, OpenMP) draws exactly what the port of the
+    reference draws, frame after frame (incl. the frozen static cache: sections beyond the draw distance at the first frame stay empty)"""
+    ents = synthetic.lattice_world(cells_per_axis=36, first_cell=110)
+    w = ro.World(16384, 64); assert w.register(to_oracle(ents)) == 0
+    s = ro.SoaWorld(w, to_oracle(ents), threads=threads)
+    from helpers import assert_render_equal
+    for pos, d, far in [((8192, 8192, 8300), (0, 0, -1), 700.0), ((7800.5, 8100.25, 9000), (0.6, 0.0, -0.8), 1500.0), ((8192, 8192, 8192), (0.3, 0.2, -1), 3000.0)]:
+        cam = oracle_camera(Camera(pos, d, far))
+        vis = w.cull(cam)
+        o = w.render(cam)
+        g = s.frame(cam, cap=o["total"] + 8)
+        assert g["n_visible_vec"] == len(vis)
+        assert_render_equal(g, o)
+        order_o = {int(i): m for i, m in zip(o["ids"], o["mats"])}
+        for i, m in zip(g["ids"], g["mats"]):
+            assert (order_o[int(i)] == m).all()
+        w.tick(cam, 0.016)                                     # the logic phase of the frame clears changed_static_unique (pipeline.rs:271)
+    s.close(); w.close()
