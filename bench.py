@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-large-pack", action="store_true", help="always use the multi-kernel pack")
     ap.add_argument("--cpu-sample-axis", type=int, default=100)
+    ap.add_argument("--probe", action="store_true", help="opt-in variant: visibility query by hash probes of the candidate cells (RE_CFG_PROBE) instead of the key stream")
     return ap.parse_args()
 
 
@@ -95,7 +96,7 @@ def main():
     ents, dims, first = make_shard(rank, world, a.axis, atomic, a.spinner_every)
     n_local = len(ents)
     cap = 1 << 16 if a.far <= 2000 else max(1 << 16, n_local // 2)
-    p = R.Pipeline(16384, atomic, device=local, max_instances=cap)
+    p = R.Pipeline(16384, atomic, device=local, max_instances=cap, flags=R._capi.CFG_PROBE if a.probe else 0)
     p.register_model_instances(ents)
     stats = p.stats()
     del ents
@@ -161,12 +162,15 @@ def main():
         n_entries = vis["n_visible_sections"]
         key_bytes = 4 if (16384 + atomic - 1) // atomic <= 512 and not os.environ.get("RE_EXP_KEY64") else 8
         alg_bytes = key_bytes * C_sections + 4 * ((C_sections + 511) // 512) + 41 * n_entries + 16 * vis["total"]
+        probed = a.probe and p.stats()["n_probe_frames"] > 0
+        if probed:      # the probe kernel reads one 16-byte table entry per candidate cell instead of the key stream
+            alg_bytes = 16 * int(p.last_candidates()) + 41 * n_entries + 16 * vis["total"]
         k1_mean = float(np.mean(k1_us)) if len(k1_us) else float("nan")
         achieved = alg_bytes / (k1_mean * 1e-6) / 1e9 if k1_mean > 0 else None
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_pmc_k_scan_cull.json")
         # the committed PMC measurement is of the default workload on one GPU; other workloads report null
-        default_workload = world == 1 and a.axis == 216 and a.far == 1000.0 and not a.spinner_every and not a.force_large_pack
+        default_workload = world == 1 and a.axis == 216 and a.far == 1000.0 and not a.spinner_every and not a.force_large_pack and not a.probe
         if default_workload and os.path.exists(prof):
             try:
                 traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
@@ -185,7 +189,7 @@ def main():
                        "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), double-buffered, stream-ordered" % SLAB_INSTANCES},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_scan_cull", "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
+                         "kernel": "k_probe_cull" if probed else "k_scan_cull", "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
                          "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY},
             "frame_latency_ms_sync": float(np.median(lat) * 1e3),
             "kernel_us_last_frame": tm, "setup_s": t_setup,

@@ -74,6 +74,9 @@ typedef struct {
 
 #define RE_CFG_DEFAULT 0u
 #define RE_CFG_FULL_REBUILD 0x1u  /* testing: after section changes rebuild the whole section table instead of patching it in place */
+#define RE_CFG_PROBE        0x4u  /* opt-in: visibility query by hash probes of the candidate cells (O(candidates), like the reference's contains_key probes)
+                                   * instead of the key stream whenever the candidate boxes hold < 1/4 of the table's sections; needs 32 B per section more */
+#define RE_CFG_PROBE_ALWAYS 0x8u  /* testing, with RE_CFG_PROBE: probe whenever the candidate cells can be enumerated, however small the table */
 #define RE_CFG_TIGHT_SLACK  0x2u  /* testing: almost no spare slots / row-pool slack, so patches and full rebuilds alternate */
 
 /* Entities, struct-of-arrays, host pointers; copied during the call.  Optional arrays may be
@@ -111,6 +114,7 @@ typedef struct {
                                          visible_sections_vec (CullResult::extend, visible_world_flow.rs:31-35, pipeline.rs:228);
                                          default 0 = each visible instance once (the visible-ID *set*) */
 #define RE_CULL_ASYNC           0x2u  /* enqueue only; results are valid after re_wait() */
+#define RE_CULL_FORCE_STREAM    0x8u  /* with RE_CFG_PROBE: take the key stream for this frame anyway */
 #define RE_CULL_FORCE_LARGE_PACK 0x4u /* always use the multi-kernel pack (count/scan/scatter) instead of k_pack_small */
 
 /* One (ModelId, sortable) group of the packed buffer == ModelRenderingInformation.instance_location
@@ -243,6 +247,7 @@ int re_get_out_of_bounds(re_ctx *ctx, uint32_t *entity_ids, uint32_t capacity, u
 typedef struct {
     uint32_t n_entities, n_dynamic, n_sections, n_shared_sections, max_level;
     uint64_t device_bytes;
+    uint32_t n_probe_frames, n_table_rebuilds;   /* frames served by the probe path (RE_CFG_PROBE); full section-table rebuilds so far */
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,

@@ -110,6 +110,7 @@ struct re_ctx {
     // collision broad phase (re_collide): lists allocated at the first call
     uint32_t user_row = ROW_CELL_NONE; DevBuf<ColHeader> d_col_hdr; DevBuf<ColRegion> d_col_region; DevBuf<uint32_t> d_col_high; DevBuf<ColShared> d_col_shared; DevBuf<ColMoved> d_col_moved;
     DevBuf<uint8_t> d_row_moved; DevBuf<unsigned long long> d_col_tab; DevBuf<uint2> d_col_pairs; uint32_t col_moved_cap = 0, col_tab_size = 0, col_pair_cap = 0; float t_collide = 0.f;
+    DevBuf<HashEntry> d_htab; uint32_t htab_mask = 0, htab_keys = 0; uint32_t probe_frames = 0;   // RE_CFG_PROBE: key -> slot table of the probe path (k_probe_cull)
     std::set<uint64_t> dormant_cached;                  // sections with ghosts that were cached when they were emptied: the reference's cache entry outlives the section and shows again when the section is re-created
     std::set<uint32_t> h_uncached;                       // rows made static after the static render cache froze: in the tree's static sets, not drawn
     // groups
@@ -474,6 +475,14 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     c->nlists = std::max(1u, (uint32_t)((ncells + wave_keys - 1) / wave_keys));       // waves of k_scan_cull
     HIPCHK(c, hipStreamSynchronize(st));
     d_refold.release(nullptr); d_carried.release(nullptr);
+    if (c->cfg.flags & RE_CFG_PROBE) {                                      // key -> slot table at load <= 0.5 (tombstones of later patches included until the next full build)
+        uint32_t sz = 1024; while (sz < 2u * (uint32_t)std::min<size_t>(ncells + 1u, 1u << 30)) sz <<= 1;
+        if (c->htab_mask + 1u != sz) { c->d_htab.release(acct); HIPCHK(c, c->d_htab.alloc(sz, acct)); c->htab_mask = sz - 1u; }
+        HIPCHK(c, hipMemsetAsync(c->d_htab.p, 0xFF, (size_t)sz * sizeof(HashEntry), st));
+        if (ncells) hipLaunchKernelGGL(k_hash_build, dim3((ncells + 255) / 256), dim3(256), 0, st, ncells, c->d_cell_key.p, c->d_htab.p, c->htab_mask);
+        HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(st));
+        c->htab_keys = (uint32_t)keys.size();
+    }
     if (!carry) { c->dirty_pending = true; c->have_cull = false; }
     else if (!carry->changed_static.empty()) c->dirty_pending = true;
     return RE_OK;
@@ -839,8 +848,40 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 8, nullptr));
     SA.timeline = c->d_timeline.p;
 #endif
-    const ScanSpans SP = candidate_spans(c, scan_grid);
-    if (c->key32)
+    // Probe path (RE_CFG_PROBE): when the candidate boxes hold far fewer cells than the table has sections, look the cells up
+    // instead of streaming the keys
+    bool probed = false;
+    if ((c->cfg.flags & RE_CFG_PROBE) && c->d_htab.p && !(flags & RE_CULL_FORCE_STREAM)) {
+        ProbeArgs Q{}; Q.tab = c->d_htab.p; Q.mask = c->htab_mask;
+        uint64_t waves = 0; bool ok = true;
+        for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
+            Q.wave0[l] = (uint32_t)waves;
+            LevelBox u{}; u.level_length = P.box[0][l].level_length;
+            if (l < P.max_level) {
+                const LevelBox &a = P.box[0][l], &b = P.box[1][l];
+                const bool ea = !a.nx || !a.ny || !a.nz, eb = !b.nx || !b.ny || !b.nz;
+                auto lo = [&](uint32_t x, uint32_t y) { return ea ? y : eb ? x : std::min(x, y); };
+                auto hi = [&](uint64_t x, uint64_t y) { return ea ? y : eb ? x : std::max(x, y); };
+                if (!(ea && eb)) {
+                    u.bx = lo(a.bx, b.bx); u.by = lo(a.by, b.by); u.bz = lo(a.bz, b.bz);
+                    const uint64_t ex = hi((uint64_t)a.bx + a.nx, (uint64_t)b.bx + b.nx) - u.bx, ey = hi((uint64_t)a.by + a.ny, (uint64_t)b.by + b.ny) - u.by, ez = hi((uint64_t)a.bz + a.nz, (uint64_t)b.bz + b.nz) - u.bz;
+                    if (ex > 65536u || ey > 65536u || ez > 65536u || ex * ey * ez > (1ull << 31)) ok = false;     // (u16 wrap-around of the ids: leave it to the stream)
+                    else { u.nx = (uint32_t)ex; u.ny = (uint32_t)ey; u.nz = (uint32_t)ez; waves += (ex * ey * ez + PROBE_KEYS - 1) / PROBE_KEYS; }
+                }
+            }
+            Q.ubox[l] = u;
+        }
+        Q.wave0[MAX_LEVELS] = (uint32_t)waves; Q.nwaves = (uint32_t)waves;
+        if (ok && waves && (waves * PROBE_KEYS * 4u <= (uint64_t)c->ncells + 4096u || ((c->cfg.flags & RE_CFG_PROBE_ALWAYS) && waves <= (1u << 20)))) {
+            const uint32_t wgs = (uint32_t)((waves + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
+            const uint32_t grid = std::max(std::max(wgs, 1u), std::min((c->nsh + CULL_THREADS - 1) / CULL_THREADS, 2048u));
+            hipExtLaunchKernelGGL(k_probe_cull, dim3(grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, Q, SA);
+            probed = true; c->probe_frames++;
+        }
+    }
+    const ScanSpans SP = probed ? ScanSpans{} : candidate_spans(c, scan_grid);
+    if (probed) {}
+    else if (c->key32)
         hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     else
@@ -959,6 +1000,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         for (const SharedRec &sr : shrec) { (void)sr; need_pool += 1; }
         for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) if (need_slots[l] > c->free_slots[l].size()) return 1;
         if ((uint64_t)c->pool_used + need_pool > c->pool_cap) return 1;
+        if ((c->cfg.flags & RE_CFG_PROBE) && (uint64_t)c->htab_keys + affected.size() > (uint64_t)(c->htab_mask + 1u) * 7u / 10u) return 1;   // key -> slot table too full of tombstones: rebuild
     }
     for (uint32_t r : removed_rows) if (c->h_row_cell[r] != ROW_CELL_NONE) { c->h_row_cell[r] = ROW_CELL_NONE; p_rowcell.push_back(Pair32{ r, ROW_CELL_NONE }); }
     for (uint64_t K : affected) {
@@ -1103,6 +1145,11 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         size_t o32[9]; for (int k = 0; k < 9; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
         const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
+        if ((c->cfg.flags & RE_CFG_PROBE) && !p_key.empty()) {                // the key -> slot table follows: retire the old keys of those slots, then enter the new ones
+            for (uint32_t pass = 0; pass < 2; pass++)
+                hipLaunchKernelGGL(k_hash_patch, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p, c->d_htab.p, c->htab_mask, pass);
+            c->htab_keys += (uint32_t)p_key.size();                         // upper bound on the keys (live + tombstones) the table holds
+        }
         if (!p_key32.empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)p_key32.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key32.size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o_k32), c->d_cell_key32.p);
         if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
         for (int k = 0; k < 9; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
@@ -1757,7 +1804,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds;
     return RE_OK;
 }
 

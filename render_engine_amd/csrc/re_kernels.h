@@ -131,6 +131,16 @@ __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, c
                        const uint32_t *dyn_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec);
+// Probe path of the visibility query (opt-in, RE_CFG_PROBE): instead of streaming every section key, enumerate the cells of the two
+// candidate boxes (their bounding box per level) and look each one up in a device hash table key -> slot, like the reference's
+// own contains_key probes (visible_world_flow.rs:96-104).  Work is O(candidates), not O(sections).
+constexpr uint32_t PROBE_KEYS = 64;        // candidate cells per wave of k_probe_cull: few, so that the dependent memory round trips of the hits spread over many waves
+struct HashEntry { unsigned long long key; uint32_t slot, pad; };          // empty: key == ~0; removed section: slot == ~0 (the key stays as a tombstone)
+struct ProbeArgs { const HashEntry *tab; uint32_t mask, nwaves; uint32_t wave0[MAX_LEVELS + 1]; LevelBox ubox[MAX_LEVELS]; };
+__global__ void k_hash_build(uint32_t ncells, const uint64_t *cell_key, HashEntry *tab, uint32_t mask);
+struct Pair64;
+__global__ void k_hash_patch(uint32_t m, const Pair64 *slot_newkey, const uint64_t *cell_key_old, HashEntry *tab, uint32_t mask, uint32_t insert_pass);
+__global__ void k_probe_cull(ProbeArgs Q, ScanCullArgs A);
 // collision broad phase (re_collide.hip)
 constexpr float COLLISION_DISTANCE = 200.0f;           // handle_collisions keeps sections within this distance of the camera (logic_flow.rs:553-566)
 struct ColHeader { uint32_t n_region, n_high, n_shared, n_moved, n_pairs, pad[3]; };

@@ -486,6 +486,142 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
 template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 
+// ---------------------------------------------------------------------------------------------
+// Probe path (RE_CFG_PROBE): the same stage A / stage B as k_scan_cull, fed by hash probes of the candidate cells
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t key_hash(unsigned long long x, uint32_t mask) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 29; return (uint32_t)x & mask; }
+__global__ __launch_bounds__(256) void k_hash_build(uint32_t ncells, const uint64_t *__restrict__ cell_key, HashEntry *tab, uint32_t mask) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncells) return;
+    const unsigned long long k = cell_key[i];
+    if ((k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull) return;                // padding / spare slot
+    for (uint32_t h = key_hash(k, mask), probe = 0; probe <= mask; probe++, h = (h + 1u) & mask) {
+        const unsigned long long prev = atomicCAS(&tab[h].key, ~0ull, k);
+        if (prev == ~0ull || prev == k) { tab[h].slot = i; return; }
+    }
+}
+// in-place table patches: pass 0 retires the old key of every slot whose key changes, pass 1 enters the new keys (two launches, so a
+// section that leaves one slot and appears in another within one batch ends up present)
+__global__ __launch_bounds__(256) void k_hash_patch(uint32_t m, const Pair64 *__restrict__ slot_newkey, const uint64_t *__restrict__ cell_key_old, HashEntry *tab, uint32_t mask, uint32_t insert_pass) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t slot = slot_newkey[i].idx;
+    const unsigned long long k = insert_pass ? slot_newkey[i].val : cell_key_old[slot];
+    if ((k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull) return;
+    for (uint32_t h = key_hash(k, mask), probe = 0; probe <= mask; probe++, h = (h + 1u) & mask) {
+        if (insert_pass) {
+            const unsigned long long prev = atomicCAS(&tab[h].key, ~0ull, k);
+            if (prev == ~0ull || prev == k) { tab[h].slot = slot; return; }
+        } else {
+            const unsigned long long cur = tab[h].key;
+            if (cur == k) { if (tab[h].slot == slot) tab[h].slot = 0xFFFFFFFFu; return; }
+            if (cur == ~0ull) return;
+        }
+    }
+}
+
+__global__ __launch_bounds__(CULL_THREADS) void k_probe_cull(ProbeArgs Q, ScanCullArgs R) {
+    constexpr uint32_t WK = PROBE_KEYS, NIT = WK / 64u;
+    __shared__ uint32_t s_idx[CULL_THREADS / 64][WK], s_key[CULL_THREADS / 64][2u * WK];
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = blockIdx.x * (CULL_THREADS / 64) + wid;
+    const FrameParams &P = R.P;
+    if (wave < Q.nwaves && !R.spec->stale) {                                 // wave-uniform
+        uint32_t lv0 = 0;
+        for (uint32_t l = 1; l < (uint32_t)MAX_LEVELS; l++) if (wave >= Q.wave0[l]) lv0 = l;     // wave0[] is non-decreasing; levels without cells own no wave
+        const LevelBox ub = Q.ubox[lv0];
+        const uint32_t cells = ub.nx * ub.ny * ub.nz, t0 = (wave - Q.wave0[lv0]) * WK;
+        uint32_t *q_idx = s_idx[wid], *q_key = s_key[wid];
+        unsigned long long key[NIT]; HashEntry e[NIT]; uint32_t h[NIT]; bool valid[NIT];
+#pragma unroll
+        for (uint32_t it = 0; it < NIT; it++) {                             // all first probes in flight together
+            const uint32_t t = t0 + it * 64u + lane;
+            valid[it] = t < cells;
+            const uint32_t tt = valid[it] ? t : 0u, iy = tt % ub.ny, r = tt / ub.ny, iz = r % ub.nz, ix = r / ub.nz;
+            key[it] = pack_key(lv0, (ub.bx + ix) & 0xFFFFu, (ub.bz + iz) & 0xFFFFu, (ub.by + iy) & 0xFFFFu);
+            h[it] = key_hash(key[it], Q.mask);
+            e[it] = Q.tab[h[it]];
+        }
+        uint32_t qn = 0;
+#pragma unroll
+        for (uint32_t it = 0; it < NIT; it++) {
+            while (valid[it] && e[it].key != key[it] && e[it].key != ~0ull) { h[it] = (h[it] + 1u) & Q.mask; e[it] = Q.tab[h[it]]; }   // collisions: rare at load 0.5
+            const bool found = valid[it] && e[it].key == key[it] && e[it].slot != 0xFFFFFFFFu;
+            const uint64_t mk = __ballot(found);
+            if (found) { const uint32_t pos = qn + mbcnt(mk); q_idx[pos] = e[it].slot; q_key[2u * pos] = (uint32_t)key[it]; q_key[2u * pos + 1u] = (uint32_t)(key[it] >> 32); }
+            qn += (uint32_t)__popcll(mk);
+        }
+        if (qn && lv0 < P.max_level) {
+            const ItemSink K = R.K; FrameHeader *hdr = R.hdr;
+            const Aabb *__restrict__ cell_tight = R.cell_tight; const uint32_t *__restrict__ cell_begin = R.cell_begin, *__restrict__ cell_nlocal = R.cell_nlocal, *__restrict__ cell_nstatic = R.cell_nstatic, *__restrict__ cell_nghost = R.cell_nghost;
+            const uint8_t *__restrict__ cell_flags = R.cell_flags; uint32_t *__restrict__ cell_stamp = R.cell_stamp;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const LevelBox la = P.box[0][lv0], lb = P.box[1][lv0];
+            uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0, nv = 0;
+            // stage A (as k_scan_cull): exact box tests and the two cullers on the section's grid box; visible sections compacted in place
+#pragma unroll 1
+            for (uint32_t base = 0; base < qn; base += 64u) {
+                const uint32_t i = base + lane; const bool on = i < qn;
+                const uint32_t idx = q_idx[on ? i : 0u];
+                const uint32_t j2 = 2u * (on ? i : 0u);
+                const uint64_t k = (uint64_t)q_key[j2] | ((uint64_t)q_key[j2 + 1u] << 32);
+                bool is_cand = false;
+                const uint32_t mult = !on ? 0u : section_multiplicity_boxes(k, la, lb, P, &is_cand);
+                cand_acc += (on && is_cand) ? 1u : 0u;
+                const uint64_t vb = __ballot(mult != 0u);
+                if (mult) q_idx[nv + mbcnt(vb)] = idx | (mult << 30);
+                nv += (uint32_t)__popcll(vb);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // stage B (as k_scan_cull): the visible sections
+#pragma unroll 1
+            for (uint32_t vbase = 0; vbase < nv; vbase += EMIT_MAX * 64u) {
+                uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
+#pragma unroll
+                for (uint32_t j = 0; j < EMIT_MAX; j++) {
+                    const uint32_t i = vbase + j * 64u + lane;
+                    rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
+                    if (vbase + j * 64u < nv) {
+                        const bool on = i < nv;
+                        const uint32_t en = q_idx[on ? i : 0u], c = en & 0x3FFFFFFFu, mult = en >> 30;
+                        const uint8_t f = cell_flags[c];
+                        const Aabb t = cell_tight[c];
+                        const uint32_t nl = cell_nlocal[c], ns = cell_nstatic[c] + cell_nghost[c], cb = cell_begin[c];
+                        if (on && !(f & CF_PAD)) {
+                            cell_stamp[c] = (P.frame << 2) | mult;
+                            vis_map_acc += 1; vis_vec_acc += mult;
+                            float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
+                            bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);
+                            bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);
+                            rbv[j] = cb + (act ? 0u : nl);
+                            cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
+                            uint32_t mm = P.emit_duplicates ? mult : 1u;
+                            lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
+                        }
+                    }
+                }
+                emit_sections_multi(rbv, cntv, lodv, hdr, K, wave);
+            }
+            for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
+            if (lane == 0) {
+                uint32_t *cnt = hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u;
+                if (cand_acc) atomicAdd(cnt + 0, cand_acc);
+                if (vis_map_acc) { atomicAdd(cnt + 1, vis_map_acc); atomicAdd(cnt + 2, vis_vec_acc); }
+            }
+        }
+    }
+    // shared world sections and the frame parameters for the tick, as in k_scan_cull
+    const uint32_t nsh = R.S.n;
+    if (blockIdx.x * CULL_THREADS < nsh && !R.spec->stale) {
+        const SharedArrays S = R.S; const ItemSink K = R.K;
+        for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < nsh; s0 += gridDim.x * CULL_THREADS)
+            cull_shared_section(s0 + threadIdx.x, S, R.cell_key64, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
+    }
+    if (blockIdx.x == gridDim.x - 1u && !R.spec->stale) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
+        for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
+    }
+}
+
 // Shared world sections (render_flow.rs:808-866): emitted once per frame when some linking unique
 // section is visible and active; static members through the unique section that cached them.
 // Called by whole waves (lanes with s >= S.n contribute nothing).

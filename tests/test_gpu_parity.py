@@ -339,6 +339,50 @@ def test_frozen_static_cache_ghosts(R):
     p.close(); w.close()
 
 
+@pytest.mark.parametrize("seed,atomic", [(3, 64), (57, 16), (101, 64)])
+def test_probe_path_soak(R, seed, atomic):
+    """RE_CFG_PROBE: the visibility query through hash probes of the candidate cells (k_probe_cull) instead of the key stream --
+    same randomized soak as above (movers, change batches, emptied and re-created sections keep the key -> slot table in step),
+    every frame compared with the oracle, and the probe path must really have served the narrow frames"""
+    rng = np.random.default_rng(seed)
+    ents = R.synthetic.mixed_world(2500 + 500 * (seed % 4), seed=seed, spread=350.0 + 60.0 * (seed % 5), atomic=atomic)
+    ents["vel"] *= 8.0
+    p, w = build_pair(R, ents, atomic=atomic, flags=R._capi.CFG_PROBE | R._capi.CFG_PROBE_ALWAYS)
+    for f in range(40):
+        pos = (8192 + rng.uniform(-300, 300), 8192 + rng.uniform(-200, 200), 8192 + rng.uniform(-100, 500))
+        d = rng.uniform(-1, 1, 3); d[2] -= 1.5
+        cam = R.Camera(pos, tuple(d / np.linalg.norm(d)), float(rng.choice([150.0, 300.0, 2500.0])))   # narrow frusta probe, the wide one streams
+        oc = oracle_camera(cam)
+        if f % 3:
+            p.cull_and_pack(cam, asynchronous=True, copy=False); p.tick(0.04, asynchronous=True)
+            w.cull(oc); w.render(oc); w.tick(oc, 0.04)
+        else:
+            check_frame(R, p, w, cam, bool(f % 2))
+            n_o, oob_o = w.tick(oc, 0.04); t = p.tick(0.04)
+            assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        if f % 4 == 1:
+            ch = random_changes(R, ents, rng, 60, set())
+            w.apply_changes(ch.view(ro.CHANGE_DT)); p.apply_changes(ch)
+    p.wait()
+    check_sections(p, w)
+    st = p.stats()
+    assert st["n_probe_frames"] >= 10, st
+    check_frame(R, p, w, R.Camera((8192, 8192, 8400), (0, 0, -1), 200.0), True)
+    p.close(); w.close()
+
+
+def test_probe_path_static_lattice(R):
+    """configs[1] at reduced size through the probe path, and the same frames through the stream (RE_CULL_FORCE_STREAM): identical"""
+    ents = R.synthetic.lattice_world(cells_per_axis=40, first_cell=108)
+    p, w = build_pair(R, ents, flags=R._capi.CFG_PROBE | R._capi.CFG_PROBE_ALWAYS)
+    for pos, d, far in [((8192, 8192, 8192), (0, 0, -1), 500.0), ((7500.5, 8100.25, 9000), (0.6, 0.0, -0.8), 700.0), ((8192, 8192, 8300), (0.2, 0.3, -1), 400.0)]:
+        for dups in (False, True):
+            g, o = check_frame(R, p, w, R.Camera(pos, d, far), dups)
+            w.tick(oracle_camera(R.Camera(pos, d, far)), 0.016); p.tick(0.016)
+    assert p.stats()["n_probe_frames"] == 6 and g["total"] > 0
+    p.close(); w.close()
+
+
 def sorted_pairs(a):
     a = np.asarray(a, np.uint32).reshape(-1, 2)
     return a[np.lexsort((a[:, 1], a[:, 0]))]
