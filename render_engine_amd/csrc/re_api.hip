@@ -108,8 +108,8 @@ struct re_ctx {
     uint32_t ghost_cap = 0, n_ghost = 0; std::vector<uint32_t> h_ghost_gc; std::map<uint64_t, std::vector<uint32_t>> ghost_map;   // per section key: its ghost rows
     DevBuf<uint32_t> d_cell_nghost; std::vector<uint32_t> h_cell_ng;
     // collision broad phase (re_collide): lists allocated at the first call
-    uint32_t user_row = ROW_CELL_NONE; DevBuf<ColHeader> d_col_hdr; DevBuf<ColRegion> d_col_region; DevBuf<uint32_t> d_col_high; DevBuf<ColShared> d_col_shared; DevBuf<ColMoved> d_col_moved;
-    DevBuf<uint8_t> d_row_moved; DevBuf<unsigned long long> d_col_tab; DevBuf<uint2> d_col_pairs; uint32_t col_moved_cap = 0, col_tab_size = 0, col_pair_cap = 0; float t_collide = 0.f;
+    uint32_t user_row = ROW_CELL_NONE; DevBuf<ColHeader> d_col_hdr; DevBuf<ColRegion> d_col_region; DevBuf<uint32_t> d_col_high; DevBuf<ColShared> d_col_shared; DevBuf<ColMoved> d_col_moved; DevBuf<ColNear> d_col_near; ColHeader *h_col = nullptr, *d_hcol = nullptr; uint32_t col_calls = 0;
+    DevBuf<uint8_t> d_row_moved; DevBuf<unsigned long long> d_col_tab; DevBuf<uint2> d_col_pairs; uint32_t col_moved_cap = 0, col_tab_size = 0, col_pair_cap = 0;
     DevBuf<HashEntry> d_htab; uint32_t htab_mask = 0, htab_keys = 0; uint32_t probe_frames = 0;   // RE_CFG_PROBE: key -> slot table of the probe path (k_probe_cull)
     std::set<uint64_t> dormant_cached;                  // sections with ghosts that were cached when they were emptied: the reference's cache entry outlives the section and shows again when the section is re-created
     std::set<uint32_t> h_uncached;                       // rows made static after the static render cache froze: in the tree's static sets, not drawn
@@ -188,6 +188,7 @@ static void free_world(re_ctx *c) {
     if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
     if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
     if (c->h_spec) { (void)hipHostFree(c->h_spec); c->h_spec = nullptr; }
+    if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }
     c->d_spec.release(nullptr); c->pending.clear();
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false;
 }
@@ -1683,41 +1684,53 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
     hipStream_t st = c->stream;
     if (!c->d_col_hdr.p) {
         HIPCHK(c, c->d_col_hdr.alloc(1, nullptr)); HIPCHK(c, c->d_col_region.alloc(COL_REGION_CAP, nullptr)); HIPCHK(c, c->d_col_high.alloc(COL_REGION_CAP, nullptr));
-        HIPCHK(c, c->d_col_shared.alloc(COL_SHARED_CAP, nullptr));
+        HIPCHK(c, c->d_col_shared.alloc(COL_SHARED_CAP, nullptr)); HIPCHK(c, c->d_col_near.alloc(COL_REGION_CAP, nullptr));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_col), sizeof(ColHeader), hipHostMallocMapped)); memset(c->h_col, 0, sizeof(ColHeader));
+        HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hcol), c->h_col, 0));
     }
     if (!c->col_moved_cap) {
         c->col_moved_cap = (uint32_t)std::min<uint64_t>(((uint64_t)c->ndyn + 1u) * 8u, 1u << 20);
         c->col_tab_size = 64; while (c->col_tab_size < 2u * c->col_moved_cap) c->col_tab_size <<= 1;
         HIPCHK(c, c->d_col_moved.alloc(c->col_moved_cap, nullptr)); HIPCHK(c, c->d_col_tab.alloc((size_t)c->col_tab_size * 2, nullptr)); HIPCHK(c, c->d_row_moved.alloc(std::max(c->n, 1u), nullptr));
+        // cleared once; every call leaves them clean again (k_col_clear)
+        HIPCHK(c, hipMemsetAsync(c->d_row_moved.p, 0, std::max(c->n, 1u), c->stream)); HIPCHK(c, hipMemsetAsync(c->d_col_tab.p, 0xFF, (size_t)c->col_tab_size * 16, c->stream));
     }
     const uint32_t want = std::max(capacity, 1u << 12);
     if (want > c->col_pair_cap) { c->d_col_pairs.release(nullptr); HIPCHK(c, c->d_col_pairs.alloc(want, nullptr)); c->col_pair_cap = want; }
-    hipEvent_t e0 = c->ev[3], e1 = c->ev[4];
-    HIPCHK(c, hipEventRecord(e0, st));
     HIPCHK(c, hipMemsetAsync(c->d_col_hdr.p, 0, sizeof(ColHeader), st));
-    HIPCHK(c, hipMemsetAsync(c->d_row_moved.p, 0, std::max(c->n, 1u), st));
-    HIPCHK(c, hipMemsetAsync(c->d_col_tab.p, 0xFF, (size_t)c->col_tab_size * 16, st));
     unsigned long long *tab_key = c->d_col_tab.p, *tab_min = c->d_col_tab.p + c->col_tab_size;
     const uint32_t user_cell = c->user_row != ROW_CELL_NONE ? c->h_row_cell[c->user_row] : ROW_CELL_NONE;
-    if (c->ncells) hipLaunchKernelGGL(k_col_region, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_key.p, c->d_cell_tight.p, c->d_params.p, c->cfg.atomic_length,
-                                      c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP);
+    if (c->ncells && c->key32) hipLaunchKernelGGL(k_col_region<true>, dim3(((c->ncells + 3) / 4 + 255) / 256), dim3(256), 0, st, c->ncells, (const void *)c->d_cell_key32.p, (const uint32_t *)c->d_chunk_level.p,
+                                                  c->d_cell_tight.p, c->d_params.p, c->cfg.atomic_length, c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP);
+    else if (c->ncells) hipLaunchKernelGGL(k_col_region<false>, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, (const void *)c->d_cell_key.p, (const uint32_t *)nullptr,
+                                           c->d_cell_tight.p, c->d_params.p, c->cfg.atomic_length, c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP);
     if (c->nsh) hipLaunchKernelGGL(k_col_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_aabb.p, c->d_sh_cells.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_cell_key.p,
                                    c->d_params.p, c->d_col_hdr.p, c->d_col_shared.p, COL_SHARED_CAP);
-    hipLaunchKernelGGL(k_col_tops, dim3(COL_REGION_CAP / 256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP);
+    hipLaunchKernelGGL(k_col_tops, dim3(COL_REGION_CAP / 256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP,
+                       c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_col_near.p, COL_REGION_CAP);
     hipLaunchKernelGGL(k_col_moved, dim3((c->ndyn + 1 + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_cell.p, c->user_row, user_cell, row_arrays(c), c->d_cell_key.p,
                        c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_row_moved.p,
                        tab_key, tab_min, c->col_tab_size - 1u);
-    hipLaunchKernelGGL(k_col_pairs, dim3(1024), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_col_region.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP,
-                       row_arrays(c), c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_row_moved.p, tab_key, tab_min,
-                       c->col_tab_size - 1u, c->d_col_pairs.p, c->col_pair_cap);
+    hipLaunchKernelGGL(k_col_pairs, dim3(256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_col_near.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP,
+                       row_arrays(c), c->d_sh_begin.p, c->d_sh_nact.p, c->d_rows.p, c->d_row_moved.p, tab_min, c->d_col_pairs.p, c->col_pair_cap);
+    hipLaunchKernelGGL(k_col_clear, dim3((c->col_moved_cap + 255) / 256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_row_moved.p, tab_key, tab_min,
+                       c->d_hcol, ++c->col_calls);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(e1, st));
     ColHeader h{};
-    HIPCHK(c, hipMemcpyAsync(&h, c->d_col_hdr.p, sizeof h, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    (void)hipEventElapsedTime(&c->t_collide, e0, e1); c->t_collide *= 1000.f;
+    {   // completion: poll the counts the last kernel publishes in mapped host memory (a stream synchronise costs tens of microseconds)
+        const volatile uint32_t *flag = &c->h_col->pad[1];
+        const auto t0 = std::chrono::steady_clock::now(); bool done = false;
+        for (uint32_t spins = 0; !(done = (*flag == c->col_calls)); spins++)
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        if (!done) HIPCHK(c, hipStreamSynchronize(st));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h = *c->h_col;
+    }
     if (h.n_region > COL_REGION_CAP || h.n_high > COL_REGION_CAP) return c->fail(RE_E_CAPACITY, "re_collide: %u world sections around the camera exceed the region list (%u)", h.n_region, COL_REGION_CAP);
     if (h.n_shared > COL_SHARED_CAP) return c->fail(RE_E_CAPACITY, "re_collide: %u shared sections within the collision distance exceed the list (%u)", h.n_shared, COL_SHARED_CAP);
+    if (h.n_moved > c->col_moved_cap) {                                     // entries beyond the list were not cleaned up by k_col_clear
+        HIPCHK(c, hipMemset(c->d_row_moved.p, 0, std::max(c->n, 1u))); HIPCHK(c, hipMemset(c->d_col_tab.p, 0xFF, (size_t)c->col_tab_size * 16));
+    }
     if (h.n_moved > c->col_moved_cap) return c->fail(RE_E_CAPACITY, "re_collide: %u (section, moved entity) entries exceed the list (%u)", h.n_moved, c->col_moved_cap);
     const uint32_t nw = std::min(std::min(h.n_pairs, capacity), c->col_pair_cap);
     if (nw) HIPCHK(c, hipMemcpy(pairs, c->d_col_pairs.p, (size_t)nw * sizeof(re_collision), hipMemcpyDeviceToHost));

@@ -28,25 +28,47 @@ __device__ __forceinline__ bool aabb_intersect(const Aabb &a, const Aabb &b) {  
 
 // Pass 1: the existing sections whose grid cell comes within 200 + 4 sides of the camera (per level; every section the 200-unit
 // test can keep, every linking section of a shared section it can keep, and all their ancestors lie inside), with the result of
-// the reference's test on the stored section AABB (:553-558).
-__global__ __launch_bounds__(256) void k_col_region(uint32_t ncells, const uint64_t *__restrict__ cell_key, const Aabb *__restrict__ cell_tight, const FrameParams *__restrict__ Pp,
-                                                    uint32_t atomic, ColHeader *hdr, ColRegion *region, uint32_t region_cap, uint32_t *high, uint32_t high_cap) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ncells) return;
-    const uint64_t k = cell_key[i];
-    if (key_pad(k)) return;
+// the reference's test on the stored section AABB (:553-558).  K32: the compact stream keys of k_scan_cull (x:9|z:9|y:9 with guard
+// bits, the level of a 512-key chunk in chunk_level), four per lane.
+__device__ __forceinline__ void region_consider(uint64_t k, uint32_t slot, const Aabb *__restrict__ cell_tight, const FrameParams *__restrict__ Pp, uint32_t atomic,
+                                                ColHeader *hdr, ColRegion *region, uint32_t region_cap, uint32_t *high, uint32_t high_cap) {
     const uint32_t level = (uint32_t)(k >> 48);
     if (level >= 24u) return;
     const float side = (float)atomic * (float)(1u << level), reach = COLLISION_DISTANCE + 4.0f * side;
     const float x0 = side * (float)((uint32_t)(k >> 32) & 0xFFFFu), z0 = side * (float)((uint32_t)(k >> 16) & 0xFFFFu), y0 = side * (float)((uint32_t)k & 0xFFFFu);
     const float cx = Pp->cam[0], cy = Pp->cam[1], cz = Pp->cam[2];
     if (x0 > cx + reach || x0 + side < cx - reach || y0 > cy + reach || y0 + side < cy - reach || z0 > cz + reach || z0 + side < cz - reach) return;
-    const Aabb t = cell_tight[i];
-    ColRegion e; e.key = k; e.slot = i; e.near = !(distance_to_aabb(t, cx, cy, cz) > COLLISION_DISTANCE) ? 1u : 0u; e.top = k;
+    const Aabb t = cell_tight[slot];
+    ColRegion e; e.key = k; e.slot = slot; e.near = !(distance_to_aabb(t, cx, cy, cz) > COLLISION_DISTANCE) ? 1u : 0u; e.top = k;
     const uint32_t at = atomicAdd(&hdr->n_region, 1u);
     if (at < region_cap) region[at] = e;
     if (level && at < region_cap) { const uint32_t h = atomicAdd(&hdr->n_high, 1u); if (h < high_cap) high[h] = at; }
 }
+template <bool K32>
+__global__ __launch_bounds__(256) void k_col_region(uint32_t ncells, const void *__restrict__ keys, const uint32_t *__restrict__ chunk_level, const Aabb *__restrict__ cell_tight,
+                                                    const FrameParams *__restrict__ Pp, uint32_t atomic, ColHeader *hdr, ColRegion *region, uint32_t region_cap, uint32_t *high, uint32_t high_cap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if constexpr (K32) {
+        const uint32_t base = i * 4u;
+        if (base >= ncells) return;
+        const uint4 q = reinterpret_cast<const uint4 *>(keys)[i];            // the compact array is padded to whole quads with padding keys
+        const uint32_t level = chunk_level[base / WAVE_KEYS32] & (MAX_LEVELS - 1);
+        const uint32_t v4[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (uint32_t h = 0; h < 4; h++) {
+            const uint32_t v = v4[h];
+            if ((int32_t)v < 0 || base + h >= ncells) continue;             // padding / spare slot
+            region_consider(pack_key(level, (v >> 20) & 0x1FFu, (v >> 10) & 0x1FFu, v & 0x1FFu), base + h, cell_tight, Pp, atomic, hdr, region, region_cap, high, high_cap);
+        }
+    } else {
+        if (i >= ncells) return;
+        const uint64_t k = reinterpret_cast<const uint64_t *>(keys)[i];
+        if (key_pad(k)) return;
+        region_consider(k, i, cell_tight, Pp, atomic, hdr, region, region_cap, high, high_cap);
+    }
+}
+template __global__ void k_col_region<false>(uint32_t, const void *, const uint32_t *, const Aabb *, const FrameParams *, uint32_t, ColHeader *, ColRegion *, uint32_t, uint32_t *, uint32_t);
+template __global__ void k_col_region<true>(uint32_t, const void *, const uint32_t *, const Aabb *, const FrameParams *, uint32_t, ColHeader *, ColRegion *, uint32_t, uint32_t *, uint32_t);
 
 // the shared sections the 200-unit test keeps (:561-566), with their linking sections
 __global__ __launch_bounds__(256) void k_col_shared(uint32_t nsh, const Aabb *__restrict__ sh_aabb, const int32_t *__restrict__ sh_cells, const uint32_t *__restrict__ sh_nact,
@@ -67,21 +89,32 @@ __device__ __forceinline__ uint64_t top_of(uint64_t k, const ColRegion *region, 
     for (uint32_t h = 0; h < nhigh; h++) { const uint64_t a = region[high[h]].key; if ((a >> 48) > (top >> 48) && key_covers(a, k)) top = a; }
     return top;
 }
-__global__ __launch_bounds__(256) void k_col_tops(ColHeader *hdr, ColRegion *region, uint32_t region_cap, const uint32_t *high, uint32_t high_cap, ColShared *shared, uint32_t shared_cap) {
+// ... and the short list the pair kernel walks: the near sections that hold non-static entities
+__global__ __launch_bounds__(256) void k_col_tops(ColHeader *hdr, ColRegion *region, uint32_t region_cap, const uint32_t *high, uint32_t high_cap, ColShared *shared, uint32_t shared_cap,
+                                                  const uint32_t *__restrict__ cell_begin, const uint32_t *__restrict__ cell_nlocal, ColNear *near, uint32_t near_cap) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nr = min(hdr->n_region, region_cap), nh = min(hdr->n_high, high_cap), ns = min(hdr->n_shared, shared_cap);
-    if (i < nr) region[i].top = top_of(region[i].key, region, high, nh);
+    if (i < nr) {
+        const ColRegion x = region[i];
+        const uint32_t nl = x.near ? cell_nlocal[x.slot] : 0u;
+        if (nl) {
+            ColNear e; e.top = top_of(x.key, region, high, nh); e.begin = cell_begin[x.slot]; e.n = nl;
+            const uint32_t at = atomicAdd(&hdr->n_near, 1u);
+            if (at < near_cap) near[at] = e;
+        }
+    }
     if (i < ns) for (uint32_t k = 0; k < shared[i].nk; k++) shared[i].top[k] = top_of(shared[i].top[k], region, high, nh);
 }
 
 // 64-bit open-addressing table: section key -> smallest order word of the moved entities that touch it
 __device__ __forceinline__ uint32_t col_hash(uint64_t x, uint32_t mask) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; return (uint32_t)x & mask; }
-__device__ __forceinline__ void first_touch_insert(unsigned long long *tab_key, unsigned long long *tab_min, uint32_t mask, uint64_t key, unsigned long long order) {
+__device__ __forceinline__ uint32_t first_touch_insert(unsigned long long *tab_key, unsigned long long *tab_min, uint32_t mask, uint64_t key, unsigned long long order) {
     uint32_t h = col_hash(key, mask);
     for (uint32_t probe = 0; probe <= mask; probe++, h = (h + 1u) & mask) {
         const unsigned long long prev = atomicCAS(&tab_key[h], ~0ull, (unsigned long long)key);
-        if (prev == ~0ull || prev == key) { atomicMin(&tab_min[h], order); return; }
+        if (prev == ~0ull || prev == key) { atomicMin(&tab_min[h], order); return h; }
     }
+    return 0xFFFFFFFFu;
 }
 __device__ __forceinline__ unsigned long long first_touch_lookup(const unsigned long long *tab_key, const unsigned long long *tab_min, uint32_t mask, uint64_t key) {
     uint32_t h = col_hash(key, mask);
@@ -129,17 +162,17 @@ __global__ __launch_bounds__(256) void k_col_moved(uint32_t ndyn, const uint32_t
     row_moved[r] = 1;
     const unsigned long long order = is_user ? (1ull << 32) : (unsigned long long)R.id[r];   // ascending EntityId, the user entity last
     if (!(rc & ROW_CELL_SHARED)) {
+        const uint32_t ts = first_touch_insert(tab_key, tab_min, tab_mask, cell_key[rc], order);
         const uint32_t at = atomicAdd(&hdr->n_moved, 1u);
-        if (at < moved_cap) { ColMoved m; m.key = cell_key[rc]; m.row = r; m.info = mult << 1; m.order = order; moved[at] = m; }
-        first_touch_insert(tab_key, tab_min, tab_mask, cell_key[rc], order);
+        if (at < moved_cap) { ColMoved m; m.key = cell_key[rc]; m.row = r; m.info = mult << 1; m.order = order; m.tslot = ts; moved[at] = m; }
     } else {
         const uint32_t s = rc & ~ROW_CELL_SHARED;
         for (int k = 0; k < 8; k++) {
             const int32_t c = sh_cells[s * 8 + k];
             if (c < 0) continue;
+            const uint32_t ts = first_touch_insert(tab_key, tab_min, tab_mask, cell_key[c], order);
             const uint32_t at = atomicAdd(&hdr->n_moved, 1u);
-            if (at < moved_cap) { ColMoved m; m.key = cell_key[c]; m.row = r; m.info = (mult << 1) | 1u; m.order = order; moved[at] = m; }
-            first_touch_insert(tab_key, tab_min, tab_mask, cell_key[c], order);
+            if (at < moved_cap) { ColMoved m; m.key = cell_key[c]; m.row = r; m.info = (mult << 1) | 1u; m.order = order; m.tslot = ts; moved[at] = m; }
         }
     }
 }
@@ -160,24 +193,22 @@ __device__ __forceinline__ void col_test(uint32_t me_row, uint32_t me_id, const 
         if (!self) col_emit(hdr, pairs, cap, oid, me_id);                    // both directions for an entity that did not move (:640-647)
     }
 }
-__global__ __launch_bounds__(256) void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, const ColRegion *region, uint32_t region_cap, const ColShared *shared,
-                                                   uint32_t shared_cap, RowArrays R, const uint32_t *__restrict__ cell_begin, const uint32_t *__restrict__ cell_nlocal,
-                                                   const uint32_t *__restrict__ sh_begin, const uint32_t *__restrict__ sh_nact, const uint32_t *__restrict__ sh_nstat,
-                                                   const uint32_t *__restrict__ rows, const uint8_t *__restrict__ row_moved, const unsigned long long *tab_key,
-                                                   const unsigned long long *tab_min, uint32_t tab_mask, uint2 *pairs, uint32_t pair_cap) {
+__global__ __launch_bounds__(256) void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, const ColNear *near, uint32_t near_cap, const ColShared *shared,
+                                                   uint32_t shared_cap, RowArrays R, const uint32_t *__restrict__ sh_begin, const uint32_t *__restrict__ sh_nact,
+                                                   const uint32_t *__restrict__ rows, const uint8_t *__restrict__ row_moved, const unsigned long long *tab_min,
+                                                   uint2 *pairs, uint32_t pair_cap) {
     const uint32_t lane = threadIdx.x & 63u, nm = min(hdr->n_moved, moved_cap);
-    const uint32_t nr = min(hdr->n_region, region_cap), ns = min(hdr->n_shared, shared_cap);
+    const uint32_t nn = min(hdr->n_near, near_cap), ns = min(hdr->n_shared, shared_cap);
     for (uint32_t e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); e < nm; e += gridDim.x * (blockDim.x >> 6)) {   // wave-uniform loop
         const ColMoved m = moved[e];
         // the entity that creates a section's entry through a Shared lookup is not pushed into it (:488-498)
-        if ((m.info & 1u) && first_touch_lookup(tab_key, tab_min, tab_mask, m.key) == m.order) continue;
+        if ((m.info & 1u) && m.tslot != 0xFFFFFFFFu && tab_min[m.tslot] == m.order) continue;
         const uint32_t mult = (m.info >> 1) & 3u, me_id = R.id[m.row];
         const Aabb a = R.aabb[m.row];
-        for (uint32_t i = lane; i < nr; i += 64u) {
-            const ColRegion x = region[i];
-            if (!x.near || !key_covers(x.top, m.key)) continue;
-            const uint32_t b = cell_begin[x.slot], n = cell_nlocal[x.slot];
-            for (uint32_t k = 0; k < n; k++) col_test(m.row, me_id, a, rows[b + k], mult, R, row_moved, hdr, pairs, pair_cap);
+        for (uint32_t i = lane; i < nn; i += 64u) {
+            const ColNear x = near[i];
+            if (!key_covers(x.top, m.key)) continue;
+            for (uint32_t k = 0; k < x.n; k++) col_test(m.row, me_id, a, rows[x.begin + k], mult, R, row_moved, hdr, pairs, pair_cap);
         }
         for (uint32_t i = lane; i < ns; i += 64u) {
             const ColShared s = shared[i];
@@ -188,6 +219,20 @@ __global__ __launch_bounds__(256) void k_col_pairs(ColHeader *hdr, const ColMove
             for (uint32_t k = 0; k < n; k++) col_test(m.row, me_id, a, rows[b + k], mult, R, row_moved, hdr, pairs, pair_cap);
         }
     }
+}
+
+// leaves the "moved" row bytes and the first-touch table clean for the next call (instead of clearing 10 MB + the table every time)
+__global__ __launch_bounds__(256) void k_col_clear(const ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, uint8_t *row_moved, unsigned long long *tab_key, unsigned long long *tab_min,
+                                                   ColHeader *h_hdr, uint32_t call) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {                                                            // the counts, into mapped host memory: the host polls pad[1] instead of synchronising the stream
+        ColHeader h = *hdr; h.pad[0] = 0; h.pad[1] = 0;
+        *h_hdr = h; __threadfence_system(); h_hdr->pad[1] = call;
+    }
+    if (i >= min(hdr->n_moved, moved_cap)) return;
+    const ColMoved m = moved[i];
+    row_moved[m.row] = 0;
+    if (m.tslot != 0xFFFFFFFFu) { tab_key[m.tslot] = ~0ull; tab_min[m.tslot] = ~0ull; }
 }
 
 }  // namespace re

@@ -143,22 +143,27 @@ __global__ void k_hash_patch(uint32_t m, const Pair64 *slot_newkey, const uint64
 __global__ void k_probe_cull(ProbeArgs Q, ScanCullArgs A);
 // collision broad phase (re_collide.hip)
 constexpr float COLLISION_DISTANCE = 200.0f;           // handle_collisions keeps sections within this distance of the camera (logic_flow.rs:553-566)
-struct ColHeader { uint32_t n_region, n_high, n_shared, n_moved, n_pairs, pad[3]; };
+struct ColHeader { uint32_t n_region, n_high, n_shared, n_moved, n_pairs, n_near, pad[2]; };
 struct ColRegion { uint64_t key, top; uint32_t slot, near; };            // an existing section around the camera; top: its topmost existing ancestor
+struct ColNear { uint64_t top; uint32_t begin, n; };                      // a section within the distance that holds non-static entities: its rows in the pool
 struct ColShared { uint64_t top[8]; uint32_t s, nk; };                    // a shared section within the distance; top[k]: topmost ancestor of its k-th linking section
-struct ColMoved { uint64_t key; unsigned long long order; uint32_t row, info; };   // (section, moved entity); info bit 0: Shared lookup, bits 1-2: listings
-__global__ void k_col_region(uint32_t ncells, const uint64_t *cell_key, const Aabb *cell_tight, const FrameParams *P, uint32_t atomic, ColHeader *hdr, ColRegion *region,
-                             uint32_t region_cap, uint32_t *high, uint32_t high_cap);
+struct ColMoved { uint64_t key; unsigned long long order; uint32_t row, info, tslot, pad; };   // (section, moved entity); info bit 0: Shared lookup, bits 1-2: listings; tslot: its first-touch table entry
+template <bool K32> __global__ void k_col_region(uint32_t ncells, const void *keys, const uint32_t *chunk_level, const Aabb *cell_tight, const FrameParams *P, uint32_t atomic,
+                                                 ColHeader *hdr, ColRegion *region, uint32_t region_cap, uint32_t *high, uint32_t high_cap);
+extern template __global__ void k_col_region<false>(uint32_t, const void *, const uint32_t *, const Aabb *, const FrameParams *, uint32_t, ColHeader *, ColRegion *, uint32_t, uint32_t *, uint32_t);
+extern template __global__ void k_col_region<true>(uint32_t, const void *, const uint32_t *, const Aabb *, const FrameParams *, uint32_t, ColHeader *, ColRegion *, uint32_t, uint32_t *, uint32_t);
 __global__ void k_col_shared(uint32_t nsh, const Aabb *sh_aabb, const int32_t *sh_cells, const uint32_t *sh_nact, const uint32_t *sh_nstat, const uint64_t *cell_key,
                              const FrameParams *P, ColHeader *hdr, ColShared *out, uint32_t cap);
-__global__ void k_col_tops(ColHeader *hdr, ColRegion *region, uint32_t region_cap, const uint32_t *high, uint32_t high_cap, ColShared *shared, uint32_t shared_cap);
+__global__ void k_col_tops(ColHeader *hdr, ColRegion *region, uint32_t region_cap, const uint32_t *high, uint32_t high_cap, ColShared *shared, uint32_t shared_cap,
+                           const uint32_t *cell_begin, const uint32_t *cell_nlocal, ColNear *near, uint32_t near_cap);
 __global__ void k_col_moved(uint32_t ndyn, const uint32_t *dyn_row, const uint32_t *dyn_cell, uint32_t user_row, uint32_t user_cell, RowArrays R, const uint64_t *cell_key,
                             const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells, const Aabb *sh_aabb, const FrameParams *P, ColHeader *hdr,
                             ColMoved *moved, uint32_t moved_cap, uint8_t *row_moved, unsigned long long *tab_key, unsigned long long *tab_min, uint32_t tab_mask);
-__global__ void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, const ColRegion *region, uint32_t region_cap, const ColShared *shared, uint32_t shared_cap,
-                            RowArrays R, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat,
-                            const uint32_t *rows, const uint8_t *row_moved, const unsigned long long *tab_key, const unsigned long long *tab_min, uint32_t tab_mask,
+__global__ void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, const ColNear *near, uint32_t near_cap, const ColShared *shared, uint32_t shared_cap,
+                            RowArrays R, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *rows, const uint8_t *row_moved, const unsigned long long *tab_min,
                             uint2 *pairs, uint32_t pair_cap);
+__global__ void k_col_clear(const ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, uint8_t *row_moved, unsigned long long *tab_key, unsigned long long *tab_min,
+                            ColHeader *h_hdr, uint32_t call);
 struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)
