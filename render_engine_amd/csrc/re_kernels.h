@@ -54,6 +54,7 @@ struct FrameParams {
     LevelBox box[2][MAX_LEVELS];            // [0] logic box, [1] render box, per level
 };
 constexpr uint32_t COUNTER_SHARDS = 64;
+constexpr uint32_t PACK_STAGED_GROUPS = 256;   // k_pack_small stages up to this many InstanceRanges in LDS before one wave writes them to the host
 constexpr uint32_t CURSOR_SHARDS = 8;
 struct FrameHeader {
     unsigned long long cursors[CURSOR_SHARDS * 8];   // one per 64-byte line; low 32: emitting sections, high 32: instances.  Sharded by

@@ -821,6 +821,12 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     uint32_t my_slot = 0xFFFFFFFFu, my_row = 0;
     if (tid < 64u && my_j0 + tid < K.seg_cap) { const uint32_t ii = my_shard * K.seg_cap + my_j0 + tid; my_slot = K.item_slot[ii]; my_row = K.item_row[ii]; }
     if (my_row >= nrows) my_row = 0;                          // a stale entry of an earlier world
+    // workgroup 0 reports the frame: its counter shards travel with this first round trip, and its InstanceRange table is staged in
+    // LDS so that one wave writes everything the host reads (table, counts, "frame done") behind a single system-scope fence
+    __shared__ InstanceRange s_rng[PACK_STAGED_GROUPS];
+    const bool staged = nslots <= PACK_STAGED_GROUPS;         // at most nslots groups
+    uint32_t fc_a = 0, fc_b = 0, fc_c = 0;
+    if (blockIdx.x == 0 && wid == 0 && lane < COUNTER_SHARDS) { const uint32_t *cnt = hdr->counters + lane * 16u; fc_a = cnt[0]; fc_b = cnt[1]; fc_c = cnt[2]; }
     for (uint32_t i = tid; i < 2u * nslots && nslots <= LDS_HIST_SLOTS; i += NT) s_dyn[i] = 0;
     if (tid == 0) { s_carry = 0; s_gcarry = 0; }
     if (tid < 64u) s_row[tid] = my_row;
@@ -867,7 +873,10 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
             uint32_t gidx = s_gcarry + wcn + incn - nz;
             if (i < nslots) {
                 s_tot[i] = begin;
-                if (v && blockIdx.x == 0) { uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v; A.ranges[gidx] = r; }
+                if (v && blockIdx.x == 0) {
+                    uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
+                    if (staged) s_rng[gidx] = r; else A.ranges[gidx] = r;
+                }
             }
             __syncthreads();
             if (tid == NT - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
@@ -877,10 +886,17 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     if (blockIdx.x == 0) {
         // the host polls done_frame while this kernel runs: every wave's InstanceRange stores must have left for host memory before
         // lane 0 publishes it (a workgroup barrier alone does not wait for the other waves' stores in flight)
-        __threadfence_system();
+        if (!staged) __threadfence_system();
         __syncthreads();
         if (wid == 0) {
-            FrameCounts fc = load_frame_counts(hdr);
+            for (int d = 32; d >= 1; d >>= 1) { fc_a += __shfl_xor(fc_a, d, 64); fc_b += __shfl_xor(fc_b, d, 64); fc_c += __shfl_xor(fc_c, d, 64); }
+            FrameCounts fc; fc.n_candidates = fc_a; fc.n_vis_map = fc_b; fc.n_vis_vec = fc_c;
+            if (staged && !overflow) {                          // the table, by this wave alone
+                const uint32_t nw = s_gcarry * (uint32_t)(sizeof(InstanceRange) / 4u);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(s_rng); uint32_t *dst = reinterpret_cast<uint32_t *>(A.ranges);
+                for (uint32_t w = lane; w < nw; w += 64u) dst[w] = src[w];
+                __threadfence_system();                         // every lane's table words before lane 0 publishes
+            }
             if (lane == 0) {
                 HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;   // (never read the mapped host struct: a PCIe round trip)
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
