@@ -335,6 +335,7 @@ def test_frozen_static_cache_ghosts(R):
     apply([(C.CHANGE_WAKE_UP, i, 0, 0, (0, 0, 0, 0)) for i in woke[:10]] + [(C.CHANGE_MODIFY, i, C.C_SCALE, 0, (2.0, 2.0, 2.0, 0)) for i in woke[:10]]
           + [(C.CHANGE_MODIFY, i, C.C_ROTATION, 0, (0.0, 1.0, 0.0, 0.7)) for i in dele[:5] + woke[5:15]])
     for dups in (False, True): frame(dups)
+    check_frame(R, p, w, cam, True, force_large_pack=True)      # ghosts and hidden rows through the multi-kernel pack as well
     check_entities(R, p, w, ents[::7])
     p.close(); w.close()
 
