@@ -58,6 +58,9 @@ struct Carry {
     std::set<uint64_t> ghost_touched;                   // sections that received a ghost instance: their row segment is rewritten, nothing else changes
 };
 
+constexpr uint32_t NUM_FRAME_HEADERS = 3;   // see frame_header()
+struct re_ctx;
+static int flush_deferred_pack(re_ctx *c);
 struct re_ctx {
     re_config cfg{};
     int device = 0;
@@ -138,6 +141,7 @@ struct re_ctx {
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
+    bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
     re_tick_result last_tick{};
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0; bool k1_timing = false;   // per-launch timing of k_scan_cull
@@ -190,7 +194,7 @@ static void free_world(re_ctx *c) {
     if (c->h_spec) { (void)hipHostFree(c->h_spec); c->h_spec = nullptr; }
     if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }
     c->d_spec.release(nullptr); c->pending.clear();
-    c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false;
+    c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false; c->deferred_pack = false;
 }
 
 extern "C" void re_destroy(re_ctx *c) {
@@ -612,10 +616,11 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
     c->item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
     c->list_cap = std::max(std::max(c->ndyn, std::min(n, 65536u)), 1u);   // movers of one tick (dynamic rows) or of one change batch (any row)
-    HIPCHK(c, c->d_item_row.alloc(c->item_cap, acct)); HIPCHK(c, c->d_item_slot.alloc(c->item_cap, acct));
-    HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 4)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 4));   // the pack reads speculatively past the cursors
+    // two instance lists, alternating by frame: a deferred pack (RE_CULL_DEFER_PACK) reads the list of frame f while the scan of frame f + 1 fills the other
+    HIPCHK(c, c->d_item_row.alloc((size_t)c->item_cap * 2, acct)); HIPCHK(c, c->d_item_slot.alloc((size_t)c->item_cap * 2, acct));
+    HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 8)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 8));   // the pack reads speculatively past the cursors
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
-    HIPCHK(c, c->d_hdr.alloc(2, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
+    HIPCHK(c, c->d_hdr.alloc(NUM_FRAME_HEADERS, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_res), sizeof(HostResult), hipHostMallocMapped));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocMapped));
     HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_th), sizeof(TickHeader), hipHostMallocMapped));
@@ -626,7 +631,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hspec), c->h_spec, 0));
     memset(c->h_spec, 0, sizeof(SpecState)); HIPCHK(c, c->d_spec.alloc(1, nullptr)); HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
     memset(c->h_res, 0, sizeof(HostResult)); memset(c->h_th, 0, sizeof(TickHeader));
-    HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, 2 * sizeof(FrameHeader), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->frame = 0; c->th_clean = true; c->pred_total = 0;
@@ -755,8 +760,12 @@ static void fill_visible(re_ctx *c, re_visible *out) {
     out->d_matrices = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
 }
 
-static ItemSink item_sink(re_ctx *c) {
-    ItemSink K; K.item_row = c->d_item_row.p; K.item_slot = c->d_item_slot.p; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
+// Frame headers rotate through three buffers: frame f accumulates into header f % 3, its pack reads it and clears header (f + 2) % 3 for
+// the frame after next -- so the pack of frame f may run inside the launch of frame f + 1, which is filling header (f + 1) % 3.
+static FrameHeader *frame_header(re_ctx *c, uint32_t frame) { return c->d_hdr.p + frame % NUM_FRAME_HEADERS; }
+static ItemSink item_sink(re_ctx *c, uint32_t frame) {
+    const size_t half = (size_t)(frame & 1u) * c->item_cap;
+    ItemSink K; K.item_row = c->d_item_row.p + half; K.item_slot = c->d_item_slot.p + half; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
     K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; return K;
 }
 static SharedArrays shared_arrays(re_ctx *c) {
@@ -767,6 +776,7 @@ static SharedArrays shared_arrays(re_ctx *c) {
 // multi-kernel pack for large visible sets: count -> scan -> scatter
 static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next) {
     const uint32_t nshards = CURSOR_SHARDS, seg_cap = c->item_cap / nshards;
+    const ItemSink KS = item_sink(c, c->frame);
     hipStream_t st = c->stream;
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
@@ -774,16 +784,17 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next)
     size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
     // few workgroups for the count: every workgroup flushes its LDS histogram with one global atomic per non-empty group,
     // and a handful of hot (model, LOD) groups saturate near 88 atomics/us per address
-    hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, c->d_item_slot.p, nshards, seg_cap, c->d_group_count.p, c->nslots, c->d_spec.p);
+    hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, KS.item_slot, nshards, seg_cap, c->d_group_count.p, c->nslots, c->d_spec.p);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
                        c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p, c->ext_out_count, c->ext_out_ids ? c->ext_out_cap : c->out_cap, c->frame);
-    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, c->d_item_row.p, c->d_item_slot.p, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
+    hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, KS.item_row, KS.item_slot, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
                        c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->d_spec.p);
     HIPCHK(c, hipGetLastError());
     return RE_OK;
 }
 
 static int finish_cull(re_ctx *c, re_visible *out) {
+    { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     // Fast completion: the pack publishes "frame done" into mapped host memory after the group table and the counters; polling that
     // word costs a PCIe write's latency instead of the driver's stream-synchronise wake-up.  The packed instances are device
     // resident, and whatever reads them next is ordered behind the pack on the stream.  Not when a tick that may leave the tree
@@ -800,7 +811,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     c->cull_inflight = false;
     if (c->h_res->overflow == 1) {
         // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
-        int rc = launch_pack_large(c, c->d_hdr.p + (c->frame & 1u), c->d_hdr.p + ((c->frame + 1u) & 1u));
+        int rc = launch_pack_large(c, frame_header(c, c->frame), frame_header(c, c->frame + 2u));
         if (rc != RE_OK) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -817,13 +828,24 @@ static int finish_cull(re_ctx *c, re_visible *out) {
 }
 
 // enqueue one frame's cull + pack (no synchronisation)
+// A pack deferred by RE_CULL_DEFER_PACK that no later frame picked up: launch it on its own (anything that needs the frame's result, or
+// is about to change what the pack reads, calls this first).
+static int flush_deferred_pack(re_ctx *c) {
+    if (!c->deferred_pack) return RE_OK;
+    c->deferred_pack = false;
+    const FusedPack &F = c->deferred;
+    hipLaunchKernelGGL(k_pack_small, dim3(c->deferred_grid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, c->stream, F.hdr, F.hdr_next, F.th, F.A, F.K, F.nrows);
+    HIPCHK(c, hipGetLastError());
+    return RE_OK;
+}
+
 static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     hipStream_t st = c->stream;
     if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
     const FrameParams &P = c->P;
-    FrameHeader *hdr = c->d_hdr.p + (c->frame & 1u), *hdr_next = c->d_hdr.p + ((c->frame + 1u) & 1u);
+    FrameHeader *hdr = frame_header(c, c->frame), *hdr_next = frame_header(c, c->frame + 2u);     // the pack clears the header of the frame after next
     c->timed_frame = !(flags & RE_CULL_ASYNC);
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (c->dirty_pending) {
@@ -843,7 +865,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
     ScanCullArgs SA; SA.B = c->PB; SA.B32 = c->PB32; SA.cell_key64 = c->d_cell_key.p; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p; SA.cell_nghost = c->d_cell_nghost.p;
-    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
+    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c, c->frame); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
     static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
 #ifdef RE_EXP_STAMPS
     if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 8, nullptr));
@@ -881,13 +903,25 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         }
     }
     const ScanSpans SP = probed ? ScanSpans{} : candidate_spans(c, scan_grid);
+    // a pack deferred by the previous frame rides in the first workgroups of this frame's scan (one launch per frame); any other
+    // kind of launch here sends it off on its own first
+    const bool fuse = c->deferred_pack && !probed && c->deferred_grid < (1u << 20);
+    if (c->deferred_pack && !fuse) { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
+    const size_t fused_lds = (size_t)std::max(c->nslots, 1u) * 8;
     if (probed) {}
+    else if (fuse && c->key32)
+        hipExtLaunchKernelGGL(k_scan_cull_fused<true>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n | (c->deferred_grid << 8),
+                              SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
+    else if (fuse)
+        hipExtLaunchKernelGGL(k_scan_cull_fused<false>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (c->deferred_grid << 8),
+                              SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
     else if (c->key32)
         hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     else
         hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
+    if (fuse) { c->deferred_pack = false; c->n_fused_frames++; }
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
@@ -896,7 +930,13 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         // makes the pack decline (overflow) and the frame is redone through the large path
         uint32_t per_shard = (c->pred_total + c->pred_total / 2u) / CURSOR_SHARDS + 64u;
         uint32_t pgrid = CURSOR_SHARDS * std::min(32u, (per_shard + 63u) / 64u);
-        hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c), c->n + c->ghost_cap);
+        // RE_CULL_DEFER_PACK: in a world without dynamic entities nothing changes what the pack reads before the next visibility query,
+        // so an asynchronous frame may leave its pack to the launch of the next one (k_scan_cull_fused)
+        if ((flags & RE_CULL_DEFER_PACK) && (flags & RE_CULL_ASYNC) && c->ndyn == 0 && !c->dirty_pending) {
+            FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->frame); F.nrows = c->n + c->ghost_cap;
+            c->deferred = F; c->deferred_grid = pgrid; c->deferred_pack = true;
+        } else
+            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->frame), c->n + c->ghost_cap);
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;
@@ -1435,6 +1475,7 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
 // Synchronise and settle speculation: when a tick raised `stale` (entities changed section or left the world), everything enqueued
 // after it has cancelled itself; patch the tree from that tick's lists, then replay the cancelled calls (which may go stale again).
 static int resolve(re_ctx *c) {
+    { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->tick_inflight && c->ndyn && c->h_th) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 16, hipMemcpyDeviceToHost));   // n_changed, n_rebucket, n_oob of the last tick that ran
     while (c->h_spec && c->h_spec->stale) {
@@ -1449,7 +1490,7 @@ static int resolve(re_ctx *c) {
         for (const auto &pc : c->pending) { if (after) replay.push_back(pc); else if (pc.kind == 1 && pc.frame == sf) after = true; }
         c->pending.clear();
         if (!replay.empty()) {
-            HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, 2 * sizeof(FrameHeader), c->stream)); c->th_clean = false;
+            HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream)); c->th_clean = false;
             c->cull_inflight = false;
             uint32_t *keep_ids = c->ext_out_ids; float *keep_mats = c->ext_out_mats; uint32_t keep_cap = c->ext_out_cap, *keep_cnt = c->ext_out_count;
             for (const auto &pc : replay) {
@@ -1817,7 +1858,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames;
     return RE_OK;
 }
 

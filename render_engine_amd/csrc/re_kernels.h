@@ -122,6 +122,11 @@ template <bool K32> __global__ void k_scan_cull(const void *keys, uint32_t ncell
 extern template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 extern template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows);
+struct FusedPack { FrameHeader *hdr, *hdr_next; TickHeader *th; PackArgs A; ItemSink K; uint32_t nrows, pad; };   // the previous frame's pack, carried by the next frame's launch
+template <bool K32> __global__ void k_scan_cull_fused(const void *keys, uint32_t ncells, uint32_t nsp_npack, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
+                                                      uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A, FusedPack F);
+extern template __global__ void k_scan_cull_fused<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
+extern template __global__ void k_scan_cull_fused<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots, const SpecState *spec);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,

@@ -281,9 +281,12 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
 // wave chunks on the host, so the level of the first key is the level of every real key of the wave; keys of any other
 // level fail the packed test by themselves.  Frame parameters live in the kernel-argument segment and are read with
 // scalar loads by candidate waves only.
+// The body of the scan + cull kernel for workgroup `bid` of `nblk` (the kernel's own grid, or the scan part of the fused launch below).
+// Force-inlined into its kernels: `A` is the kernel's by-value argument, and the kernel-argument offsets used below are those of the
+// common leading signature.
 template <bool K32>
-__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
-                                                            uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A) {
+__device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_t nblk, const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                               uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, const ScanCullArgs &A) {
     constexpr uint32_t WK = WAVE_KEYS, NB = WK / 64u, NLD = K32 ? 2u : CULL_ITERS;   // keys per wave; ballots per wave (one per key a lane holds); 16-byte loads per lane
     // per-wave candidate list (no barrier: wave-private): section index + its key (one word compact, two words full); the visible
     // sections are compacted in place over its front
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
     const unsigned long long tl_start = wall_clock64(); unsigned long long tl_keys = tl_start, tl_pred = 0, tl_emit = 0; uint32_t tl_cand = 0;
 #endif
     // workgroup -> key chunk: the candidate spans first (see ScanSpans); all scalar
-    uint32_t chunk = blockIdx.x;
+    uint32_t chunk = bid;
     {
         const uint32_t st[4] = { s0, s1, s2, s3 }, ct[4] = { c0, c1, c2, c3 };
         uint32_t acc = 0; bool in_span = false;
@@ -468,12 +471,12 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
         asm volatile("" : "+s"(ka));
         const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
         const uint32_t nsh = R.S.n;
-        if (blockIdx.x * CULL_THREADS < nsh && !R.spec->stale) {
+        if (bid * CULL_THREADS < nsh && !R.spec->stale) {
             const SharedArrays S = R.S; const ItemSink K = R.K;
-            for (uint32_t s0 = blockIdx.x * CULL_THREADS; s0 < nsh; s0 += gridDim.x * CULL_THREADS)
+            for (uint32_t s0 = bid * CULL_THREADS; s0 < nsh; s0 += nblk * CULL_THREADS)
                 cull_shared_section(s0 + threadIdx.x, S, R.cell_key64, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
         }
-        if (blockIdx.x == gridDim.x - 1u && !R.spec->stale) {
+        if (bid == nblk - 1u && !R.spec->stale) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
             for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
         }
@@ -483,6 +486,11 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
     }
 }
 
+template <bool K32>
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                                            uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A) {
+    scan_cull_body<K32>(blockIdx.x, gridDim.x, keys, ncells, nsp, s0, c0, s1, c1, s2, c2, s3, c3, chunk_level, A);
+}
 template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 
@@ -798,18 +806,18 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 // (row, slot) pairs are requested together -- entries beyond a shard's count are stale but harmless, they are masked once the
 // cursors are known -- and the 64-byte matrices follow one round trip later, in flight while the histograms are built:
 // two dependent memory round trips from launch to store.
-__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows) {
+__device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32_t nblk, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t nrows) {
     extern __shared__ uint32_t s_dyn[];                       // [nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
     __shared__ uint32_t s_pos[64], s_row[64];
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (blockIdx.x == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; __threadfence_system(); A.hres->done_frame = A.frame; }
+        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; __threadfence_system(); A.hres->done_frame = A.frame; }
         return;
     }
     const uint32_t nslots = A.nslots;
     uint32_t *s_tot = s_dyn, *s_fill = s_dyn + nslots;
-    const uint32_t my_shard = blockIdx.x & (CURSOR_SHARDS - 1u), my_j0 = (blockIdx.x >> 3) * 64u;
+    const uint32_t my_shard = bid & (CURSOR_SHARDS - 1u), my_j0 = (bid >> 3) * 64u;
     const uint32_t part = tid & 3u, li = tid >> 2;
     // ---- round trip 1: everything that needs no other load
     unsigned long long cur[CURSOR_SHARDS];
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     __shared__ InstanceRange s_rng[PACK_STAGED_GROUPS];
     const bool staged = nslots <= PACK_STAGED_GROUPS;         // at most nslots groups
     uint32_t fc_a = 0, fc_b = 0, fc_c = 0;
-    if (blockIdx.x == 0 && wid == 0 && lane < COUNTER_SHARDS) { const uint32_t *cnt = hdr->counters + lane * 16u; fc_a = cnt[0]; fc_b = cnt[1]; fc_c = cnt[2]; }
+    if (bid == 0 && wid == 0 && lane < COUNTER_SHARDS) { const uint32_t *cnt = hdr->counters + lane * 16u; fc_a = cnt[0]; fc_b = cnt[1]; fc_c = cnt[2]; }
     for (uint32_t i = tid; i < 2u * nslots && nslots <= LDS_HIST_SLOTS; i += NT) s_dyn[i] = 0;
     if (tid == 0) { s_carry = 0; s_gcarry = 0; }
     if (tid < 64u) s_row[tid] = my_row;
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) if (k == my_shard) my_n = n[k];
     const bool have = my_j0 < my_n;                           // this workgroup owns instances
-    if (blockIdx.x != 0 && (overflow || !have)) return;
+    if (bid != 0 && (overflow || !have)) return;
     if (!overflow) {
         // histograms: all instances -> s_tot; the instances ordered before this workgroup's chunk -> s_fill
 #pragma unroll
@@ -873,7 +881,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
             uint32_t gidx = s_gcarry + wcn + incn - nz;
             if (i < nslots) {
                 s_tot[i] = begin;
-                if (v && blockIdx.x == 0) {
+                if (v && bid == 0) {
                     uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
                     if (staged) s_rng[gidx] = r; else A.ranges[gidx] = r;
                 }
@@ -883,7 +891,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
             __syncthreads();
         }
     }
-    if (blockIdx.x == 0) {
+    if (bid == 0) {
         // the host polls done_frame while this kernel runs: every wave's InstanceRange stores must have left for host memory before
         // lane 0 publishes it (a workgroup barrier alone does not wait for the other waves' stores in flight)
         if (!staged) __threadfence_system();
@@ -926,7 +934,7 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
     }
     // ---- a shard longer than the launch anticipated (the grid is sized from the previous frame): further chunks of this workgroup,
     // without the speculative loads; the "before this chunk" histogram is rebuilt per chunk
-    const uint32_t stride = (gridDim.x >> 3) * 64u;
+    const uint32_t stride = (nblk >> 3) * 64u;
     for (uint32_t j0 = my_j0 + stride; j0 < my_n; j0 += stride) {           // workgroup-uniform
         __syncthreads();
         for (uint32_t i = tid; i < nslots; i += NT) s_fill[i] = 0;
@@ -951,6 +959,25 @@ __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeade
         if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[li] * 16)[part];
     }
 }
+
+__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows) {
+    pack_small_body(blockIdx.x, gridDim.x, hdr, hdr_next, th, A, K, nrows);
+}
+
+// Software-pipelined frame loop of a static world: the launch of frame f + 1 carries the pack of frame f in its first workgroups
+// (`npack` of them, passed in the upper bits of the preloaded `nsp` word so that no wave waits for another scalar load), the rest is
+// the scan of frame f + 1.  The pack's chain of dependent round trips overlaps the key stream instead of following it in a launch of
+// its own; one launch per frame.  The host defers a pack only when nothing can touch the rows between the two culls (no dynamic
+// entities), see issue_cull.
+template <bool K32>
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull_fused(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp_npack, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                                                  uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A, FusedPack F) {
+    const uint32_t npack = nsp_npack >> 8;
+    if (blockIdx.x < npack) { pack_small_body(blockIdx.x, npack, F.hdr, F.hdr_next, F.th, F.A, F.K, F.nrows); return; }
+    scan_cull_body<K32>(blockIdx.x - npack, gridDim.x - npack, keys, ncells, nsp_npack & 0xFFu, s0, c0, s1, c1, s2, c2, s3, c3, chunk_level, A);
+}
+template __global__ void k_scan_cull_fused<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
+template __global__ void k_scan_cull_fused<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
 
 // ---------------------------------------------------------------------------------------------
 // K3: the ECS tick.  LogicFlow::apply_kinematics (flows/logic_flow.rs:366-448) + the component math of

@@ -384,6 +384,32 @@ def test_probe_path_static_lattice(R):
     p.close(); w.close()
 
 
+def test_deferred_pack_static_fly_through(R):
+    """RE_CULL_DEFER_PACK: asynchronous frames of a static world leave their pack to the next frame's launch (k_scan_cull_fused, one
+    launch per frame).  A camera flying through the lattice: whatever frame is waited for, copied or followed by a synchronous frame
+    is bit-exact with the oracle, and the fused launches did happen"""
+    ents = R.synthetic.lattice_world(cells_per_axis=40, first_cell=108, straddler_fraction=0.03)
+    p, w = build_pair(R, ents)
+    cams = [R.Camera((8192 + 9.5 * i, 8192 - 4.25 * i, 8500 - 11.0 * i), (0.02 * i, 0.01 * i, -1), 900.0) for i in range(24)]
+    def oracle_frame(cam, dups=False):
+        oc = oracle_camera(cam); w.cull(oc); o = w.render(oc, emit_duplicates=dups); w.tick(oc, 0.016); return o
+    check_frame(R, p, w, cams[0], False); w.tick(oracle_camera(cams[0]), 0.016); p.tick(0.016)          # the static cache freezes here
+    for i, cam in enumerate(cams[1:], 1):
+        if i % 6 == 0:                                            # a synchronous frame in between picks up the deferred pack of its predecessor
+            check_frame(R, p, w, cam, bool(i % 4 == 0)); w.tick(oracle_camera(cam), 0.016); p.tick(0.016)
+            continue
+        p.cull_and_pack(cam, asynchronous=True, copy=False, defer_pack=True); p.tick(0.016, asynchronous=True)
+        o = oracle_frame(cam)
+        if i % 5 == 0:                                            # wait for this very frame: its pack is sent off on its own
+            vis, _ = p.wait(copy=True)
+            assert_render_equal(vis, o)
+    vis, _ = p.wait(copy=True)
+    assert_render_equal(vis, o)
+    st = p.stats()
+    assert st["n_fused_frames"] >= 10, st
+    p.close(); w.close()
+
+
 def sorted_pairs(a):
     a = np.asarray(a, np.uint32).reshape(-1, 2)
     return a[np.lexsort((a[:, 1], a[:, 0]))]
