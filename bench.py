@@ -111,11 +111,16 @@ def main():
     def step(sync_each):
         if gather is not None:
             gather.begin_frame()
-            p.cull_and_pack(camc, asynchronous=True, copy=False, force_large_pack=a.force_large_pack)
-            gather.exchange()
+            p.cull_and_pack(camc, asynchronous=True, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack)
+            if a.no_defer_pack:
+                gather.exchange()
+            else:
+                gather.exchange_lagged()       # this launch carried the previous frame's pack: that frame's slab goes out now
             p.tick(0.016, asynchronous=True)
             if sync_each:
-                p.wait(); gather.finish()
+                p.wait()
+                if a.no_defer_pack: gather.finish()
+                else: gather.finish_lagged()
         else:
             # asynchronous frames of a static world leave their pack to the next frame's launch (one launch per frame); the last one is
             # sent off by the fence.  Worlds with dynamic entities pack every frame before its tick (the library ignores the flag there).
@@ -125,7 +130,8 @@ def main():
     def fence():
         p.wait()
         if gather is not None:
-            gather.finish()
+            if a.no_defer_pack: gather.finish()
+            else: gather.finish_lagged()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -152,8 +158,8 @@ def main():
     # second timing leg, outside the timed region: the scan kernel on its own (every frame's pack launched separately), so that the
     # roofline of the scan can be read next to that of the fused launch the timed region runs
     scan_only_us = None
-    fused = gather is None and not a.no_defer_pack and (p.stats()["n_fused_frames"] - fused_before) * 2 >= a.steps    # the launches of the timed region carried the packs
-    if fused and rank == 0:
+    fused = not a.no_defer_pack and (p.stats()["n_fused_frames"] - fused_before) * 2 >= a.steps    # the launches of the timed region carried the packs
+    if fused and rank == 0 and gather is None:
         nleg = 96
         p.timing_begin(nleg, every=TIMING_EVERY)
         for _ in range(nleg):

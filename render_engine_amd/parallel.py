@@ -89,6 +89,7 @@ class SlabAllGather:
         self.recv = [torch.zeros(words * self.world, dtype=torch.int32, device=dev) for _ in range(2)]
         self.work = [None, None]
         self.frame = 0
+        self._lag_pending = False
         self.stream = torch.cuda.ExternalStream(pipeline.stream()) if hasattr(torch.cuda, "ExternalStream") else torch.cuda.current_stream()
 
     def _bind(self, b):
@@ -112,6 +113,33 @@ class SlabAllGather:
         with torch.cuda.stream(self.stream):
             self.work[b] = self.dist.all_gather_into_tensor(self.recv[b], self.slab[b], group=self.group, async_op=True)
         self.frame += 1
+        return b
+
+    def _gather(self, b):
+        with torch.cuda.stream(self.stream):
+            self.work[b] = self.dist.all_gather_into_tensor(self.recv[b], self.slab[b], group=self.group, async_op=True)
+
+    def exchange_lagged(self):
+        """for frames issued with defer_pack=True (Pipeline.cull_and_pack): the launch just enqueued carries the pack of the PREVIOUS
+        frame, so that frame's slab is complete in stream order now -- enqueue its all-gather.  Call after the frame's asynchronous
+        cull_and_pack; returns the buffer gathered (None for the first frame).  Works unchanged when the library did not defer the
+        pack (worlds with dynamic entities): the exchange then simply runs one frame late."""
+        prev = None
+        if self.frame >= 1:
+            prev = (self.frame - 1) & 1
+            self._gather(prev)
+        self.frame += 1
+        self._lag_pending = True
+        return prev
+
+    def finish_lagged(self):
+        """after Pipeline.wait() (which sends a still deferred pack off on its own): the last frame's all-gather, then wait for all"""
+        b = None
+        if self._lag_pending and self.frame >= 1:
+            b = (self.frame - 1) & 1
+            self._gather(b)
+            self._lag_pending = False
+        self.finish()
         return b
 
     def finish(self):

@@ -41,9 +41,29 @@ def main():
     np.testing.assert_array_equal(got, want)
     o1 = np.argsort(ids.cpu().numpy().astype(np.uint32), kind="stable"); o2 = np.argsort(ref["ids"], kind="stable")
     np.testing.assert_array_equal(mats.cpu().numpy()[o1], ref["mats"][o2])
+    p.close(); full.close()
+    # the same with the one-launch-per-frame loop of a static world: packs deferred into the next frame's launch, exchange one frame late
+    mine = synthetic.box_world(dims, first_cell=first, atomic=atomic, index_range=(lo, hi))
+    p = R.Pipeline(16384, atomic, max_instances=1 << 14); p.register_model_instances(mine)
+    full = R.Pipeline(16384, atomic, max_instances=1 << 14); full.register_model_instances(synthetic.box_world(dims, first_cell=first, atomic=atomic))
+    g = parallel.SlabAllGather(p, 2048, dist)
+    for cam in cams:
+        g.begin_frame()
+        p.cull_and_pack(cam, asynchronous=True, copy=False, defer_pack=True)
+        g.exchange_lagged()
+        p.tick(0.016, asynchronous=True)
+    p.wait(); b = g.finish_lagged()
+    ids, mats, counts2 = g.gathered(b)
+    for cam in cams:
+        ref = full.cull_and_pack(cam); full.tick(0.016)
+    assert sum(counts2) == ref["total"], (counts2, ref["total"])
+    np.testing.assert_array_equal(np.sort(ids.cpu().numpy().astype(np.uint32)), np.sort(ref["ids"]))
+    o1 = np.argsort(ids.cpu().numpy().astype(np.uint32), kind="stable"); o2 = np.argsort(ref["ids"], kind="stable")
+    np.testing.assert_array_equal(mats.cpu().numpy()[o1], ref["mats"][o2])
+    assert p.stats()["n_fused_frames"] >= len(cams) - 2, p.stats()
     dist.barrier()
     if rank == 0:
-        print("OK slab all-gather", counts)
+        print("OK slab all-gather", counts, counts2)
     dist.destroy_process_group()
 
 
