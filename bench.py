@@ -226,7 +226,12 @@ def main():
                 out["roofline_scan_only"] = {"bound": "hbm", "kernel": "k_scan_cull (second leg after the timed region: every pack launched on its own)", "mean_launch_us": so,
                                              "algorithmic_bytes_per_launch": alg_bytes, "achieved": alg_bytes / (so * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                              "frac": alg_bytes / (so * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "launches_timed": int(len(scan_only_us))}
-                out["roofline"]["traffic"] = None        # the committed PMC figure is of the scan kernel alone
+            out["roofline"]["traffic"] = None            # the committed PMC figure `traffic` above is of the scan kernel alone
+            if default_workload and os.path.exists(prof):
+                try:
+                    out["roofline"]["traffic"] = json.load(open(prof))["fused_launch"]["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_optimised"] = cpu_baseline(a, atomic, n_total)
         print(json.dumps(out))

@@ -19,7 +19,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if r.get("Counter_Name") == ctr:
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if "k_scan_cull" in k or "k_pack_small" in k or "k_tick" in k:
+        if "k_scan_cull" in k or "k_pack_small" in k or "k_tick" in k or "k_probe" in k:
             v = v[len(v) // 3:]                      # steady state
             out.setdefault(k, {})[ctr] = sum(v) / len(v)
 print(json.dumps(out, indent=1))
