@@ -410,6 +410,38 @@ def test_deferred_pack_static_fly_through(R):
     p.close(); w.close()
 
 
+def test_deferred_pack_with_change_batches(R):
+    """deferred packs and user change batches: a batch between two asynchronous frames must find the pending pack done first (it reads
+    the matrices the batch rewrites), and the frames after it see the changed world -- ghosts of the frozen static cache included"""
+    C = R._capi
+    ents = R.synthetic.lattice_world(cells_per_axis=24, first_cell=116)
+    p, w = build_pair(R, ents, flags=C.CFG_PROBE)                 # (the key -> slot table just rides along: narrow frames take the probe kernel and send a pending pack off on its own)
+    rng = np.random.default_rng(12)
+    cam0 = R.Camera((8192, 8192, 8192 + 700), (0, 0, -1), 1500.0)
+    check_frame(R, p, w, cam0, False); w.tick(oracle_camera(cam0), 0.016); p.tick(0.016)
+    ids = ents["id"]
+    for i in range(1, 16):
+        cam = R.Camera((8192 + 6.0 * i, 8192 - 3.0 * i, 8192 + 700 - 9.0 * i), (0.01 * i, 0, -1), 1500.0 if i % 4 else 250.0)
+        oc = oracle_camera(cam)
+        p.cull_and_pack(cam, asynchronous=True, copy=False, defer_pack=True); p.tick(0.016, asynchronous=True)
+        w.cull(oc); o = w.render(oc); w.tick(oc, 0.016)
+        if i % 3 == 0:
+            ch = np.zeros(12, R.CHANGE_DT)
+            for k in range(12):
+                e = int(rng.choice(ids)); kind = rng.integers(0, 4)
+                ch[k] = ((C.CHANGE_MODIFY, e, C.C_POSITION, 0, (8192 + rng.uniform(-300, 300), 8192 + rng.uniform(-300, 300), 8192 + rng.uniform(-300, 300), 0)) if kind == 0 else
+                         (C.CHANGE_WAKE_UP, e, 0, 0, (0, 0, 0, 0)) if kind == 1 else (C.CHANGE_MAKE_STATIC, e, 0, 0, (0, 0, 0, 0)) if kind == 2 else (C.CHANGE_DELETE, e, 0, 0, (0, 0, 0, 0)))
+            n_a, _ = w.apply_changes(ch.view(ro.CHANGE_DT)); g = p.apply_changes(ch)
+            assert g["n_changed"] == n_a
+    vis, _ = p.wait(copy=True)
+    assert_render_equal(vis, o)
+    check_sections(p, w)
+    st = p.stats()
+    assert st["n_fused_frames"] >= 5 and st["n_probe_frames"] >= 2, st
+    check_frame(R, p, w, cam0, True)
+    p.close(); w.close()
+
+
 def sorted_pairs(a):
     a = np.asarray(a, np.uint32).reshape(-1, 2)
     return a[np.lexsort((a[:, 1], a[:, 0]))]
