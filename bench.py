@@ -171,6 +171,7 @@ def main():
     lat = []
     for _ in range(min(50, a.steps)):
         t1 = time.perf_counter(); step(True); lat.append(time.perf_counter() - t1)     # both calls return with their results complete
+    p.timings_us(); step(True)                       # kernel event timing is off until asked for: switch it on, time one more synchronous frame
     tm = p.timings_us()
 
     if rank == 0:

@@ -260,7 +260,9 @@ int re_debug_get_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, float 
 /* visible_sections_map of the last cull, ascending; multiplicity[i] = 2 when the section is in both
  * the logic and the render result (appears twice in visible_sections_vec). */
 int re_debug_get_visible_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n);
-/* device time of the kernels of the last cull_pack / tick, microseconds (hipEvent on the ctx stream) */
+/* device time of the kernels of the last synchronous cull_pack / tick, microseconds (hipEvent on the ctx stream).  The first call
+ * switches the event recording on (it costs ~12 us per synchronous frame, so it is off until asked for) and returns zeros; call again
+ * after the next frame. */
 int re_get_timings(re_ctx *ctx, float *cull_us, float *pack_us, float *tick_us);
 /* per-launch HIP-event timing of the dominant kernel (the section-key scan + cull) over a timed region, sampling every
  * `every`-th launch (0 or 1 = all): re_timing_begin(ctx, max_launches, every); ...frames...;

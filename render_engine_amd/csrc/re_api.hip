@@ -141,6 +141,7 @@ struct re_ctx {
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
+    bool timings_on = false;                          // re_get_timings was asked for: synchronous frames record their kernel events (5 event records cost ~12 us per frame)
     bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
     re_tick_result last_tick{};
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
@@ -846,7 +847,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     make_frame_params(c, cam, flags);
     const FrameParams &P = c->P;
     FrameHeader *hdr = frame_header(c, c->frame), *hdr_next = frame_header(c, c->frame + 2u);     // the pack clears the header of the frame after next
-    c->timed_frame = !(flags & RE_CULL_ASYNC);
+    c->timed_frame = c->timings_on && !(flags & RE_CULL_ASYNC);
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (c->dirty_pending) {
         if (c->ncells) hipLaunchKernelGGL(k_static_cache_cells, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_tight.p, c->d_cell_flags.p, P);
@@ -1440,7 +1441,7 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
 
 static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     hipStream_t st = c->stream;
-    c->timed_tick = !(flags & RE_TICK_ASYNC);
+    c->timed_tick = c->timings_on && !(flags & RE_TICK_ASYNC);
     if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[3], st));
     if (c->ndyn) {
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
@@ -1912,6 +1913,7 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
 
 extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *tick_us) {
     if (!c) return RE_E_ARG;
+    c->timings_on = true;                                                     // from now on synchronous frames are timed
     if (c->timings_pending) {
         HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);

@@ -47,6 +47,18 @@ int main(int argc, char **argv) {
     std::sort(us.begin(), us.end());
     std::printf("entities %zu visible sections %u instances %u | synchronous re_cull_pack + re_tick per frame: median %.1f us, p10 %.1f, p90 %.1f\n",
                 n, vis.n_visible_sections, vis.n_instances, us[us.size() / 2], us[us.size() / 10], us[us.size() * 9 / 10]);
+    // host cost of issuing a frame (asynchronous calls return once the launches are enqueued) and the time until its result is there
+    std::vector<double> issue, wait;
+    for (uint32_t f = 0; f < frames; f++) {
+        auto t0 = std::chrono::steady_clock::now();
+        if (re_cull_pack(ctx, &cam, RE_CULL_ASYNC, nullptr) != RE_OK) { std::fprintf(stderr, "frame: %s\n", re_last_error(ctx)); return 1; }
+        auto t1 = std::chrono::steady_clock::now();
+        if (re_wait(ctx, &vis, &tr) != RE_OK) { std::fprintf(stderr, "wait: %s\n", re_last_error(ctx)); return 1; }
+        auto t2 = std::chrono::steady_clock::now();
+        issue.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count()); wait.push_back(std::chrono::duration<double, std::micro>(t2 - t1).count());
+    }
+    std::sort(issue.begin(), issue.end()); std::sort(wait.begin(), wait.end());
+    std::printf("asynchronous re_cull_pack returns after %.1f us (host side: frame parameters, candidate spans, two launches); re_wait then takes %.1f us\n", issue[issue.size() / 2], wait[wait.size() / 2]);
     re_destroy(ctx);
     return 0;
 }
