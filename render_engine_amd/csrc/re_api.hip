@@ -193,7 +193,6 @@ static void free_world(re_ctx *c) {
     if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
     if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
     if (c->h_spec) { (void)hipHostFree(c->h_spec); c->h_spec = nullptr; }
-    if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }
     c->d_spec.release(nullptr); c->pending.clear();
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false; c->deferred_pack = false;
 }
@@ -203,6 +202,7 @@ extern "C" void re_destroy(re_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_world(c);
+    if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }        // lives with the collision scratch lists (kept across uploads)
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : c->k1_events) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
