@@ -384,13 +384,17 @@ def test_probe_path_static_lattice(R):
     p.close(); w.close()
 
 
-def test_deferred_pack_static_fly_through(R):
+@pytest.mark.parametrize("atomic", [64, 16])
+def test_deferred_pack_static_fly_through(R, atomic):
     """RE_CULL_DEFER_PACK: asynchronous frames of a static world leave their pack to the next frame's launch (k_scan_cull_fused, one
     launch per frame).  A camera flying through the lattice: whatever frame is waited for, copied or followed by a synchronous frame
     is bit-exact with the oracle, and the fused launches did happen"""
-    ents = R.synthetic.lattice_world(cells_per_axis=40, first_cell=108, straddler_fraction=0.03)
-    p, w = build_pair(R, ents)
-    cams = [R.Camera((8192 + 9.5 * i, 8192 - 4.25 * i, 8500 - 11.0 * i), (0.02 * i, 0.01 * i, -1), 900.0) for i in range(24)]
+    # atomic 16: more than 512 sections per axis, so the fused launch runs over the full 64-bit stream keys
+    first = (16384 // atomic - 40) // 2
+    ents = R.synthetic.lattice_world(cells_per_axis=40, first_cell=first, atomic=atomic, straddler_fraction=0.03)
+    p, w = build_pair(R, ents, atomic=atomic)
+    s_ = atomic / 64.0
+    cams = [R.Camera((8192 + 9.5 * i * s_, 8192 - 4.25 * i * s_, 8192 + (308 - 11.0 * i) * s_), (0.02 * i, 0.01 * i, -1), 900.0 * s_) for i in range(24)]
     def oracle_frame(cam, dups=False):
         oc = oracle_camera(cam); w.cull(oc); o = w.render(oc, emit_duplicates=dups); w.tick(oc, 0.016); return o
     check_frame(R, p, w, cams[0], False); w.tick(oracle_camera(cams[0]), 0.016); p.tick(0.016)          # the static cache freezes here
