@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--force-large-pack", action="store_true", help="always use the multi-kernel pack")
     ap.add_argument("--cpu-sample-axis", type=int, default=100)
     ap.add_argument("--no-defer-pack", action="store_true", help="launch every frame's pack on its own instead of letting the next frame's launch carry it (RE_CULL_DEFER_PACK)")
+    ap.add_argument("--one-lane", action="store_true", help="keep all frames on one HIP stream (no RE_CULL_TWO_LANES)")
     ap.add_argument("--probe", action="store_true", help="opt-in variant: visibility query by hash probes of the candidate cells (RE_CFG_PROBE) instead of the key stream")
     return ap.parse_args()
 
@@ -124,7 +125,8 @@ def main():
         else:
             # asynchronous frames of a static world leave their pack to the next frame's launch (one launch per frame); the last one is
             # sent off by the fence.  Worlds with dynamic entities pack every frame before its tick (the library ignores the flag there).
-            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack)
+            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack,
+                            two_lanes=not (a.one_lane or a.no_defer_pack))
             p.tick(0.016, asynchronous=not sync_each)
 
     def fence():

@@ -117,6 +117,10 @@ typedef struct {
 #define RE_CULL_DEFER_PACK      0x10u /* with RE_CULL_ASYNC, in a world without dynamic entities: leave the instance pack of this frame to the launch of the
                                        * next re_cull_pack (one launch per frame; the pack's dependent round trips overlap the next key stream) or to the
                                        * next call that needs the result (re_wait, re_copy_visible, ...).  The packed instances are complete only then. */
+#define RE_CULL_TWO_LANES       0x20u /* with RE_CULL_ASYNC | RE_CULL_DEFER_PACK: alternate such frames between two sets of per-frame resources on two HIP
+                                       * streams, so that the launches of consecutive frames overlap on the GPU (the pack of frame f then rides in launch
+                                       * f + 2).  Needs a second copy of the per-frame buffers (~70 B per entity).  re_get_stream returns the stream of the
+                                       * frame issued last. */
 #define RE_CULL_FORCE_STREAM    0x8u  /* with RE_CFG_PROBE: take the key stream for this frame anyway */
 #define RE_CULL_FORCE_LARGE_PACK 0x4u /* always use the multi-kernel pack (count/scan/scatter) instead of k_pack_small */
 
@@ -250,7 +254,7 @@ int re_get_out_of_bounds(re_ctx *ctx, uint32_t *entity_ids, uint32_t capacity, u
 typedef struct {
     uint32_t n_entities, n_dynamic, n_sections, n_shared_sections, max_level;
     uint64_t device_bytes;
-    uint32_t n_probe_frames, n_table_rebuilds, n_fused_frames, reserved;   /* frames served by the probe path (RE_CFG_PROBE); full section-table rebuilds so far */
+    uint32_t n_probe_frames, n_table_rebuilds, n_fused_frames, reserved /* lane switches */;   /* frames served by the probe path (RE_CFG_PROBE); full section-table rebuilds so far */
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,

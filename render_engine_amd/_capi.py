@@ -10,7 +10,7 @@ F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
 F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
 F_CAN_COLLIDE = 0x1000
-CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK, CULL_FORCE_STREAM, CULL_DEFER_PACK = 0x1, 0x2, 0x4, 0x8, 0x10
+CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK, CULL_FORCE_STREAM, CULL_DEFER_PACK, CULL_TWO_LANES = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 TICK_ALL_DYNAMIC, TICK_ASYNC = 0x1, 0x2
 (C_POSITION, C_ROTATION, C_SCALE, C_VELOCITY, C_ACCELERATION, C_ROTATION_VEL, C_ROTATION_ACC,
  C_TRANSFORMATION, C_STATIC_AABB, C_ORIGINAL_AABB, C_FLAGS) = range(11)

@@ -61,6 +61,8 @@ struct Carry {
 constexpr uint32_t NUM_FRAME_HEADERS = 3;   // see frame_header()
 struct re_ctx;
 static int flush_deferred_pack(re_ctx *c);
+static int drain_other_lane(re_ctx *c);
+static void free_second_lane(re_ctx *c);
 struct re_ctx {
     re_config cfg{};
     int device = 0;
@@ -142,7 +144,17 @@ struct re_ctx {
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
     bool timings_on = false;                          // re_get_timings was asked for: synchronous frames record their kernel events (5 event records cost ~12 us per frame)
-    bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
+    bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;
+    // RE_CULL_TWO_LANES: a second set of per-frame resources ("lane": stream, frame headers, instance lists, section stamps, frame
+    // parameters, packed output, result block, deferred pack).  The members above/below always are those of the CURRENT lane; the other
+    // lane's are parked here and swapped in by switch_lane().  Frames of a static fly-through alternate lanes, so the launches of
+    // consecutive frames sit on different streams and overlap; everything else first drains the other lane (drain_other_lane).
+    struct LanePark {
+        hipStream_t stream = nullptr; DevBuf<FrameHeader> d_hdr; DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids, d_cell_stamp; DevBuf<float> d_out_mats; DevBuf<FrameParams> d_params;
+        HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr;
+        bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, lane_seq = 0; bool busy = false;
+    } park;
+    bool park_ready = false, lane_busy = false; uint32_t lane_seq = 0, lane_id = 0, n_lane_switches = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
     re_tick_result last_tick{};
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0; bool k1_timing = false;   // per-launch timing of k_scan_cull
@@ -200,6 +212,7 @@ static void free_world(re_ctx *c) {
 extern "C" void re_destroy(re_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_world(c);
     if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }        // lives with the collision scratch lists (kept across uploads)
@@ -498,6 +511,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     if (!c) return RE_E_ARG;
     if (!E || (E->n && (!E->entity_id || !E->model_index || !E->flags || !E->original_aabb || !E->position))) return c->fail(RE_E_ARG, "re_upload_entities: missing required array");
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     free_world(c);
     const uint32_t n = E->n;
@@ -635,7 +649,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->frame = 0; c->th_clean = true; c->pred_total = 0;
+    c->frame = 0; c->lane_seq = 0; c->th_clean = true; c->pred_total = 0;
     return RE_OK;
 }
 
@@ -777,7 +791,7 @@ static SharedArrays shared_arrays(re_ctx *c) {
 // multi-kernel pack for large visible sets: count -> scan -> scatter
 static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next) {
     const uint32_t nshards = CURSOR_SHARDS, seg_cap = c->item_cap / nshards;
-    const ItemSink KS = item_sink(c, c->frame);
+    const ItemSink KS = item_sink(c, c->lane_seq);
     hipStream_t st = c->stream;
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
@@ -795,6 +809,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next)
 }
 
 static int finish_cull(re_ctx *c, re_visible *out) {
+    { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     // Fast completion: the pack publishes "frame done" into mapped host memory after the group table and the counters; polling that
     // word costs a PCIe write's latency instead of the driver's stream-synchronise wake-up.  The packed instances are device
@@ -809,10 +824,10 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         if (done) { std::atomic_thread_fence(std::memory_order_acquire); if (c->h_res->overflow == 2u || (c->h_spec && c->h_spec->stale)) done = false; else c->pending.clear(); }
     }
     if (!done) { int rc = resolve(c); if (rc != RE_OK) return rc; }
-    c->cull_inflight = false;
+    c->cull_inflight = false; c->lane_busy = false;
     if (c->h_res->overflow == 1) {
         // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
-        int rc = launch_pack_large(c, frame_header(c, c->frame), frame_header(c, c->frame + 2u));
+        int rc = launch_pack_large(c, frame_header(c, c->lane_seq), frame_header(c, c->lane_seq + 2u));
         if (rc != RE_OK) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -829,6 +844,58 @@ static int finish_cull(re_ctx *c, re_visible *out) {
 }
 
 // enqueue one frame's cull + pack (no synchronisation)
+// ---- frame lanes (RE_CULL_TWO_LANES) ----
+static void switch_lane(re_ctx *c) {
+    re_ctx::LanePark &k = c->park;
+    std::swap(c->stream, k.stream); std::swap(c->d_hdr, k.d_hdr); std::swap(c->d_item_row, k.d_item_row); std::swap(c->d_item_slot, k.d_item_slot);
+    std::swap(c->d_out_ids, k.d_out_ids); std::swap(c->d_out_mats, k.d_out_mats); std::swap(c->d_cell_stamp, k.d_cell_stamp); std::swap(c->d_params, k.d_params);
+    std::swap(c->h_res, k.h_res); std::swap(c->d_hres, k.d_hres); std::swap(c->h_ranges, k.h_ranges); std::swap(c->d_hranges, k.d_hranges);
+    std::swap(c->deferred_pack, k.deferred_pack); std::swap(c->deferred, k.deferred); std::swap(c->deferred_grid, k.deferred_grid);
+    std::swap(c->lane_seq, k.lane_seq); std::swap(c->lane_busy, k.busy);
+    c->lane_id ^= 1u; c->n_lane_switches++;
+}
+// second lane: same sizes as the first one's per-frame buffers
+static int ensure_second_lane(re_ctx *c) {
+    if (c->park_ready) return RE_OK;
+    re_ctx::LanePark &k = c->park; uint64_t *acct = &c->dev_bytes;
+    HIPCHK(c, hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
+    HIPCHK(c, k.d_hdr.alloc(NUM_FRAME_HEADERS, acct)); HIPCHK(c, k.d_item_row.alloc((size_t)c->item_cap * 2, acct)); HIPCHK(c, k.d_item_slot.alloc((size_t)c->item_cap * 2, acct));
+    HIPCHK(c, k.d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, k.d_out_mats.alloc((size_t)c->out_cap * 16, acct));
+    HIPCHK(c, k.d_cell_stamp.alloc(std::max<size_t>(c->d_cell_stamp.n, 1), acct)); HIPCHK(c, k.d_params.alloc(1, acct));
+    HIPCHK(c, hipMemset(k.d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader))); HIPCHK(c, hipMemset(k.d_item_row.p, 0, (size_t)c->item_cap * 8)); HIPCHK(c, hipMemset(k.d_item_slot.p, 0xFF, (size_t)c->item_cap * 8));
+    HIPCHK(c, hipMemset(k.d_cell_stamp.p, 0, k.d_cell_stamp.n * 4));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&k.h_res), sizeof(HostResult), hipHostMallocMapped)); memset(k.h_res, 0, sizeof(HostResult));
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&k.h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&k.d_hres), k.h_res, 0)); HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&k.d_hranges), k.h_ranges, 0));
+    k.deferred_pack = false; k.lane_seq = 0; k.busy = false;
+    c->park_ready = true;
+    return RE_OK;
+}
+static void free_second_lane(re_ctx *c) {
+    if (c->lane_id) switch_lane(c);                                          // lane 0 is the one the rest of the context owns
+    re_ctx::LanePark &k = c->park; uint64_t *acct = &c->dev_bytes;
+    if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
+    k.d_hdr.release(acct); k.d_item_row.release(acct); k.d_item_slot.release(acct); k.d_out_ids.release(acct); k.d_out_mats.release(acct); k.d_cell_stamp.release(acct); k.d_params.release(acct);
+    if (k.h_res) { (void)hipHostFree(k.h_res); k.h_res = nullptr; k.d_hres = nullptr; }
+    if (k.h_ranges) { (void)hipHostFree(k.h_ranges); k.h_ranges = nullptr; k.d_hranges = nullptr; }
+    k.deferred_pack = false; k.busy = false; c->park_ready = false;
+}
+static int flush_deferred_pack(re_ctx *c);
+// Everything except the alternating frames themselves works on one lane: send the other lane's pending pack off and wait for its stream.
+// The current lane holds the newest frame (lanes are switched before a frame is issued), so results, stamps and frame parameters
+// of "the last frame" are those of the current lane afterwards.
+static int drain_other_lane(re_ctx *c) {
+    if (!c->park_ready || !(c->park.busy || c->park.deferred_pack)) return RE_OK;
+    switch_lane(c);
+    int rc = flush_deferred_pack(c);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    c->lane_busy = false;
+    switch_lane(c);
+    if (rc != RE_OK) return rc;
+    HIPCHK(c, e);
+    return RE_OK;
+}
+
 // A pack deferred by RE_CULL_DEFER_PACK that no later frame picked up: launch it on its own (anything that needs the frame's result, or
 // is about to change what the pack reads, calls this first).
 static int flush_deferred_pack(re_ctx *c) {
@@ -846,7 +913,8 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     c->frame += 1;
     make_frame_params(c, cam, flags);
     const FrameParams &P = c->P;
-    FrameHeader *hdr = frame_header(c, c->frame), *hdr_next = frame_header(c, c->frame + 2u);     // the pack clears the header of the frame after next
+    c->lane_seq += 1;                                                           // frames issued on this lane: rotates its headers and instance lists
+    FrameHeader *hdr = frame_header(c, c->lane_seq), *hdr_next = frame_header(c, c->lane_seq + 2u);     // the pack clears the header of the frame after next
     c->timed_frame = c->timings_on && !(flags & RE_CULL_ASYNC);
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (c->dirty_pending) {
@@ -866,7 +934,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
     ScanCullArgs SA; SA.B = c->PB; SA.B32 = c->PB32; SA.cell_key64 = c->d_cell_key.p; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p; SA.cell_nghost = c->d_cell_nghost.p;
-    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c, c->frame); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
+    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c, c->lane_seq); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
     static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
 #ifdef RE_EXP_STAMPS
     if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 8, nullptr));
@@ -934,10 +1002,10 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         // RE_CULL_DEFER_PACK: in a world without dynamic entities nothing changes what the pack reads before the next visibility query,
         // so an asynchronous frame may leave its pack to the launch of the next one (k_scan_cull_fused)
         if ((flags & RE_CULL_DEFER_PACK) && (flags & RE_CULL_ASYNC) && c->ndyn == 0 && !c->dirty_pending) {
-            FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->frame); F.nrows = c->n + c->ghost_cap;
+            FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->lane_seq); F.nrows = c->n + c->ghost_cap;
             c->deferred = F; c->deferred_grid = pgrid; c->deferred_pack = true;
         } else
-            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->frame), c->n + c->ghost_cap);
+            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->lane_seq), c->n + c->ghost_cap);
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next);
         if (rc != RE_OK) return rc;
@@ -958,6 +1026,16 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     // Movers of the previous tick may change the section table.  A synchronous call waits for that tick; an asynchronous one is
     // enqueued speculatively: if the tick does find movers, this frame's kernels cancel themselves and resolve() replays it.
     if (!(flags & RE_CULL_ASYNC) && c->tick_inflight && c->ndyn) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    {   // frame lanes: a deferred asynchronous frame of a static world may go to the other lane (its launch then overlaps the previous
+        // frame's on the GPU); anything else runs on one lane only and waits for the other one first
+        const uint32_t need = RE_CULL_ASYNC | RE_CULL_DEFER_PACK | RE_CULL_TWO_LANES;
+        const bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
+        if ((flags & need) == need && c->ndyn == 0 && !c->dirty_pending && small && c->have_cull) {
+            int rc = ensure_second_lane(c); if (rc != RE_OK) return rc;
+            switch_lane(c);
+            c->lane_busy = true;
+        } else { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
+    }
     int rc = issue_cull(c, cam, flags);
     if (rc != RE_OK || (flags & RE_CULL_ASYNC)) return rc;
     return finish_cull(c, out);
@@ -1476,6 +1554,7 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
 // Synchronise and settle speculation: when a tick raised `stale` (entities changed section or left the world), everything enqueued
 // after it has cancelled itself; patch the tree from that tick's lists, then replay the cancelled calls (which may go stale again).
 static int resolve(re_ctx *c) {
+    { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->tick_inflight && c->ndyn && c->h_th) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 16, hipMemcpyDeviceToHost));   // n_changed, n_rebucket, n_oob of the last tick that ran
@@ -1859,7 +1938,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches;
     return RE_OK;
 }
 

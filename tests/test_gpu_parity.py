@@ -384,8 +384,8 @@ def test_probe_path_static_lattice(R):
     p.close(); w.close()
 
 
-@pytest.mark.parametrize("atomic", [64, 16])
-def test_deferred_pack_static_fly_through(R, atomic):
+@pytest.mark.parametrize("atomic,two_lanes", [(64, False), (16, False), (64, True), (16, True)])
+def test_deferred_pack_static_fly_through(R, atomic, two_lanes):
     """RE_CULL_DEFER_PACK: asynchronous frames of a static world leave their pack to the next frame's launch (k_scan_cull_fused, one
     launch per frame).  A camera flying through the lattice: whatever frame is waited for, copied or followed by a synchronous frame
     is bit-exact with the oracle, and the fused launches did happen"""
@@ -402,7 +402,7 @@ def test_deferred_pack_static_fly_through(R, atomic):
         if i % 6 == 0:                                            # a synchronous frame in between picks up the deferred pack of its predecessor
             check_frame(R, p, w, cam, bool(i % 4 == 0)); w.tick(oracle_camera(cam), 0.016); p.tick(0.016)
             continue
-        p.cull_and_pack(cam, asynchronous=True, copy=False, defer_pack=True); p.tick(0.016, asynchronous=True)
+        p.cull_and_pack(cam, asynchronous=True, copy=False, defer_pack=True, two_lanes=two_lanes); p.tick(0.016, asynchronous=True)
         o = oracle_frame(cam)
         if i % 5 == 0:                                            # wait for this very frame: its pack is sent off on its own
             vis, _ = p.wait(copy=True)
@@ -410,7 +410,8 @@ def test_deferred_pack_static_fly_through(R, atomic):
     vis, _ = p.wait(copy=True)
     assert_render_equal(vis, o)
     st = p.stats()
-    assert st["n_fused_frames"] >= 10, st
+    assert st["n_fused_frames"] >= (6 if two_lanes else 10), st
+    assert (st["reserved"] >= 12) == two_lanes, st               # lane switches (RE_CULL_TWO_LANES: frames alternate between two streams)
     p.close(); w.close()
 
 
