@@ -107,32 +107,36 @@ def main():
     cam = R.Camera(centre, (0.0, 0.0, -1.0), a.far)
     camc = cam.to_c()
     # N > 1: every rank packs into a fixed slab and the slabs are all-gathered in stream order, double-buffered -- no host round trip
-    gather = parallel.SlabAllGather(p, SLAB_INSTANCES, dist) if world > 1 else None
+    lanes = not (a.one_lane or a.no_defer_pack)
+    gather = None
+    if world > 1:
+        gather = parallel.SlabAllGatherLanes(p, SLAB_INSTANCES, dist) if lanes else parallel.SlabAllGather(p, SLAB_INSTANCES, dist)
 
     def step(sync_each):
         if gather is not None:
             gather.begin_frame()
-            p.cull_and_pack(camc, asynchronous=True, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack)
-            if a.no_defer_pack:
+            p.cull_and_pack(camc, asynchronous=True, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack, two_lanes=lanes)
+            if lanes:
+                gather.after_cull()            # frames alternate between two streams; the slab of frame g - 2 goes out behind launch g
+            elif a.no_defer_pack:
                 gather.exchange()
             else:
                 gather.exchange_lagged()       # this launch carried the previous frame's pack: that frame's slab goes out now
             p.tick(0.016, asynchronous=True)
             if sync_each:
                 p.wait()
-                if a.no_defer_pack: gather.finish()
+                if lanes or a.no_defer_pack: gather.finish()
                 else: gather.finish_lagged()
         else:
             # asynchronous frames of a static world leave their pack to the next frame's launch (one launch per frame); the last one is
             # sent off by the fence.  Worlds with dynamic entities pack every frame before its tick (the library ignores the flag there).
-            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack,
-                            two_lanes=not (a.one_lane or a.no_defer_pack))
+            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack, two_lanes=lanes)
             p.tick(0.016, asynchronous=not sync_each)
 
     def fence():
         p.wait()
         if gather is not None:
-            if a.no_defer_pack: gather.finish()
+            if lanes or a.no_defer_pack: gather.finish()
             else: gather.finish_lagged()
         torch.cuda.synchronize()
         if dist is not None:
@@ -211,7 +215,7 @@ def main():
                                    ("configs[2]: %d entities incl. every %dth rotating (ECS tick + cull), far=%g" % (n_total, a.spinner_every, a.far)),
                        "entities": n_total, "sections": C_sections * world, "dynamic_entities": stats["n_dynamic"] * world,
                        "visible_sections": vis["n_visible_sections"], "visible_instances": vis["total"], "far": a.far,
-                       "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), double-buffered, stream-ordered" % SLAB_INSTANCES},
+                       "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), slabs in rotation, stream-ordered behind the launch that carries the pack" % SLAB_INSTANCES},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_probe_cull" if probed else ("k_scan_cull_fused (scan of frame f+1 + pack of frame f in one launch)" if fused else "k_scan_cull"), "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
@@ -235,6 +239,10 @@ def main():
                     out["roofline"]["traffic"] = json.load(open(prof))["fused_launch"]["hbm_bytes_per_launch"]
                 except Exception:
                     pass
+        # with two frame lanes the launches of consecutive frames overlap: next to the per-launch figure, the algorithmic bytes of the timed
+        # region over its wall time (what the device as a whole sustained)
+        out["roofline"]["timed_region_achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] * a.steps / elapsed / 1e9 if out["roofline"].get("algorithmic_bytes_per_launch") else None
+        out["roofline"]["timed_region_frac"] = out["roofline"]["timed_region_achieved"] / HBM_PEAK_GBS if out["roofline"]["timed_region_achieved"] else None
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"], out["cpu_optimised"] = cpu_baseline(a, atomic, n_total)
         print(json.dumps(out))

@@ -156,3 +156,80 @@ class SlabAllGather:
         ids = torch.cat([r[k, self.HEADER_WORDS:self.HEADER_WORDS + min(counts[k], self.cap)] for k in range(self.world)])
         mats = torch.cat([r[k, self.HEADER_WORDS + self.cap:].view(torch.float32).view(self.cap, 16)[:min(counts[k], self.cap)] for k in range(self.world)])
         return ids, mats, counts
+
+
+class SlabAllGatherLanes:
+    """The exchange for frame loops issued with defer_pack=True, two_lanes=True (Pipeline.cull_and_pack): frames alternate between two
+    HIP streams and the pack of frame g rides in the launch of frame g + 2 on the same stream, so the slab of frame g - 2 is complete,
+    in the order of the stream frame g was just issued on, as soon as that call returns.  Eight slabs rotate (frame g packs into slab
+    g % 8); the all-gather of the slab of frame g - 2 is enqueued behind launch g.  Also correct when the library keeps the frames on one
+    stream or packs at once (worlds with dynamic entities, first frames): a slab is then simply complete earlier than assumed.
+    Call order per frame: begin_frame(); pipeline.cull_and_pack(..., asynchronous=True, defer_pack=True, two_lanes=True);
+    after_cull(); at the end pipeline.wait(); finish()."""
+
+    HEADER_WORDS = SlabAllGather.HEADER_WORDS
+    DEPTH = 8                                       # a slab is rewritten 8 frames after it was filled: its collective (handed over 6 frames earlier at the latest) has long finished
+
+    def __init__(self, pipeline, slab_instances, dist, group=None):
+        self.p, self.dist, self.group, self.cap = pipeline, dist, group, int(slab_instances)
+        self.world = dist.get_world_size(group)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        words = self.HEADER_WORDS + self.cap * 17
+        self.slab = [torch.zeros(words, dtype=torch.int32, device=dev) for _ in range(self.DEPTH)]
+        self.recv = [torch.zeros(words * self.world, dtype=torch.int32, device=dev) for _ in range(self.DEPTH)]
+        self.work = [None] * self.DEPTH
+        self.gathered_upto = -1                     # newest frame whose slab has been handed to the collective
+        self.frame = 0
+        self._streams = {}                          # raw stream handle -> torch ExternalStream
+
+    def _stream(self):
+        h = self.p.stream()
+        if h not in self._streams:
+            self._streams[h] = torch.cuda.ExternalStream(h)
+        return self._streams[h]
+
+    def begin_frame(self):
+        g = self.frame
+        # the launch about to be issued may write the slab of frame g (pack at once), g - 1 or g - 2 (deferred packs): the previous
+        # collectives on those slabs (six or more frames old) must have finished -- waited for on every stream the pipeline has used so far
+        for b in {g % self.DEPTH, (g - 1) % self.DEPTH, (g - 2) % self.DEPTH}:
+            if self.work[b] is not None:
+                for st in self._streams.values():
+                    with torch.cuda.stream(st):
+                        self.work[b].wait()
+                self.work[b] = None
+        base = self.slab[g % self.DEPTH].data_ptr()
+        self.p.set_output_count(base)
+        self.p.set_output_buffers(base + 4 * self.HEADER_WORDS, base + 4 * (self.HEADER_WORDS + self.cap), self.cap)
+
+    def _gather(self, frame, st):
+        b = frame % self.DEPTH
+        with torch.cuda.stream(st):
+            self.work[b] = self.dist.all_gather_into_tensor(self.recv[b], self.slab[b], group=self.group, async_op=True)
+        self.gathered_upto = frame
+
+    def after_cull(self):
+        g = self.frame
+        st = self._stream()                         # the stream frame g was issued on
+        if g >= 2:
+            self._gather(g - 2, st)
+        self.frame += 1
+
+    def finish(self):
+        """after Pipeline.wait() (every pending pack has run): the slabs of the last frames, then wait for all collectives"""
+        st = self._stream()
+        for f in range(max(self.gathered_upto + 1, 0), self.frame):
+            self._gather(f, st)
+        for b in range(self.DEPTH):
+            if self.work[b] is not None:
+                self.work[b].wait(); self.work[b] = None
+        torch.cuda.synchronize()
+        return (self.frame - 1) % self.DEPTH
+
+    def gathered(self, b):
+        words = self.HEADER_WORDS + self.cap * 17
+        r = self.recv[b].view(self.world, words)
+        counts = [int(c) for c in r[:, 0].tolist()]
+        ids = torch.cat([r[k, self.HEADER_WORDS:self.HEADER_WORDS + min(counts[k], self.cap)] for k in range(self.world)])
+        mats = torch.cat([r[k, self.HEADER_WORDS + self.cap:].view(torch.float32).view(self.cap, 16)[:min(counts[k], self.cap)] for k in range(self.world)])
+        return ids, mats, counts

@@ -61,9 +61,29 @@ def main():
     o1 = np.argsort(ids.cpu().numpy().astype(np.uint32), kind="stable"); o2 = np.argsort(ref["ids"], kind="stable")
     np.testing.assert_array_equal(mats.cpu().numpy()[o1], ref["mats"][o2])
     assert p.stats()["n_fused_frames"] >= len(cams) - 2, p.stats()
+    # and with two frame lanes: frames alternate between two streams, the slab of frame g - 2 goes out behind launch g
+    p.close()
+    p = R.Pipeline(16384, atomic, max_instances=1 << 14); p.register_model_instances(mine)
+    g2 = parallel.SlabAllGatherLanes(p, 2048, dist)
+    cams2 = cams + [R.Camera((8192 + 11 * i, 8192 - 7 * i, 8450 - 13 * i), (0.01 * i, 0, -1), 900.0) for i in range(9)]
+    for cam in cams2:
+        g2.begin_frame()
+        p.cull_and_pack(cam, asynchronous=True, copy=False, defer_pack=True, two_lanes=True)
+        g2.after_cull()
+        p.tick(0.016, asynchronous=True)
+    p.wait(); b = g2.finish()
+    ids, mats, counts3 = g2.gathered(b)
+    for cam in cams2[len(cams):]:
+        ref = full.cull_and_pack(cam); full.tick(0.016)
+    assert sum(counts3) == ref["total"], (counts3, ref["total"])
+    np.testing.assert_array_equal(np.sort(ids.cpu().numpy().astype(np.uint32)), np.sort(ref["ids"]))
+    o1 = np.argsort(ids.cpu().numpy().astype(np.uint32), kind="stable"); o2 = np.argsort(ref["ids"], kind="stable")
+    np.testing.assert_array_equal(mats.cpu().numpy()[o1], ref["mats"][o2])
+    ids_prev, _, counts_prev = g2.gathered((b - 1) % g2.DEPTH)             # the frame before the last one went through the other lane
+    assert sum(counts_prev) > 0 and p.stats()["reserved"] >= len(cams2) - 3, p.stats()
     dist.barrier()
     if rank == 0:
-        print("OK slab all-gather", counts, counts2)
+        print("OK slab all-gather", counts, counts2, counts3)
     dist.destroy_process_group()
 
 
