@@ -143,6 +143,7 @@ struct re_ctx {
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
+    uint32_t tick_seq = 0;                            // ticks issued with a kernel: k_tick_publish writes the number into h_th->ticket behind the tick
     bool timings_on = false;                          // re_get_timings was asked for: synchronous frames record their kernel events (5 event records cost ~12 us per frame)
     bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;
     // RE_CULL_TWO_LANES: a second set of per-frame resources ("lane": stream, frame headers, instance lists, section stamps, frame
@@ -1507,8 +1508,24 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
         if (out) *out = c->last_tick;
         return RE_OK;
     }
-    int rc = resolve(c);
-    if (rc != RE_OK) return rc;
+    // fast completion: the counters arrive in mapped host memory behind the tick (k_tick_publish).  A tick that found movers or entities
+    // leaving the world (the stale word is raised before the counters are published) still needs resolve(): patch the tree, replay.
+    bool done = false;
+    if (!c->park_ready || !(c->park.busy || c->park.deferred_pack)) {
+        const volatile uint32_t *flag = &c->h_th->ticket;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !(done = (*flag == c->tick_seq)); spins++)
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+        if (done) { std::atomic_thread_fence(std::memory_order_acquire); if (c->h_spec && c->h_spec->stale) done = false; }
+    }
+    if (!done) {
+        int rc = resolve(c);
+        if (rc != RE_OK) return rc;
+        // (after resolve the stream has drained: the published counters are those of the last tick that ran, replays included)
+        const volatile uint32_t *flag = &c->h_th->ticket;
+        const auto t0 = std::chrono::steady_clock::now();
+        while (*flag != c->tick_seq && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200)) {}
+    } else c->pending.clear();
     c->tick_inflight = false;
     if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
     if (c->ndyn) { c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
@@ -1527,6 +1544,7 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
                            row_arrays(c), c->d_dyn_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
                            (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec);
         c->th_clean = false;
+        hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
     }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
         uint32_t m = std::max(c->ncells, c->nsh);
@@ -1557,7 +1575,7 @@ static int resolve(re_ctx *c) {
     { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->tick_inflight && c->ndyn && c->h_th) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 16, hipMemcpyDeviceToHost));   // n_changed, n_rebucket, n_oob of the last tick that ran
+    if (c->tick_inflight && c->ndyn && c->h_th) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost));   // n_changed, n_rebucket, n_oob of the last tick that ran
     while (c->h_spec && c->h_spec->stale) {
         const uint32_t sf = c->h_spec->stale_frame;
         c->h_spec->stale = 0; HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
@@ -1581,7 +1599,7 @@ static int resolve(re_ctx *c) {
             c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->ndyn) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 16, hipMemcpyDeviceToHost));
+        if (c->ndyn) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost));
     }
     c->pending.clear();
     return RE_OK;

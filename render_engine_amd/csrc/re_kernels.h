@@ -170,6 +170,7 @@ __global__ void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t move
                             uint2 *pairs, uint32_t pair_cap);
 __global__ void k_col_clear(const ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, uint8_t *row_moved, unsigned long long *tab_key, unsigned long long *tab_min,
                             ColHeader *h_hdr, uint32_t call);
+__global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq);
 struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)

@@ -1011,6 +1011,16 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
     tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, dyn_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec);
 }
 
+// The tick's counters for the host: a one-wave kernel behind k_tick copies them into mapped host memory and then publishes the tick's
+// sequence number there; the host polls that word instead of synchronising the stream and copying (and does not depend on what a
+// stream synchronise considers finished).
+__global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    h_th->n_changed = th->n_changed; h_th->n_rebucket = th->n_rebucket; h_th->n_oob = th->n_oob;
+    __threadfence_system();
+    h_th->ticket = seq;
+}
+
 // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + update_entity_in_tree (:325-351) for one entity whose
 // Position / Rotation / Scale changed: new TransformationMatrix and StaticAABB, out-of-bounds handling, and -- only when the
 // spatial-hash section differs (entity_exists_in_section, bounding_box_tree_v2.rs:765-782) -- an entry in the re-bucket list.
