@@ -1575,7 +1575,7 @@ static int resolve(re_ctx *c) {
     { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->tick_inflight && c->ndyn && c->h_th) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost));   // n_changed, n_rebucket, n_oob of the last tick that ran
+    if (c->tick_inflight && c->ndyn && c->h_th) { HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }   // (stream-ordered copy)   // n_changed, n_rebucket, n_oob of the last tick that ran
     while (c->h_spec && c->h_spec->stale) {
         const uint32_t sf = c->h_spec->stale_frame;
         c->h_spec->stale = 0; HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
@@ -1599,7 +1599,7 @@ static int resolve(re_ctx *c) {
             c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->ndyn) HIPCHK(c, hipMemcpy(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost));
+        if (c->ndyn) { HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
     }
     c->pending.clear();
     return RE_OK;
