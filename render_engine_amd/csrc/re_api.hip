@@ -143,6 +143,7 @@ struct re_ctx {
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
+    bool tick_published = false;                      // the tick in flight is followed by k_tick_publish (synchronous ticks; asynchronous ones are settled by resolve())
     uint32_t tick_seq = 0;                            // ticks issued with a kernel: k_tick_publish writes the number into h_th->ticket behind the tick
     bool timings_on = false;                          // re_get_timings was asked for: synchronous frames record their kernel events (5 event records cost ~12 us per frame)
     bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;
@@ -1511,7 +1512,7 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
     // fast completion: the counters arrive in mapped host memory behind the tick (k_tick_publish).  A tick that found movers or entities
     // leaving the world (the stale word is raised before the counters are published) still needs resolve(): patch the tree, replay.
     bool done = false;
-    if (!c->park_ready || !(c->park.busy || c->park.deferred_pack)) {
+    if (c->tick_published && (!c->park_ready || !(c->park.busy || c->park.deferred_pack))) {
         const volatile uint32_t *flag = &c->h_th->ticket;
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t spins = 0; !(done = (*flag == c->tick_seq)); spins++)
@@ -1524,7 +1525,7 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
         // (after resolve the stream has drained: the published counters are those of the last tick that ran, replays included)
         const volatile uint32_t *flag = &c->h_th->ticket;
         const auto t0 = std::chrono::steady_clock::now();
-        while (*flag != c->tick_seq && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200)) {}
+        while (c->tick_published && *flag != c->tick_seq && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200)) {}
     } else c->pending.clear();
     c->tick_inflight = false;
     if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
@@ -1544,7 +1545,8 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
                            row_arrays(c), c->d_dyn_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
                            (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec);
         c->th_clean = false;
-        hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
+        c->tick_published = !(flags & RE_TICK_ASYNC);
+        if (c->tick_published) hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
     }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
         uint32_t m = std::max(c->ncells, c->nsh);
