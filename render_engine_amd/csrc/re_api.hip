@@ -144,6 +144,7 @@ struct re_ctx {
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
     bool tick_published = false;                      // the tick in flight is followed by k_tick_publish (synchronous ticks; asynchronous ones are settled by resolve())
+    uint32_t tick_frame = 0xFFFFFFFFu;                // frame of the last tick issued
     uint32_t tick_seq = 0;                            // ticks issued with a kernel: k_tick_publish writes the number into h_th->ticket behind the tick
     bool timings_on = false;                          // re_get_timings was asked for: synchronous frames record their kernel events (5 event records cost ~12 us per frame)
     bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;
@@ -1543,7 +1544,7 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
         hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_dyn_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
-                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec);
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame);
         c->th_clean = false;
         c->tick_published = !(flags & RE_TICK_ASYNC);
         if (c->tick_published) hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
@@ -1566,6 +1567,9 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
     if (!(flags & RE_TICK_ALL_DYNAMIC) && !c->have_cull) return c->fail(RE_E_STATE, "re_tick: reference semantics tick entities of the last visibility query; call re_cull_pack first or pass RE_TICK_ALL_DYNAMIC");
     if (dt == 0.0f && c->has_rotvel) return c->fail(RE_E_ARG, "re_tick: delta_time == 0 with rotating entities (the reference asserts, exports/movement_components.rs:287)");
     HIPCHK(c, hipSetDevice(c->device));
+    // (a second tick of the same frame while the first is still in flight would carry the same frame number in the stale word: settle the first)
+    if (c->ndyn && c->tick_inflight && c->tick_frame == c->frame) { int rc0 = finish_tick(c, nullptr); if (rc0 != RE_OK) return rc0; }
+    c->tick_frame = c->frame;
     int rc = issue_tick(c, dt, flags);
     if (rc != RE_OK || (flags & RE_TICK_ASYNC)) return rc;
     return finish_tick(c, out);

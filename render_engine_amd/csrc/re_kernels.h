@@ -68,7 +68,7 @@ struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[
 // Speculation across frames of a world with dynamic entities: frames are enqueued without waiting for the previous tick; a tick that
 // finds entities that change section (or leave the world) raises `stale`, and every kernel enqueued after it cancels itself until the
 // host has patched the tree and replayed those frames.
-struct SpecState { uint32_t stale, stale_frame; };
+struct alignas(8) SpecState { uint32_t stale, stale_frame; };   // written and read as one 64-bit word by the tick (k_tick)
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
@@ -136,7 +136,7 @@ __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row,
 __global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *dyn_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
-                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec);
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame);
 // Probe path of the visibility query (opt-in, RE_CFG_PROBE): instead of streaming every section key, enumerate the cells of the two
 // candidate boxes (their bounding box per level) and look each one up in a device hash table key -> slot, like the reference's
 // own contains_key probes (visible_world_flow.rs:96-104).  Work is O(candidates), not O(sections).

@@ -994,7 +994,7 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
                                             const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                             const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb, const FrameParams &P, float dt, uint32_t tick_all,
                                             uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                            SpecState *spec, SpecState *h_spec);
+                                            SpecState *spec, SpecState *h_spec, uint32_t tick_frame);
 
 __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                               float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
@@ -1003,12 +1003,18 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                               const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
                                               TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                              SpecState *spec, SpecState *h_spec) {
-    if (spec->stale) return;                                   // an earlier tick left the tree stale: this frame is replayed by the host
+                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
+    // An EARLIER tick left the tree stale: this frame is replayed by the host.  The flag a workgroup of THIS tick raises when it finds a
+    // mover must not stop the workgroups of the same tick that start later (they would skip their entities for good): the frame travels
+    // with the flag in one 64-bit word.
+    {
+        const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(spec);
+        if ((uint32_t)w != 0u && (uint32_t)(w >> 32) != tick_frame) return;     // tick_frame: the frame this tick was issued for (a cancelled frame never wrote its parameters, so Pp->frame would be the stale one's)
+    }
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     // No completion ticket: the counters stay in device memory (the host copies the 16 bytes when it synchronises), and a workgroup
     // that finds a mover or an entity leaving the world raises `stale` itself -- idempotent stores, any number of workgroups may do it.
-    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, dyn_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec);
+    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, dyn_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec, tick_frame);
 }
 
 // The tick's counters for the host: a one-wave kernel behind k_tick copies them into mapped host memory and then publishes the tick's
@@ -1050,7 +1056,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     if (oob && !(fl & F_OOB_LOGIC)) {
         uint32_t slot = atomicAdd(&th->n_oob, 1u);
         if (slot < list_cap) oob_rows[slot] = r;
-        if (spec) { SpecState sp; sp.stale = 1u; sp.stale_frame = frame; *spec = sp; *h_spec = sp; }     // the host must retire the row before any later frame runs
+        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; *reinterpret_cast<volatile unsigned long long *>(h_spec) = w; }   // {stale = 1, stale_frame = frame} in one store     // the host must retire the row before any later frame runs
         R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
         return;
     }
@@ -1070,7 +1076,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     if (!same) {
         uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
         if (slot < list_cap) mover_rows[slot] = r | (translation_only ? 0x80000000u : 0u);   // bit 31: translation-only mover
-        if (spec) { SpecState sp; sp.stale = 1u; sp.stale_frame = frame; *spec = sp; *h_spec = sp; }     // the host must patch the tree before any later frame runs
+        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; *reinterpret_cast<volatile unsigned long long *>(h_spec) = w; }   // {stale = 1, stale_frame = frame} in one store     // the host must patch the tree before any later frame runs
     }
 }
 
@@ -1080,7 +1086,7 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
                                             const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                             const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                             const FrameParams &P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                            TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec) {
+                                            TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
     if (j >= ndyn) return;
     const uint32_t r = dyn_row[j], rc = dyn_cell[j];           // both coalesced; the flag word and the section stamp are then fetched together
     const bool unique_cell = rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED);
@@ -1158,7 +1164,7 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
     if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
     if (rot_set) { R.rot[r * 4 + 0] = rot[0]; R.rot[r * 4 + 1] = rot[1]; R.rot[r * 4 + 2] = rot[2]; R.rot[r * 4 + 3] = rot[3]; }
 
-    place_changed_entity(r, fl, nfl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec, P.frame);
+    place_changed_entity(r, fl, nfl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec, tick_frame);
 }
 
 // section decision (add_entity with add_if_out_bounds = true: the box is clamped) for a list of rows, from their current StaticAABB;

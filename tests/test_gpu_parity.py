@@ -513,6 +513,32 @@ def test_rejected_calls_leave_the_world_untouched(R):
     p.close(); w.close()
 
 
+def test_tick_with_many_movers_ticks_every_entity(R):
+    """a tick whose first workgroups find entities that change world section raises the "tree is stale" word for the frames behind it;
+    the workgroups of the same tick that start later must still process their entities (regression: they read the word and returned,
+    so a box-dependent handful of entities was never ticked).  Enough dynamic entities for ~100 workgroups, most of them movers."""
+    ents = R.synthetic.mixed_world(60000, seed=77, spread=1500.0)
+    ents["vel"] *= 10.0
+    p, w = build_pair(R, ents)
+    cam = R.Camera((8192, 8192, 9800), (0, 0, -1), 4000.0)
+    for f in range(4):
+        check_frame(R, p, w, cam, False)
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.05)
+        t = p.tick(0.05)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o), (f, t, n_o)
+        assert t["n_rebucket"] > 100
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::50])
+    # the same through asynchronous frames (speculation: the frames behind a stale tick cancel themselves and are replayed)
+    for f in range(4):
+        p.cull_and_pack(cam, asynchronous=True, copy=False); p.tick(0.05, asynchronous=True)
+        oc = oracle_camera(cam); w.cull(oc); w.render(oc); w.tick(oc, 0.05)
+    p.wait()
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::50])
+    p.close(); w.close()
+
+
 def sorted_pairs(a):
     a = np.asarray(a, np.uint32).reshape(-1, 2)
     return a[np.lexsort((a[:, 1], a[:, 0]))]
