@@ -837,7 +837,16 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     c->timings_pending = c->timed_frame;                                      // the events are read in re_get_timings (they may still be in flight here)
     c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
     {   // every instance the cull reserved must have been counted into a group (dead rows excepted): otherwise a cursor segment overflowed
-        uint32_t counted = 0; for (uint32_t g = 0; g < c->h_res->n_groups && g < c->nslots; g++) counted += c->h_ranges[g].count;
+        // The table and the counts reach host memory as separate posted writes; "frame done" is written behind a system-scope fence, but
+        // on some boxes the last table words have been seen to land after it.  The sum is the cross-check: wait for it to agree (the data
+        // is on its way), and only a table that still disagrees once the stream has drained is an error.
+        auto counted_groups = [&]() { uint32_t n = 0; const volatile InstanceRange *r = c->h_ranges; for (uint32_t g = 0; g < c->h_res->n_groups && g < c->nslots; g++) n += r[g].count; return n; };
+        uint32_t counted = counted_groups();
+        if (counted != c->h_res->total) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while ((counted = counted_groups()) != c->h_res->total && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {}
+            if (counted != c->h_res->total) { HIPCHK(c, hipStreamSynchronize(c->stream)); std::atomic_thread_fence(std::memory_order_acquire); counted = counted_groups(); }
+        }
         if (counted != c->h_res->total) return c->fail(RE_E_STATE, "group table inconsistent (%u vs %u)", counted, c->h_res->total);
         if (c->h_res->n_items > c->h_res->total + c->n_dead + (uint32_t)c->h_uncached.size()) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
     }
@@ -1529,7 +1538,7 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
         while (c->tick_published && *flag != c->tick_seq && std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(200)) {}
     } else c->pending.clear();
     c->tick_inflight = false;
-    if (c->timed_tick) { (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
+    if (c->timed_tick) { (void)hipEventSynchronize(c->ev[4]); (void)hipEventElapsedTime(&c->t_tick, c->ev[3], c->ev[4]); c->t_tick *= 1000.f; }
     if (c->ndyn) { c->last_tick.n_changed = c->h_th->n_changed; c->last_tick.n_rebucket = c->h_th->n_rebucket; c->last_tick.n_out_of_bounds = c->h_th->n_oob; }
     else c->last_tick = re_tick_result{ 0, 0, 0 };
     if (out) *out = c->last_tick;
