@@ -840,7 +840,16 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         // The table and the counts reach host memory as separate posted writes; "frame done" is written behind a system-scope fence, but
         // on some boxes the last table words have been seen to land after it.  The sum is the cross-check: wait for it to agree (the data
         // is on its way), and only a table that still disagrees once the stream has drained is an error.
-        auto counted_groups = [&]() { uint32_t n = 0; const volatile InstanceRange *r = c->h_ranges; for (uint32_t g = 0; g < c->h_res->n_groups && g < c->nslots; g++) n += r[g].count; return n; };
+        auto counted_groups = [&]() {
+            uint32_t n = 0, hsh = 0; const volatile InstanceRange *r = c->h_ranges; const volatile uint32_t *wds = reinterpret_cast<const volatile uint32_t *>(c->h_ranges);
+            const uint32_t ng = std::min(c->h_res->n_groups, c->nslots);
+            for (uint32_t g = 0; g < ng; g++) n += r[g].count;
+            if (c->h_res->table_hash) {                                       // the whole table, not just the counts
+                for (uint32_t w2 = 0; w2 < ng * (uint32_t)(sizeof(InstanceRange) / 4u); w2++) hsh ^= table_word_hash(wds[w2], w2);
+                if ((hsh | 1u) != c->h_res->table_hash) return 0xFFFFFFFFu;
+            }
+            return n;
+        };
         uint32_t counted = counted_groups();
         if (counted != c->h_res->total) {
             const auto t0 = std::chrono::steady_clock::now();

@@ -70,9 +70,12 @@ struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[
 // host has patched the tree and replayed those frames.
 struct alignas(8) SpecState { uint32_t stale, stale_frame; };   // written and read as one 64-bit word by the tick (k_tick)
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
+// position-dependent hash of one table word (device and host)
+RE_HD uint32_t table_word_hash(uint32_t v, uint32_t w) { uint32_t x = (v ^ (w * 0x9E3779B1u)) * 0x85EBCA6Bu; return x ^ (x >> 15); }
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
-    uint32_t done_frame, pad;               // written last (after a system-scope fence): the frame whose results above are complete -- a synchronous
+    uint32_t done_frame, table_hash;        // table_hash: hash of the InstanceRange table words k_pack_small wrote to host memory (0: none), so the reader can tell a table whose
+                                            // posted writes have not all landed yet.  done_frame: written last (after a system-scope fence): the frame whose results above are complete -- a synchronous
                                             // call polls this word instead of paying the driver's stream-synchronise latency
 };
 constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances k_pack_small takes (every workgroup counts all of them); more go through the count/scan/scatter path

@@ -899,16 +899,19 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
         if (wid == 0) {
             for (int d = 32; d >= 1; d >>= 1) { fc_a += __shfl_xor(fc_a, d, 64); fc_b += __shfl_xor(fc_b, d, 64); fc_c += __shfl_xor(fc_c, d, 64); }
             FrameCounts fc; fc.n_candidates = fc_a; fc.n_vis_map = fc_b; fc.n_vis_vec = fc_c;
+            uint32_t table_hash = 0;
             if (staged && !overflow) {                          // the table, by this wave alone
                 const uint32_t nw = s_gcarry * (uint32_t)(sizeof(InstanceRange) / 4u);
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(s_rng); uint32_t *dst = reinterpret_cast<uint32_t *>(A.ranges);
-                for (uint32_t w = lane; w < nw; w += 64u) dst[w] = src[w];
+                for (uint32_t w = lane; w < nw; w += 64u) { const uint32_t v = src[w]; dst[w] = v; table_hash ^= table_word_hash(v, w); }
+                for (int d = 32; d >= 1; d >>= 1) table_hash ^= __shfl_xor(table_hash, d, 64);
+                table_hash |= 1u;                                 // 0 = "no hash" (the multi-kernel pack: its reader synchronises the stream)
                 __threadfence_system();                         // every lane's table words before lane 0 publishes
             }
             if (lane == 0) {
                 HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;   // (never read the mapped host struct: a PCIe round trip)
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
-                r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
+                r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items; r.table_hash = table_hash;
                 *A.hres = r;                                        // mapped pinned host memory
                 if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
                 __threadfence_system(); A.hres->done_frame = A.frame;   // the group table and the counters above are complete
