@@ -846,7 +846,8 @@ static int finish_cull(re_ctx *c, re_visible *out) {
             for (uint32_t g = 0; g < ng; g++) n += r[g].count;
             if (c->h_res->table_hash) {                                       // the whole table, not just the counts
                 for (uint32_t w2 = 0; w2 < ng * (uint32_t)(sizeof(InstanceRange) / 4u); w2++) hsh ^= table_word_hash(wds[w2], w2);
-                if ((hsh | 1u) != c->h_res->table_hash) return 0xFFFFFFFFu;
+                const volatile HostResult *hr = c->h_res;
+                if (result_seal(hsh | 1u, c->frame, hr->n_groups, hr->total, hr->n_vis_map, hr->n_vis_vec, hr->n_items) != hr->table_hash) return 0xFFFFFFFFu;
             }
             return n;
         };
@@ -1536,7 +1537,13 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
         const auto t0 = std::chrono::steady_clock::now();
         for (uint32_t spins = 0; !(done = (*flag == c->tick_seq)); spins++)
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
-        if (done) { std::atomic_thread_fence(std::memory_order_acquire); if (c->h_spec && c->h_spec->stale) done = false; }
+        if (done) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            auto sealed = [&]() { const volatile TickHeader *t = c->h_th; return t->pad[0] == (table_word_hash(t->n_changed, 1u) ^ table_word_hash(t->n_rebucket, 2u) ^ table_word_hash(t->n_oob, 3u) ^ table_word_hash(c->tick_seq, 4u)); };
+            const auto t1 = std::chrono::steady_clock::now();
+            while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(200)) {}     // counters landing behind the sequence word
+            if (!sealed() || (c->h_spec && c->h_spec->stale)) done = false;
+        }
     }
     if (!done) {
         int rc = resolve(c);
@@ -1887,6 +1894,10 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
         if (!done) HIPCHK(c, hipStreamSynchronize(st));
         std::atomic_thread_fence(std::memory_order_acquire);
+        auto sealed = [&]() { const volatile ColHeader *q = c->h_col; return q->pad[0] == (table_word_hash(q->n_region, 1u) ^ table_word_hash(q->n_high, 2u) ^ table_word_hash(q->n_shared, 3u) ^ table_word_hash(q->n_moved, 4u) ^ table_word_hash(q->n_pairs, 5u) ^ table_word_hash(q->n_near, 6u) ^ table_word_hash(c->col_calls, 7u)); };
+        const auto t1 = std::chrono::steady_clock::now();
+        while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(500)) {}
+        if (!sealed()) { HIPCHK(c, hipStreamSynchronize(st)); std::atomic_thread_fence(std::memory_order_acquire); }
         h = *c->h_col;
     }
     if (h.n_region > COL_REGION_CAP || h.n_high > COL_REGION_CAP) return c->fail(RE_E_CAPACITY, "re_collide: %u world sections around the camera exceed the region list (%u)", h.n_region, COL_REGION_CAP);

@@ -72,6 +72,10 @@ struct alignas(8) SpecState { uint32_t stale, stale_frame; };   // written and r
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 // position-dependent hash of one table word (device and host)
 RE_HD uint32_t table_word_hash(uint32_t v, uint32_t w) { uint32_t x = (v ^ (w * 0x9E3779B1u)) * 0x85EBCA6Bu; return x ^ (x >> 15); }
+struct HostResult;
+RE_HD uint32_t result_seal(uint32_t table_hash, uint32_t frame, uint32_t n_groups, uint32_t total, uint32_t n_vis_map, uint32_t n_vis_vec, uint32_t n_items) {   // ties the table hash to the frame and the counts
+    return (table_hash ^ table_word_hash(frame, 0x101u) ^ table_word_hash(n_groups, 0x102u) ^ table_word_hash(total, 0x103u) ^ table_word_hash(n_vis_map, 0x104u) ^ table_word_hash(n_vis_vec, 0x105u) ^ table_word_hash(n_items, 0x106u)) | 1u;
+}
 struct HostResult {
     uint32_t n_vis_map, n_vis_vec, n_groups, total, n_candidates, overflow, n_entries, n_items;
     uint32_t done_frame, table_hash;        // table_hash: hash of the InstanceRange table words k_pack_small wrote to host memory (0: none), so the reader can tell a table whose

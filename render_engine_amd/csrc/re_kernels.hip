@@ -911,7 +911,8 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
             if (lane == 0) {
                 HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;   // (never read the mapped host struct: a PCIe round trip)
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
-                r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items; r.table_hash = table_hash;
+                r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
+                r.table_hash = table_hash ? result_seal(table_hash, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items) : 0u;
                 *A.hres = r;                                        // mapped pinned host memory
                 if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
                 __threadfence_system(); A.hres->done_frame = A.frame;   // the group table and the counters above are complete
@@ -1025,7 +1026,8 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__r
 // stream synchronise considers finished).
 __global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    h_th->n_changed = th->n_changed; h_th->n_rebucket = th->n_rebucket; h_th->n_oob = th->n_oob;
+    const uint32_t a = th->n_changed, b = th->n_rebucket, c2 = th->n_oob;
+    h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
     __threadfence_system();
     h_th->ticket = seq;
 }
