@@ -416,6 +416,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     HIPCHK(c, c->d_cell_key.alloc(keys_padded.size(), acct));
     HIPCHK(c, c->d_cell_tight.alloc(ncells, acct)); HIPCHK(c, c->d_cell_begin.alloc(ncells + 1, acct)); HIPCHK(c, c->d_cell_nlocal.alloc(ncells, acct));
     HIPCHK(c, c->d_cell_nstatic.alloc(ncells, acct)); HIPCHK(c, c->d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, c->d_cell_flags.alloc(ncells, acct));
+    if (c->park_ready) { HIPCHK(c, c->park.d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, hipMemset(c->park.d_cell_stamp.p, 0, (size_t)std::max(ncells, 1u) * 4)); }   // the parked lane's stamps follow a rebuilt table (it is idle: rebuilds happen behind drain_other_lane)
     c->pool_used = (uint32_t)rows.size(); c->pool_cap = c->pool_used + ((c->cfg.flags & RE_CFG_TIGHT_SLACK) ? 96u : c->pool_used / 4u + 65536u);      // slack: re-bucket patches append relocated segments
     HIPCHK(c, c->d_rows.alloc(c->pool_cap, acct)); HIPCHK(c, c->d_row_cell.alloc(n, acct));
     HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
