@@ -218,7 +218,7 @@ def main():
                        "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), slabs in rotation, stream-ordered behind the launch that carries the pack" % SLAB_INSTANCES},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_probe_cull" if probed else ("k_scan_cull_fused (scan of frame f+1 + pack of frame f in one launch)" if fused else "k_scan_cull"), "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
+                         "kernel": "k_probe_cull" if probed else (("k_scan_cull_fused (scan of frame f + pack of frame f-2 in one launch; frames alternate between two streams)" if lanes else "k_scan_cull_fused (scan of frame f+1 + pack of frame f in one launch)") if fused else "k_scan_cull"), "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
                          "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY},
             "frame_latency_ms_sync": float(np.median(lat) * 1e3),
             "kernel_us_last_frame": tm, "setup_s": t_setup,
