@@ -255,6 +255,9 @@ typedef struct {
     uint32_t n_entities, n_dynamic, n_sections, n_shared_sections, max_level;
     uint64_t device_bytes;
     uint32_t n_probe_frames, n_table_rebuilds, n_fused_frames, reserved /* lane switches */;   /* frames served by the probe path (RE_CFG_PROBE); full section-table rebuilds so far */
+    uint32_t n_seal_waits;      /* result blocks in mapped host memory (frame result + InstanceRange table, tick counters, collision header) whose
+                                 * seal did not agree when the polled "done" word became visible.  0 while the publication protocol holds. */
+    uint32_t n_sync_fallbacks;  /* of those, blocks that only agreed after a stream synchronise */
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,

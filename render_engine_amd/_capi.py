@@ -61,7 +61,8 @@ class TickResult(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_entities", C.c_uint32), ("n_dynamic", C.c_uint32), ("n_sections", C.c_uint32),
                 ("n_shared_sections", C.c_uint32), ("max_level", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("n_probe_frames", C.c_uint32), ("n_table_rebuilds", C.c_uint32), ("n_fused_frames", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_probe_frames", C.c_uint32), ("n_table_rebuilds", C.c_uint32), ("n_fused_frames", C.c_uint32), ("reserved", C.c_uint32),
+                ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32)]
 
 
 class LightingConfig(C.Structure):

@@ -140,6 +140,8 @@ struct re_ctx {
     std::vector<uint32_t> h_oob_ids;                    // entities removed because they left the world, since the last re_get_out_of_bounds
     std::vector<PendingCall> pending;                   // calls enqueued since the last resolved synchronisation, in order
     HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr; TickHeader *h_th = nullptr, *d_hth = nullptr;
+    void *h_block = nullptr;                           // the one mapped, coherent host block those four live in (alloc_host_block)
+    uint32_t n_seal_waits = 0, n_sync_fallbacks = 0;  // a polled block whose seal did not agree at first sight / that needed a stream synchronise: both stay 0 when the publication protocol holds
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
@@ -154,7 +156,7 @@ struct re_ctx {
     // consecutive frames sit on different streams and overlap; everything else first drains the other lane (drain_other_lane).
     struct LanePark {
         hipStream_t stream = nullptr; DevBuf<FrameHeader> d_hdr; DevBuf<uint32_t> d_item_row, d_item_slot, d_out_ids, d_cell_stamp; DevBuf<float> d_out_mats; DevBuf<FrameParams> d_params;
-        HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr;
+        HostResult *h_res = nullptr, *d_hres = nullptr; InstanceRange *h_ranges = nullptr, *d_hranges = nullptr; void *h_block = nullptr;
         bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, lane_seq = 0; bool busy = false;
     } park;
     bool park_ready = false, lane_busy = false; uint32_t lane_seq = 0, lane_id = 0, n_lane_switches = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
@@ -170,7 +172,22 @@ struct re_ctx {
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (ctx)->fail(RE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-extern "C" uint32_t re_abi_version(void) { return 1u; }
+extern "C" uint32_t re_abi_version(void) { return 2u; }
+
+// Everything the kernels publish to the polling host thread lives in ONE block of mapped, coherent pinned host memory per frame lane
+// (hipHostMallocMapped | hipHostMallocCoherent): the frame result at 0, the speculation word at 128, the tick counters at 256, the
+// InstanceRange table from 4096 on.  (Round 1 used four separate hipHostMalloc(Mapped) blocks; what made its group table arrive after
+// the "frame done" word was not the number of blocks but the plain store of that word -- see publish_to_host in re_kernels.h.)
+constexpr size_t HB_RES = 0, HB_SPEC = 128, HB_TICK = 256, HB_RANGES = 4096;
+static_assert(sizeof(HostResult) <= HB_SPEC && sizeof(SpecState) <= HB_TICK - HB_SPEC && HB_TICK + sizeof(TickHeader) <= HB_RANGES, "host block layout");
+static hipError_t alloc_host_block(uint32_t nslots, void **host, void **dev) {
+    const size_t bytes = HB_RANGES + sizeof(InstanceRange) * (size_t)std::max(nslots, 1u);
+    hipError_t e = hipHostMalloc(host, bytes, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e != hipSuccess) return e;
+    memset(*host, 0, bytes);
+    return hipHostGetDevicePointer(dev, *host, 0);
+}
+template <typename T> static inline T *hb_at(void *base, size_t off) { return reinterpret_cast<T *>(static_cast<char *>(base) + off); }
 
 extern "C" const char *re_last_error(const re_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -204,10 +221,8 @@ static void free_world(re_ctx *c) {
     c->d_gc_model.release(a); c->d_gc_rs.release(a); c->d_gc_sort.release(a); c->d_group_count.release(a); c->d_group_begin.release(a); c->d_group_fill.release(a);
     c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
     c->d_hdr.release(a); c->d_th.release(a); c->d_params.release(a); c->d_movers.release(a); c->d_oob.release(a);
-    if (c->h_res) { (void)hipHostFree(c->h_res); c->h_res = nullptr; }
-    if (c->h_ranges) { (void)hipHostFree(c->h_ranges); c->h_ranges = nullptr; }
-    if (c->h_th) { (void)hipHostFree(c->h_th); c->h_th = nullptr; }
-    if (c->h_spec) { (void)hipHostFree(c->h_spec); c->h_spec = nullptr; }
+    if (c->h_block) { (void)hipHostFree(c->h_block); c->h_block = nullptr; }      // one block: frame result, speculation word, tick counters, group table
+    c->h_res = nullptr; c->h_ranges = nullptr; c->h_th = nullptr; c->h_spec = nullptr;
     c->d_spec.release(nullptr); c->pending.clear();
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false; c->deferred_pack = false;
 }
@@ -640,16 +655,16 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 8)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 8));   // the pack reads speculatively past the cursors
     HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
     HIPCHK(c, c->d_hdr.alloc(NUM_FRAME_HEADERS, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_res), sizeof(HostResult), hipHostMallocMapped));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocMapped));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_th), sizeof(TickHeader), hipHostMallocMapped));
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hres), c->h_res, 0));
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hranges), c->h_ranges, 0));
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hth), c->h_th, 0));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_spec), sizeof(SpecState), hipHostMallocMapped));
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hspec), c->h_spec, 0));
-    memset(c->h_spec, 0, sizeof(SpecState)); HIPCHK(c, c->d_spec.alloc(1, nullptr)); HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
-    memset(c->h_res, 0, sizeof(HostResult)); memset(c->h_th, 0, sizeof(TickHeader));
+    {
+        void *hb = nullptr, *db = nullptr;
+        HIPCHK(c, alloc_host_block(c->nslots, &hb, &db));
+        c->h_block = hb;
+        c->h_res = hb_at<HostResult>(hb, HB_RES); c->d_hres = hb_at<HostResult>(db, HB_RES);
+        c->h_spec = hb_at<SpecState>(hb, HB_SPEC); c->d_hspec = hb_at<SpecState>(db, HB_SPEC);
+        c->h_th = hb_at<TickHeader>(hb, HB_TICK); c->d_hth = hb_at<TickHeader>(db, HB_TICK);
+        c->h_ranges = hb_at<InstanceRange>(hb, HB_RANGES); c->d_hranges = hb_at<InstanceRange>(db, HB_RANGES);
+    }
+    HIPCHK(c, c->d_spec.alloc(1, nullptr)); HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
     HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -837,28 +852,28 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     }
     c->timings_pending = c->timed_frame;                                      // the events are read in re_get_timings (they may still be in flight here)
     c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
-    {   // every instance the cull reserved must have been counted into a group (dead rows excepted): otherwise a cursor segment overflowed
-        // The table and the counts reach host memory as separate posted writes; "frame done" is written behind a system-scope fence, but
-        // on some boxes the last table words have been seen to land after it.  The sum is the cross-check: wait for it to agree (the data
-        // is on its way), and only a table that still disagrees once the stream has drained is an error.
-        auto counted_groups = [&]() {
-            uint32_t n = 0, hsh = 0; const volatile InstanceRange *r = c->h_ranges; const volatile uint32_t *wds = reinterpret_cast<const volatile uint32_t *>(c->h_ranges);
-            const uint32_t ng = std::min(c->h_res->n_groups, c->nslots);
-            for (uint32_t g = 0; g < ng; g++) n += r[g].count;
-            if (c->h_res->table_hash) {                                       // the whole table, not just the counts
-                for (uint32_t w2 = 0; w2 < ng * (uint32_t)(sizeof(InstanceRange) / 4u); w2++) hsh ^= table_word_hash(wds[w2], w2);
-                const volatile HostResult *hr = c->h_res;
-                if (result_seal(hsh | 1u, c->frame, hr->n_groups, hr->total, hr->n_vis_map, hr->n_vis_vec, hr->n_items) != hr->table_hash) return 0xFFFFFFFFu;
+    {   // The group table carries a seal: a hash over every table word, tied to the frame number and the counts (result_seal).  With the
+        // publication protocol of publish_to_host the block is complete when "frame done" is visible, so the check below passes at first
+        // sight; n_seal_waits / n_sync_fallbacks (re_stats) count the times it did not, and the GPU tests assert that both stay 0.
+        // Every instance the cull reserved must also have been counted into a group (dead rows excepted): otherwise a cursor segment overflowed.
+        auto table_ok = [&]() -> bool {
+            uint32_t n = 0, hsh = 0; const volatile HostResult *hr = c->h_res; const volatile uint32_t *wds = reinterpret_cast<const volatile uint32_t *>(c->h_ranges);
+            const uint32_t ng = std::min((uint32_t)hr->n_groups, c->nslots), nw = (uint32_t)(sizeof(InstanceRange) / 4u);
+            for (uint32_t g = 0; g < ng; g++) {
+                for (uint32_t k = 0; k < nw; k++) hsh ^= table_word_hash(wds[g * nw + k], g * nw + k);
+                n += wds[g * nw + 4u];                                         // InstanceRange::count
             }
-            return n;
+            if (hr->table_hash && result_seal(hsh | 1u, c->frame, hr->n_groups, hr->total, hr->n_vis_map, hr->n_vis_vec, hr->n_items) != hr->table_hash) return false;
+            return n == hr->total;
         };
-        uint32_t counted = counted_groups();
-        if (counted != c->h_res->total) {
+        if (!table_ok()) {
+            c->n_seal_waits++;
             const auto t0 = std::chrono::steady_clock::now();
-            while ((counted = counted_groups()) != c->h_res->total && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {}
-            if (counted != c->h_res->total) { HIPCHK(c, hipStreamSynchronize(c->stream)); std::atomic_thread_fence(std::memory_order_acquire); counted = counted_groups(); }
+            bool ok = false;
+            while (!(ok = table_ok()) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {}
+            if (!ok) { c->n_sync_fallbacks++; HIPCHK(c, hipStreamSynchronize(c->stream)); std::atomic_thread_fence(std::memory_order_acquire); ok = table_ok(); }
+            if (!ok) return c->fail(RE_E_STATE, "group table inconsistent with its seal (frame %u, %u groups, %u instances)", c->frame, c->h_res->n_groups, c->h_res->total);
         }
-        if (counted != c->h_res->total) return c->fail(RE_E_STATE, "group table inconsistent (%u vs %u)", counted, c->h_res->total);
         if (c->h_res->n_items > c->h_res->total + c->n_dead + (uint32_t)c->h_uncached.size()) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
     }
     if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
@@ -872,7 +887,7 @@ static void switch_lane(re_ctx *c) {
     re_ctx::LanePark &k = c->park;
     std::swap(c->stream, k.stream); std::swap(c->d_hdr, k.d_hdr); std::swap(c->d_item_row, k.d_item_row); std::swap(c->d_item_slot, k.d_item_slot);
     std::swap(c->d_out_ids, k.d_out_ids); std::swap(c->d_out_mats, k.d_out_mats); std::swap(c->d_cell_stamp, k.d_cell_stamp); std::swap(c->d_params, k.d_params);
-    std::swap(c->h_res, k.h_res); std::swap(c->d_hres, k.d_hres); std::swap(c->h_ranges, k.h_ranges); std::swap(c->d_hranges, k.d_hranges);
+    std::swap(c->h_res, k.h_res); std::swap(c->d_hres, k.d_hres); std::swap(c->h_ranges, k.h_ranges); std::swap(c->d_hranges, k.d_hranges);   // (h_block stays: lane 0's block also holds the tick counters and the speculation word)
     std::swap(c->deferred_pack, k.deferred_pack); std::swap(c->deferred, k.deferred); std::swap(c->deferred_grid, k.deferred_grid);
     std::swap(c->lane_seq, k.lane_seq); std::swap(c->lane_busy, k.busy);
     c->lane_id ^= 1u; c->n_lane_switches++;
@@ -887,9 +902,13 @@ static int ensure_second_lane(re_ctx *c) {
     HIPCHK(c, k.d_cell_stamp.alloc(std::max<size_t>(c->d_cell_stamp.n, 1), acct)); HIPCHK(c, k.d_params.alloc(1, acct));
     HIPCHK(c, hipMemset(k.d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader))); HIPCHK(c, hipMemset(k.d_item_row.p, 0, (size_t)c->item_cap * 8)); HIPCHK(c, hipMemset(k.d_item_slot.p, 0xFF, (size_t)c->item_cap * 8));
     HIPCHK(c, hipMemset(k.d_cell_stamp.p, 0, k.d_cell_stamp.n * 4));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&k.h_res), sizeof(HostResult), hipHostMallocMapped)); memset(k.h_res, 0, sizeof(HostResult));
-    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&k.h_ranges), sizeof(InstanceRange) * std::max(c->nslots, 1u), hipHostMallocMapped));
-    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&k.d_hres), k.h_res, 0)); HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&k.d_hranges), k.h_ranges, 0));
+    {
+        void *hb = nullptr, *db = nullptr;
+        HIPCHK(c, alloc_host_block(c->nslots, &hb, &db));
+        k.h_block = hb;
+        k.h_res = hb_at<HostResult>(hb, HB_RES); k.d_hres = hb_at<HostResult>(db, HB_RES);
+        k.h_ranges = hb_at<InstanceRange>(hb, HB_RANGES); k.d_hranges = hb_at<InstanceRange>(db, HB_RANGES);
+    }
     k.deferred_pack = false; k.lane_seq = 0; k.busy = false;
     c->park_ready = true;
     return RE_OK;
@@ -899,8 +918,8 @@ static void free_second_lane(re_ctx *c) {
     re_ctx::LanePark &k = c->park; uint64_t *acct = &c->dev_bytes;
     if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
     k.d_hdr.release(acct); k.d_item_row.release(acct); k.d_item_slot.release(acct); k.d_out_ids.release(acct); k.d_out_mats.release(acct); k.d_cell_stamp.release(acct); k.d_params.release(acct);
-    if (k.h_res) { (void)hipHostFree(k.h_res); k.h_res = nullptr; k.d_hres = nullptr; }
-    if (k.h_ranges) { (void)hipHostFree(k.h_ranges); k.h_ranges = nullptr; k.d_hranges = nullptr; }
+    if (k.h_block) { (void)hipHostFree(k.h_block); k.h_block = nullptr; }
+    k.h_res = nullptr; k.d_hres = nullptr; k.h_ranges = nullptr; k.d_hranges = nullptr;
     k.deferred_pack = false; k.busy = false; c->park_ready = false;
 }
 static int flush_deferred_pack(re_ctx *c);
@@ -1541,8 +1560,12 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
         if (done) {
             std::atomic_thread_fence(std::memory_order_acquire);
             auto sealed = [&]() { const volatile TickHeader *t = c->h_th; return t->pad[0] == (table_word_hash(t->n_changed, 1u) ^ table_word_hash(t->n_rebucket, 2u) ^ table_word_hash(t->n_oob, 3u) ^ table_word_hash(c->tick_seq, 4u)); };
-            const auto t1 = std::chrono::steady_clock::now();
-            while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(200)) {}     // counters landing behind the sequence word
+            if (!sealed()) {                                                  // (does not happen with publish_to_host; counted, and asserted to be 0 by the tests)
+                c->n_seal_waits++;
+                const auto t1 = std::chrono::steady_clock::now();
+                while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(200)) {}
+                if (!sealed()) c->n_sync_fallbacks++;
+            }
             if (!sealed() || (c->h_spec && c->h_spec->stale)) done = false;
         }
     }
@@ -1856,7 +1879,7 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
     if (!c->d_col_hdr.p) {
         HIPCHK(c, c->d_col_hdr.alloc(1, nullptr)); HIPCHK(c, c->d_col_region.alloc(COL_REGION_CAP, nullptr)); HIPCHK(c, c->d_col_high.alloc(COL_REGION_CAP, nullptr));
         HIPCHK(c, c->d_col_shared.alloc(COL_SHARED_CAP, nullptr)); HIPCHK(c, c->d_col_near.alloc(COL_REGION_CAP, nullptr));
-        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_col), sizeof(ColHeader), hipHostMallocMapped)); memset(c->h_col, 0, sizeof(ColHeader));
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_col), sizeof(ColHeader), hipHostMallocMapped | hipHostMallocCoherent)); memset(c->h_col, 0, sizeof(ColHeader));
         HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_hcol), c->h_col, 0));
     }
     if (!c->col_moved_cap) {
@@ -1896,9 +1919,12 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
         if (!done) HIPCHK(c, hipStreamSynchronize(st));
         std::atomic_thread_fence(std::memory_order_acquire);
         auto sealed = [&]() { const volatile ColHeader *q = c->h_col; return q->pad[0] == (table_word_hash(q->n_region, 1u) ^ table_word_hash(q->n_high, 2u) ^ table_word_hash(q->n_shared, 3u) ^ table_word_hash(q->n_moved, 4u) ^ table_word_hash(q->n_pairs, 5u) ^ table_word_hash(q->n_near, 6u) ^ table_word_hash(c->col_calls, 7u)); };
-        const auto t1 = std::chrono::steady_clock::now();
-        while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(500)) {}
-        if (!sealed()) { HIPCHK(c, hipStreamSynchronize(st)); std::atomic_thread_fence(std::memory_order_acquire); }
+        if (!sealed()) {                                                      // (as in finish_cull: counted, asserted to be 0 by the tests)
+            c->n_seal_waits++;
+            const auto t1 = std::chrono::steady_clock::now();
+            while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(500)) {}
+            if (!sealed()) { c->n_sync_fallbacks++; HIPCHK(c, hipStreamSynchronize(st)); std::atomic_thread_fence(std::memory_order_acquire); }
+        }
         h = *c->h_col;
     }
     if (h.n_region > COL_REGION_CAP || h.n_high > COL_REGION_CAP) return c->fail(RE_E_CAPACITY, "re_collide: %u world sections around the camera exceed the region list (%u)", h.n_region, COL_REGION_CAP);
@@ -1992,7 +2018,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks;
     return RE_OK;
 }
 

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_col_clear(const ColHeader *hdr, const C
     if (i == 0) {                                                            // the counts, into mapped host memory: the host polls pad[1] instead of synchronising the stream
         ColHeader h = *hdr; h.pad[1] = 0;
         h.pad[0] = table_word_hash(h.n_region, 1u) ^ table_word_hash(h.n_high, 2u) ^ table_word_hash(h.n_shared, 3u) ^ table_word_hash(h.n_moved, 4u) ^ table_word_hash(h.n_pairs, 5u) ^ table_word_hash(h.n_near, 6u) ^ table_word_hash(call, 7u);   // seal
-        *h_hdr = h; __threadfence_system(); h_hdr->pad[1] = call;
+        *h_hdr = h; publish_to_host(&h_hdr->pad[1], call);
     }
     if (i >= min(hdr->n_moved, moved_cap)) return;
     const ColMoved m = moved[i];

@@ -72,6 +72,24 @@ struct alignas(8) SpecState { uint32_t stale, stale_frame; };   // written and r
 // per-frame results the kernels write straight into mapped pinned host memory (no copy kernels)
 // position-dependent hash of one table word (device and host)
 RE_HD uint32_t table_word_hash(uint32_t v, uint32_t w) { uint32_t x = (v ^ (w * 0x9E3779B1u)) * 0x85EBCA6Bu; return x ^ (x >> 15); }
+// Publication of a result block in mapped pinned host memory to the host thread that polls one of its words.
+// The block's words are plain stores; the polled word must NOT be: a plain store behind __threadfence_system() carries no scope, and on
+// MI355X it was observed to reach host memory up to 6.5 us BEFORE the fenced stores in front of it (tools/cpp/publish_order_test.hip:
+// 216 torn blocks in 533,000 polled frames with the plain word, none with the system-scope atomic; it was the cause of round 1's
+// `group table inconsistent`).  Form (MI355X_MICROARCH.md, inter-workgroup visibility, "Valid forms", at system scope): every storing
+// wave has waited for its own stores (s_waitcnt vmcnt(0)) and joined a workgroup barrier; then ONE lane runs a system-scope release
+// fence, waits for it behind an s_waitcnt the compiler cannot drop, and stores the word with a system-scope atomic release store.
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void publish_to_host(uint32_t *word, uint32_t value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                  // "" = system scope: buffer_wbl2 sc0 sc1 + s_waitcnt
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // global_store_dword ... sc0 sc1 (the release is the fence above)
+}
+__device__ __forceinline__ void post_to_host64(unsigned long long *word, unsigned long long value) {   // a single self-contained word (no block in front of it): scope only, no release
+    __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 struct HostResult;
 RE_HD uint32_t result_seal(uint32_t table_hash, uint32_t frame, uint32_t n_groups, uint32_t total, uint32_t n_vis_map, uint32_t n_vis_vec, uint32_t n_items) {   // ties the table hash to the frame and the counts
     return (table_hash ^ table_word_hash(frame, 0x101u) ^ table_word_hash(n_groups, 0x102u) ^ table_word_hash(total, 0x103u) ^ table_word_hash(n_vis_map, 0x104u) ^ table_word_hash(n_vis_vec, 0x105u) ^ table_word_hash(n_items, 0x106u)) | 1u;

@@ -692,12 +692,13 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
                                                      uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
                                                      InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
                                                      uint32_t *out_count, uint32_t out_cap, uint32_t frame) {
-    __shared__ uint32_t s_wsum[16], s_wcnt[16];
-    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; __threadfence_system(); hres->done_frame = frame; } return; }
+    __shared__ uint32_t s_wsum[16], s_wcnt[16], s_whash[16];
+    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; publish_to_host(&hres->done_frame, frame); } return; }
     __shared__ uint32_t s_carry, s_gcarry;
     if (threadIdx.x == 0) { s_carry = 0; s_gcarry = 0; }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wid = threadIdx.x >> 6;
+    uint32_t my_hash = 0;                                       // hash of the table words this thread stores (see HostResult::table_hash)
     for (uint32_t base = 0; base < nslots; base += 1024) {
         uint32_t i = base + threadIdx.x;
         uint32_t v = i < nslots ? group_count[i] : 0u;
@@ -715,22 +716,31 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
                 uint32_t gc = i >> 3, lod = i & 7u;
                 InstanceRange r; r.model_index = gc_model[gc] | (lod << 25); r.render_system = gc_rs[gc]; r.sortable = gc_sort[gc]; r.begin = begin; r.count = v;
                 ranges[gidx] = r;
+                const uint32_t w0 = gidx * (uint32_t)(sizeof(InstanceRange) / 4u);
+                my_hash ^= table_word_hash(r.model_index, w0) ^ table_word_hash(r.render_system, w0 + 1u) ^ table_word_hash(r.sortable, w0 + 2u) ^ table_word_hash(r.begin, w0 + 3u) ^ table_word_hash(r.count, w0 + 4u);
             }
         }
         __syncthreads();
         if (threadIdx.x == 1023) { s_carry = begin + v; s_gcarry = gidx + nz; }
         __syncthreads();
     }
+    // every wave's table stores have left the wave before the barrier in front of the publication (publish_to_host)
+    for (int d = 32; d >= 1; d >>= 1) my_hash ^= __shfl_xor(my_hash, d, 64);
+    if (lane == 0) s_whash[wid] = my_hash;
+    wait_own_stores();
+    __syncthreads();
     FrameCounts fc = {};
     if (wid == 0) fc = load_frame_counts(hdr);
     if (threadIdx.x == 0) {
-        uint32_t nsec = 0, nitems = 0;
+        uint32_t nsec = 0, nitems = 0, table_hash = 0;
         for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * 8]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
-        HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry; r.total = s_carry; r.n_candidates = fc.n_candidates;
+        for (uint32_t w = 0; w < 16u; w++) table_hash ^= s_whash[w];
+        HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry < range_cap ? s_gcarry : range_cap; r.total = s_carry; r.n_candidates = fc.n_candidates;
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
+        r.table_hash = result_seal(table_hash | 1u, frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items);
         *hres = r;                                              // mapped pinned host memory
         if (out_count) *out_count = s_carry < out_cap ? s_carry : out_cap;
-        __threadfence_system(); hres->done_frame = frame;
+        publish_to_host(&hres->done_frame, frame);
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
     for (uint32_t i = threadIdx.x; i < sizeof(TickHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(th)[i] = 0u;
@@ -808,11 +818,12 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 // two dependent memory round trips from launch to store.
 __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32_t nblk, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, const PackArgs &A, const ItemSink &K, uint32_t nrows) {
     extern __shared__ uint32_t s_dyn[];                       // [nslots] all instances -> group begins, [nslots] instances before this chunk -> running fill
-    __shared__ uint32_t s_wsum[4], s_wcnt[4], s_carry, s_gcarry;
+    __shared__ uint32_t s_wsum[4], s_wcnt[4], s_whash[4], s_carry, s_gcarry;
     __shared__ uint32_t s_pos[64], s_row[64];
+    uint32_t direct_hash = 0;                                 // hash of the table words this thread stores straight to the host (a table too large to stage)
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; __threadfence_system(); A.hres->done_frame = A.frame; }
+        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; publish_to_host(&A.hres->done_frame, A.frame); }
         return;
     }
     const uint32_t nslots = A.nslots;
@@ -883,7 +894,12 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
                 s_tot[i] = begin;
                 if (v && bid == 0) {
                     uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
-                    if (staged) s_rng[gidx] = r; else A.ranges[gidx] = r;
+                    if (staged) s_rng[gidx] = r;
+                    else {
+                        A.ranges[gidx] = r;
+                        const uint32_t w0 = gidx * (uint32_t)(sizeof(InstanceRange) / 4u);
+                        direct_hash ^= table_word_hash(r.model_index, w0) ^ table_word_hash(r.render_system, w0 + 1u) ^ table_word_hash(r.sortable, w0 + 2u) ^ table_word_hash(r.begin, w0 + 3u) ^ table_word_hash(r.count, w0 + 4u);
+                    }
                 }
             }
             __syncthreads();
@@ -892,9 +908,13 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
         }
     }
     if (bid == 0) {
-        // the host polls done_frame while this kernel runs: every wave's InstanceRange stores must have left for host memory before
-        // lane 0 publishes it (a workgroup barrier alone does not wait for the other waves' stores in flight)
-        if (!staged) __threadfence_system();
+        // the host polls done_frame while this kernel runs: every wave's InstanceRange stores (the table that is not staged in LDS) must have
+        // left the wave before the barrier in front of lane 0's publication (a workgroup barrier alone does not wait for stores in flight)
+        if (!staged) {
+            for (int d = 32; d >= 1; d >>= 1) direct_hash ^= __shfl_xor(direct_hash, d, 64);
+            if (lane == 0) s_whash[wid] = direct_hash;
+            wait_own_stores();
+        }
         __syncthreads();
         if (wid == 0) {
             for (int d = 32; d >= 1; d >>= 1) { fc_a += __shfl_xor(fc_a, d, 64); fc_b += __shfl_xor(fc_b, d, 64); fc_c += __shfl_xor(fc_c, d, 64); }
@@ -905,9 +925,9 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(s_rng); uint32_t *dst = reinterpret_cast<uint32_t *>(A.ranges);
                 for (uint32_t w = lane; w < nw; w += 64u) { const uint32_t v = src[w]; dst[w] = v; table_hash ^= table_word_hash(v, w); }
                 for (int d = 32; d >= 1; d >>= 1) table_hash ^= __shfl_xor(table_hash, d, 64);
-                table_hash |= 1u;                                 // 0 = "no hash" (the multi-kernel pack: its reader synchronises the stream)
-                __threadfence_system();                         // every lane's table words before lane 0 publishes
-            }
+                table_hash |= 1u;
+            } else if (!overflow) table_hash = (s_whash[0] ^ s_whash[1] ^ s_whash[2] ^ s_whash[3]) | 1u;     // a table too large to stage: written by all waves above
+            wait_own_stores();                                  // the whole wave: every lane's table words have left before lane 0 publishes
             if (lane == 0) {
                 HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;   // (never read the mapped host struct: a PCIe round trip)
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
@@ -915,7 +935,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
                 r.table_hash = table_hash ? result_seal(table_hash, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items) : 0u;
                 *A.hres = r;                                        // mapped pinned host memory
                 if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
-                __threadfence_system(); A.hres->done_frame = A.frame;   // the group table and the counters above are complete
+                publish_to_host(&A.hres->done_frame, A.frame);      // the group table and the counters above are complete
             }
         }
         // next frame's cursors / counters (this frame's header stays readable), also when this pack declines (overflow): frames enqueued
@@ -1028,8 +1048,7 @@ __global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t 
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const uint32_t a = th->n_changed, b = th->n_rebucket, c2 = th->n_oob;
     h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
-    __threadfence_system();
-    h_th->ticket = seq;
+    publish_to_host(&h_th->ticket, seq);
 }
 
 // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + update_entity_in_tree (:325-351) for one entity whose
@@ -1061,7 +1080,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     if (oob && !(fl & F_OOB_LOGIC)) {
         uint32_t slot = atomicAdd(&th->n_oob, 1u);
         if (slot < list_cap) oob_rows[slot] = r;
-        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; *reinterpret_cast<volatile unsigned long long *>(h_spec) = w; }   // {stale = 1, stale_frame = frame} in one store     // the host must retire the row before any later frame runs
+        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; post_to_host64(reinterpret_cast<unsigned long long *>(h_spec), w); }   // {stale = 1, stale_frame = frame} in one store     // the host must retire the row before any later frame runs
         R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
         return;
     }
@@ -1081,7 +1100,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     if (!same) {
         uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
         if (slot < list_cap) mover_rows[slot] = r | (translation_only ? 0x80000000u : 0u);   // bit 31: translation-only mover
-        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; *reinterpret_cast<volatile unsigned long long *>(h_spec) = w; }   // {stale = 1, stale_frame = frame} in one store     // the host must patch the tree before any later frame runs
+        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; post_to_host64(reinterpret_cast<unsigned long long *>(h_spec), w); }   // {stale = 1, stale_frame = frame} in one store     // the host must patch the tree before any later frame runs
     }
 }
 

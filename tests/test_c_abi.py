@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/re_hip.h but not exported"
     assert set(R._capi.EXPORTS) <= set(names)
-    assert L.re_abi_version() == 1
+    assert L.re_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -36,6 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.TickResult) == 12
     assert C.sizeof(_capi.Entities) == 8 + 13 * 8
     assert C.sizeof(_capi.Visible) == 5 * 4 + 4 + 3 * 8
+    assert C.sizeof(_capi.Stats) == 5 * 4 + 4 + 8 + 6 * 4            # 5 counts, padding, device_bytes, 6 counters
 
 
 def test_fails_loudly_without_a_device():

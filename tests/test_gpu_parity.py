@@ -18,6 +18,13 @@ def R():
 
 def build_pair(R, ents, outline=16384, atomic=64, flags=0):
     p = R.Pipeline(outline, atomic, flags=flags)
+    plain_close = p.close
+
+    def close_checked():                      # every test that closes its pipeline also asserts the publication counters
+        if getattr(p, "_h", None):
+            assert_clean_publication(p)
+        plain_close()
+    p.close = close_checked
     rej = p.register_model_instances(ents)
     w = ro.World(outline, atomic)
     rej_o = w.register(to_oracle(ents))
@@ -44,7 +51,15 @@ def check_frame(R, p, w, cam, dups, force_large_pack=False):
     assert g["n_visible_vec"] == len(vis_o) and g["n_visible_sections"] == len(np.unique(vis_o))
     o = w.render(oc, emit_duplicates=dups)
     assert_render_equal(g, o)
+    assert_clean_publication(p)
     return g, o
+
+
+def assert_clean_publication(p):
+    """every result block the host polled in mapped memory (frame result + InstanceRange table, tick counters, collision header) agreed
+    with its seal at first sight: the slow paths behind the publication protocol (re_kernels.h: publish_to_host) were never taken"""
+    st = p.stats()
+    assert st["n_seal_waits"] == 0 and st["n_sync_fallbacks"] == 0, st
 
 
 def check_entities(R, p, w, ents):
@@ -68,7 +83,7 @@ def check_entities(R, p, w, ents):
 
 
 def test_library_loaded_and_fails_loudly(R):
-    assert R._capi.load().re_abi_version() == 1
+    assert R._capi.load().re_abi_version() == 2
     with pytest.raises(R.RenderEngineError):
         R.Pipeline(16384, 64, device=99)
 
