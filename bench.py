@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py -- entities/sec through cull + transform on the BASELINE.json workload.
+"""bench.py -- entities/sec through cull + transform on the BASELINE.json workload (SURVEY.md section 8d).
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path over the resident world: re_cull_pack (visibility query over the
-spatial hash + frustum/logic cull + instance pack) followed by re_tick (ECS kinematic / TRS->mat4
-tick) -- Pipeline::execute of the reference (flows/pipeline.rs:212-276).  Inputs are resident in HBM
-before the timed region starts.  N=1: BASELINE.json configs[1] (10,077,696 static entities, one
-per level-0 world section, uniform spatial-hash fill, one camera frustum).  N>1 (weak scaling):
-N x 10,077,696 entities sharded by contiguous section-key range, one process per GPU, with an RCCL
-all-gather of every GPU's packed visible-instance buffer each step (configs[3] at N=8).
-Rank 0 prints ONE JSON line.
+A step is ONE FRAME of the hot path over the resident world, as a frame loop that draws every frame sees it:
+re_cull_pack (visibility query over the spatial hash + frustum / logic cull + instance pack, with the
+InstanceRange table and the counts available to the host when the call returns) followed by re_tick (ECS
+kinematic / TRS->mat4 tick) -- Pipeline::execute of the reference (flows/pipeline.rs:212-276).  Both calls are
+synchronous.  Inputs are resident in HBM before the timed region starts.
+
+N=1: BASELINE.json configs[1] -- 10,077,696 static entities, one per level-0 world section (uniform spatial-hash
+fill), one camera frustum, far = 1000.  `value` = entities / median frame time (median of >= 100 frames);
+`ms_per_step` = wall time of exactly K timed frames / K.  The same run also reports, as labelled extras: the
+pipelined throughput of asynchronous frames, far = 8192 (wide frustum, ~500 K instances: the large pack path),
+configs[2] (100,777 rotating bodies: tick + cull) incl. a tick of every dynamic entity, configs[4] (deferred
+lighting), the CPU rows, and a full-size check of the visible set against the CPU oracle.
+N>1 (weak scaling, configs[3] at N=8): N x 10,077,696 entities sharded by contiguous section-key range, one process
+per GPU, an RCCL all-gather of every GPU's packed visible-instance slab each frame; the frame ends when the
+gathered buffer is complete.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -24,10 +31,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-TIMING_EVERY = 8
-SLAB_INSTANCES = 4096           # all-gather slab per rank and frame (instances); ~2.8x the visible set of a rank at far=1000
+TIMING_EVERY = 4               # HIP events on every 4th launch of the scan kernel inside the timed region (timed dispatches cost queue time)
+SLAB_INSTANCES = 4096          # all-gather slab per rank and frame (instances); ~2.8x the visible set of a rank at far=1000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (MI355X_MICROARCH.md), the bound of the lighting kernel
 PER_GPU_AXIS = 216             # 216^3 = 10,077,696 sections/entities per GPU
+MEDIAN_FRAMES = 128            # median of >= 100 frames
 
 
 def parse():
@@ -35,15 +44,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=["default", "visible", "lighting"], default="default",
+                    help="default: the visible-set headline + every extra leg; visible: headline only; lighting: configs[4] only")
     ap.add_argument("--far", type=float, default=1000.0, help="camera far draw distance (reference default 1000, main.rs:23)")
     ap.add_argument("--axis", type=int, default=PER_GPU_AXIS, help="sections per axis per GPU (216 -> 10,077,696 entities)")
     ap.add_argument("--spinner-every", type=int, default=0, help="0 = configs[1] (all static); 100 = configs[2] (100k rotating bodies)")
+    ap.add_argument("--tick-all", action="store_true", help="tick every dynamic entity (RE_TICK_ALL_DYNAMIC) instead of the visible ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the far=8192 / configs[2] / lighting legs")
     ap.add_argument("--force-large-pack", action="store_true", help="always use the multi-kernel pack")
     ap.add_argument("--cpu-sample-axis", type=int, default=100)
-    ap.add_argument("--no-defer-pack", action="store_true", help="launch every frame's pack on its own instead of letting the next frame's launch carry it (RE_CULL_DEFER_PACK)")
-    ap.add_argument("--one-lane", action="store_true", help="keep all frames on one HIP stream (no RE_CULL_TWO_LANES)")
     ap.add_argument("--probe", action="store_true", help="opt-in variant: visibility query by hash probes of the candidate cells (RE_CFG_PROBE) instead of the key stream")
+    ap.add_argument("--pipelined-only", action="store_true", help="profiling aid: only the asynchronous two-lane loop (round 1's headline)")
     return ap.parse_args()
 
 
@@ -69,6 +81,34 @@ def make_shard(rank, n_gpus, axis, atomic, spinner_every):
     return synthetic.box_world((nx, nz, ny), first_cell=first, atomic=atomic, index_range=(lo, hi), spinner_every=spinner_every), (nx, nz, ny), first
 
 
+def kernel_times(p, camc, frames, tick_all=False, R=None):
+    """device time of the frame's kernels (HIP events on the pipeline's stream, re_get_timings) over a few synchronous frames: medians, us"""
+    p.timings_us()                                     # switches the event recording on
+    cull, pack, tick = [], [], []
+    for _ in range(frames):
+        p.cull_and_pack(camc, copy=False); p.tick(0.016, all_dynamic=tick_all)
+        t = p.timings_us(); cull.append(t["cull"]); pack.append(t["pack"]); tick.append(t["tick"])
+    p.timings_off()                                    # the event records cost ~12 us per synchronous frame
+    return {"cull": float(np.median(cull)), "pack": float(np.median(pack)), "tick": float(np.median(tick))}
+
+
+def sync_frames(p, camc, n, tick_all=False):
+    import render_engine_amd as R
+    us, vis, tr = p.run_frames(camc, n, 0.016, 0, R._capi.TICK_ALL_DYNAMIC if tick_all else 0)
+    return us, vis, tr
+
+
+def pipelined_frames(p, camc, n, tick_all=False):
+    """asynchronous frames: static worlds defer every pack to the next launch and alternate between two frame lanes"""
+    import render_engine_amd as R
+    F = R._capi
+    p.wait()
+    t0 = time.perf_counter()
+    p.run_frames(camc, n, 0.016, F.CULL_ASYNC | F.CULL_DEFER_PACK | F.CULL_TWO_LANES, F.TICK_ASYNC | (F.TICK_ALL_DYNAMIC if tick_all else 0))
+    p.wait()
+    return (time.perf_counter() - t0) / n
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,186 +129,292 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+    if a.config == "lighting":
+        if rank == 0:
+            out = lighting_leg(headline=True, steps=a.steps, warmup=a.warmup)
+            print(json.dumps(out))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     import render_engine_amd as R
     from render_engine_amd import parallel
+    F = R._capi
 
     atomic = 64 if world == 1 else 32            # 432 sections per axis need atomic 32
+    extras = world == 1 and a.config == "default" and not a.no_extras and a.far == 1000.0 and not a.spinner_every and a.axis == PER_GPU_AXIS and not a.probe
     t0 = time.time()
     ents, dims, first = make_shard(rank, world, a.axis, atomic, a.spinner_every)
     n_local = len(ents)
-    cap = 1 << 16 if a.far <= 2000 else max(1 << 16, n_local // 2)
-    p = R.Pipeline(16384, atomic, device=local, max_instances=cap, flags=R._capi.CFG_PROBE if a.probe else 0)
+    cap = max(1 << 16, n_local // 2) if (a.far > 2000 or extras) else 1 << 16      # the far=8192 leg packs ~500 K instances
+    p = R.Pipeline(16384, atomic, device=local, max_instances=cap, flags=F.CFG_PROBE if a.probe else 0)
     p.register_model_instances(ents)
     stats = p.stats()
-    del ents
+    if not extras:
+        del ents
     t_setup = time.time() - t0
     centre = [(first + d / 2.0) * atomic for d in (dims[0], dims[2], dims[1])]      # x, y, z
     cam = R.Camera(centre, (0.0, 0.0, -1.0), a.far)
     camc = cam.to_c()
-    # N > 1: every rank packs into a fixed slab and the slabs are all-gathered in stream order, double-buffered -- no host round trip
-    lanes = not (a.one_lane or a.no_defer_pack)
-    gather = None
-    if world > 1:
-        gather = parallel.SlabAllGatherLanes(p, SLAB_INSTANCES, dist) if lanes else parallel.SlabAllGather(p, SLAB_INSTANCES, dist)
+    tick_flags = F.TICK_ALL_DYNAMIC if a.tick_all else 0
+    cull_flags = F.CULL_FORCE_LARGE_PACK if a.force_large_pack else 0
+    gather = parallel.SlabAllGather(p, SLAB_INSTANCES, dist) if world > 1 else None
 
-    def step(sync_each):
-        if gather is not None:
+    def frames(n, record=None):
+        """n synchronous frames; N > 1: the frame ends when the all-gathered visible-instance buffer is complete on this rank"""
+        if gather is None:
+            us, vis, tr = p.run_frames(camc, n, 0.016, cull_flags, tick_flags)        # the two C ABI calls in a native loop
+            if record is not None:
+                record.extend(us.tolist())
+            return vis
+        cv, ct = F.Visible(), F.TickResult()            # the C ABI straight through ctypes: no per-frame conversion of the results
+        for _ in range(n):
+            t1 = time.perf_counter()
             gather.begin_frame()
-            p.cull_and_pack(camc, asynchronous=True, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack, two_lanes=lanes)
-            if lanes:
-                gather.after_cull()            # frames alternate between two streams; the slab of frame g - 2 goes out behind launch g
-            elif a.no_defer_pack:
-                gather.exchange()
-            else:
-                gather.exchange_lagged()       # this launch carried the previous frame's pack: that frame's slab goes out now
-            p.tick(0.016, asynchronous=True)
-            if sync_each:
-                p.wait()
-                if lanes or a.no_defer_pack: gather.finish()
-                else: gather.finish_lagged()
-        else:
-            # asynchronous frames of a static world leave their pack to the next frame's launch (one launch per frame); the last one is
-            # sent off by the fence.  Worlds with dynamic entities pack every frame before its tick (the library ignores the flag there).
-            p.cull_and_pack(camc, asynchronous=not sync_each, copy=False, force_large_pack=a.force_large_pack, defer_pack=not a.no_defer_pack, two_lanes=lanes)
-            p.tick(0.016, asynchronous=not sync_each)
+            p._check(p._L.re_cull_pack(p._h, C.byref(camc), cull_flags, C.byref(cv)), "re_cull_pack")
+            gather.exchange()                           # enqueued on the pipeline's stream: ordered behind the pack
+            p._check(p._L.re_tick(p._h, np.float32(0.016), tick_flags, C.byref(ct)), "re_tick")
+            gather.finish()                             # the gathered buffer is complete on this rank
+            if record is not None:
+                record.append((time.perf_counter() - t1) * 1e6)
+        return p._visible_to_py(cv, copy=False) if n else None
 
     def fence():
         p.wait()
         if gather is not None:
-            if lanes or a.no_defer_pack: gather.finish()
-            else: gather.finish_lagged()
+            gather.finish()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step(False)
+    if a.pipelined_only:
+        pipelined_frames(p, camc, a.warmup); per = pipelined_frames(p, camc, a.steps)
+        if rank == 0:
+            print(json.dumps({"pipelined_ms_per_frame": per * 1e3, "entities_per_s": n_local / per}))
+        return
+
+    frames(a.warmup)
     fence()
-    fused_before = p.stats()["n_fused_frames"]
-    p.timing_begin(a.steps, every=TIMING_EVERY)     # HIP events on every 8th launch of the dominant kernel: timed dispatches cost queue time
+    p.timing_begin(a.steps, every=TIMING_EVERY)
+    wall = []
     t_start = time.perf_counter()
-    for _ in range(a.steps):
-        step(False)
+    vis = frames(a.steps, wall)
     fence()
     elapsed = time.perf_counter() - t_start
     k1_us = p.timing_collect(a.steps)
-    vis, _ = p.wait()
     n_cand = p.last_candidates()
+    med_frames = list(wall)
+    if len(med_frames) < MEDIAN_FRAMES:                # SURVEY 8d: median of >= 100 frames
+        frames(MEDIAN_FRAMES - len(med_frames), med_frames)
+        fence()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        t = torch.tensor([elapsed, float(np.median(med_frames))], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, med_us = float(t[0].item()), float(t[1].item())
         tot = torch.tensor([n_local], dtype=torch.int64, device="cuda"); dist.all_reduce(tot); n_total = int(tot.item())
     else:
-        n_total = n_local
-
-    # second timing leg, outside the timed region: the scan kernel on its own (every frame's pack launched separately), so that the
-    # roofline of the scan can be read next to that of the fused launch the timed region runs
-    scan_only_us = None
-    fused = not a.no_defer_pack and (p.stats()["n_fused_frames"] - fused_before) * 2 >= a.steps    # the launches of the timed region carried the packs
-    if fused and rank == 0 and gather is None:
-        nleg = 96
-        p.timing_begin(nleg, every=TIMING_EVERY)
-        for _ in range(nleg):
-            p.cull_and_pack(camc, asynchronous=True, copy=False, force_large_pack=a.force_large_pack, defer_pack=False); p.tick(0.016, asynchronous=True)
-        p.wait()
-        scan_only_us = p.timing_collect(nleg)
-
-    # per-frame latency with a host sync after every call (what a frame loop that draws each frame sees)
-    lat = []
-    for _ in range(min(50, a.steps)):
-        t1 = time.perf_counter(); step(True); lat.append(time.perf_counter() - t1)     # both calls return with their results complete
-    p.timings_us(); step(True)                       # kernel event timing is off until asked for: switch it on, time one more synchronous frame
-    tm = p.timings_us()
+        med_us = float(np.median(med_frames)); n_total = n_local
 
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        # roofline of the dominant kernel (k_scan_cull): algorithmic bytes per launch, see DESIGN.md "Roofline accounting":
-        # the stream key of every section slot (4 B compact when the world has <= 512 sections per axis, else 8 B) + one level word per
-        # 512-key chunk + 41 B per visible section (flags, tight AABB, counts, begin read; stamp written) + 16 B per visible instance
-        # (row index and group class read, instance-list entry written).  Candidate sections that turn out invisible cost no bytes:
-        # their test runs on the key alone.
-        C_sections = stats["n_section_slots"] if "n_section_slots" in stats else stats["n_sections"]
-        n_entries = vis["n_visible_sections"]
+        slots = stats["n_section_slots"]
+        n_entries, V = vis["n_visible_sections"], vis["total"]
         key_bytes = 4 if (16384 + atomic - 1) // atomic <= 512 and not os.environ.get("RE_EXP_KEY64") else 8
-        alg_bytes = key_bytes * C_sections + 4 * ((C_sections + 511) // 512) + 41 * n_entries + 16 * vis["total"]
+        # Two byte bases for the dominant kernel (the section-key scan + cull, k_scan_cull), see DESIGN.md "Roofline accounting":
+        #  survey_8d   SURVEY 8(d): 40 B per section (key, tight AABB, begin/count) + 8 B per entity (id, model word) + 132 B per visible instance.
+        #              It assumes every section's AABB / ranges and every entity's id word are streamed; this layout never touches them for
+        #              sections outside the frustum, so bytes_survey_8d / time exceeds the HBM peak: the kernel does not move those bytes.
+        #  compulsory  what this layout must read: the stream key of every section slot + one level word per 512 slots + 41 B per visible
+        #              section (flags, tight AABB, counts, begin; stamp written) + 16 B per visible instance (row index, group class; list entry).
+        bytes_8d = 40 * stats["n_sections"] + 8 * stats["n_entities"] + 132 * V
+        bytes_comp = key_bytes * slots + 4 * ((slots + 511) // 512) + 41 * n_entries + 16 * V
         probed = a.probe and p.stats()["n_probe_frames"] > 0
-        if probed:      # the probe kernel reads one 16-byte table entry per candidate cell instead of the key stream
-            alg_bytes = 16 * int(p.last_candidates()) + 41 * n_entries + 16 * vis["total"]
+        if probed:
+            bytes_comp = 16 * int(n_cand) + 41 * n_entries + 16 * V
         k1_mean = float(np.mean(k1_us)) if len(k1_us) else float("nan")
-        achieved = alg_bytes / (k1_mean * 1e-6) / 1e9 if k1_mean > 0 else None
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_k_scan_cull.json")
-        # the committed PMC measurement is of the default workload on one GPU; other workloads report null
-        default_workload = world == 1 and a.axis == 216 and a.far == 1000.0 and not a.spinner_every and not a.force_large_pack and not a.probe
-        if default_workload and os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        gbs = lambda b, us: b / (us * 1e-6) / 1e9 if us and us > 0 else None
+        traffic, tr_src = committed_traffic("scan") if (world == 1 and a.axis == 216 and a.far == 1000.0 and not a.spinner_every and not probed) else (None, None)
+        wl = ("configs[1]: %d static entities, one per level-0 world section (uniform spatial-hash fill), 1 camera frustum far=%g" % (n_total, a.far)) if not a.spinner_every else \
+             ("configs[2]: %d entities incl. every %dth rotating (ECS tick + cull), far=%g" % (n_total, a.spinner_every, a.far))
         out = {
             "metric": "entities/sec through cull+transform; visible-set ms/frame @ 10M entities",
-            "value": n_total / (elapsed / a.steps), "unit": "entities/s",
+            "value": n_total / (med_us * 1e-6), "unit": "entities/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("configs[1]: %d static entities, one per level-0 world section (uniform spatial-hash fill), 1 camera frustum far=%g"
-                                    % (n_total, a.far)) if not a.spinner_every else
-                                   ("configs[2]: %d entities incl. every %dth rotating (ECS tick + cull), far=%g" % (n_total, a.spinner_every, a.far)),
-                       "entities": n_total, "sections": C_sections * world, "dynamic_entities": stats["n_dynamic"] * world,
-                       "visible_sections": vis["n_visible_sections"], "visible_instances": vis["total"], "far": a.far,
-                       "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), slabs in rotation, stream-ordered behind the launch that carries the pack" % SLAB_INSTANCES},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_probe_cull" if probed else (("k_scan_cull_fused (scan of frame f + pack of frame f-2 in one launch; frames alternate between two streams)" if lanes else "k_scan_cull_fused (scan of frame f+1 + pack of frame f in one launch)") if fused else "k_scan_cull"), "algorithmic_bytes_per_launch": alg_bytes, "stream_key_bytes": key_bytes,
-                         "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY},
-            "frame_latency_ms_sync": float(np.median(lat) * 1e3),
-            "kernel_us_last_frame": tm, "setup_s": t_setup,
+            "value_basis": "entities / median wall time of one synchronous frame (re_cull_pack + re_tick, results available to the host%s) over %d frames; ms_per_step = wall of the %d timed frames / %d"
+                           % ("; N>1: incl. the all-gather of the packed visible-instance slabs" if world > 1 else "", len(med_frames), a.steps, a.steps),
+            "frame_ms_median": med_us * 1e-3,
+            "config": {"workload": wl, "entities": n_total, "sections": stats["n_sections"] * world, "dynamic_entities": stats["n_dynamic"] * world,
+                       "visible_sections": n_entries, "visible_instances": V, "far": a.far, "frame": "synchronous re_cull_pack + re_tick%s" % (" (RE_TICK_ALL_DYNAMIC)" if a.tick_all else ""),
+                       "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), stream-ordered behind the pack" % SLAB_INSTANCES},
+            "roofline": {"bound": "hbm", "kernel": "k_probe_cull" if probed else "k_scan_cull", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY,
+                         "bytes_compulsory": bytes_comp, "bytes_survey_8d": bytes_8d, "stream_key_bytes": key_bytes,
+                         "achieved": gbs(bytes_comp, k1_mean), "frac": (gbs(bytes_comp, k1_mean) or 0) / HBM_PEAK_GBS if k1_mean == k1_mean else None,
+                         "achieved_survey_8d": gbs(bytes_8d, k1_mean), "frac_survey_8d": (gbs(bytes_8d, k1_mean) or 0) / HBM_PEAK_GBS if k1_mean == k1_mean else None,
+                         "basis": "achieved / frac use bytes_compulsory (what this layout must move); frac_survey_8d > 1 means the kernel does not move SURVEY 8d's bytes: sections outside the frustum cost only their %d-byte stream key" % key_bytes,
+                         "traffic": traffic, "traffic_source": tr_src},
+            "setup_s": t_setup,
         }
-        if fused:
-            # the fused launch also carries the previous frame's pack: 8 B per instance-list entry read, id + matrix read and written
-            out["roofline"]["algorithmic_bytes_per_launch"] = alg_bytes + (8 + 68 + 68) * vis["total"]
-            out["roofline"]["achieved"] = out["roofline"]["algorithmic_bytes_per_launch"] / (k1_mean * 1e-6) / 1e9
-            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
-            if scan_only_us is not None and len(scan_only_us):
-                so = float(np.mean(scan_only_us))
-                out["roofline_scan_only"] = {"bound": "hbm", "kernel": "k_scan_cull (second leg after the timed region: every pack launched on its own)", "mean_launch_us": so,
-                                             "algorithmic_bytes_per_launch": alg_bytes, "achieved": alg_bytes / (so * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                             "frac": alg_bytes / (so * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "launches_timed": int(len(scan_only_us))}
-            out["roofline"]["traffic"] = None            # the committed PMC figure `traffic` above is of the scan kernel alone
-            if default_workload and os.path.exists(prof):
-                try:
-                    out["roofline"]["traffic"] = json.load(open(prof))["fused_launch"]["hbm_bytes_per_launch"]
-                except Exception:
-                    pass
-        # with two frame lanes the launches of consecutive frames overlap: next to the per-launch figure, the algorithmic bytes of the timed
-        # region over its wall time (what the device as a whole sustained)
-        rf = out["roofline"]
-        rf["timed_region_achieved"] = rf["algorithmic_bytes_per_launch"] * a.steps / elapsed / 1e9 if rf.get("algorithmic_bytes_per_launch") else None
-        rf["timed_region_frac"] = rf["timed_region_achieved"] / HBM_PEAK_GBS if rf["timed_region_achieved"] else None
-        if fused and lanes and world == 1 and rf["timed_region_achieved"]:
-            # Two launches are in flight at any time (frame lanes): the HIP events of one launch then span a period in which the device moves the
-            # bytes of about two.  achieved / frac are therefore the algorithmic bytes of the timed region over its wall time -- the bandwidth
-            # the device sustains while this kernel runs; the event figures of the single launch stay next to them.
-            rf["per_launch_event"] = {"achieved": rf["achieved"], "frac": rf["frac"], "mean_launch_us": rf["mean_launch_us"],
-                                      "note": "one launch timed alone with HIP events while a second one shares the device"}
-            rf["achieved"], rf["frac"], rf["concurrent_launches"] = rf["timed_region_achieved"], rf["timed_region_frac"], 2
+        if world == 1:
+            kt = kernel_times(p, camc, 16, a.tick_all)
+            out["kernel_us"] = kt
+            per = pipelined_frames(p, camc, 64); per = pipelined_frames(p, camc, max(a.steps, 200))
+            out["pipelined"] = {"ms_per_frame": per * 1e3, "entities_per_s": n_total / per,
+                                "note": "asynchronous frames, no result read by the host per frame; static worlds defer each pack to the next launch and alternate two frame lanes (round 1's headline figure)"}
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], out["cpu_optimised"] = cpu_baseline(a, atomic, n_total)
+            gpu_frame = p.cull_and_pack(camc, copy=True) if not a.spinner_every else None
+            out["cpu_baseline"], out["cpu_optimised"], out["full_size_check"] = cpu_baseline(a, atomic, n_total, dims, first, gpu_frame)
+        p.close()
+        if extras:
+            # a fresh upload of the same entities: the reference's static render cache freezes with the camera of the first frame after a
+            # registration (render_flow.rs:549-594), so a world first seen at far=1000 would draw only those sections at far=8192
+            out["far_8192"] = far_leg(R, ents, atomic, centre, n_total, key_bytes)
+            del ents
+            out["configs_2"] = spinner_leg(R, a, atomic)
+            out["lighting"] = lighting_leg(headline=False)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, atomic, n_total):
+def committed_traffic(which):
+    """HBM traffic per launch from the committed PMC profile (separate --pmc passes, gfx950 FETCH_SIZE correction applied); not measured in this run"""
+    for name in ("r02_pmc.json", "r01_pmc_k_scan_cull.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            try:
+                d = json.load(open(f))
+                v = d.get("hbm_bytes_per_launch") if which == "scan" else d.get(which, {}).get("hbm_bytes_per_launch")
+                if v:
+                    return v, "profiles/%s (committed PMC profile of this workload, not measured in this run)" % name
+            except Exception:
+                pass
+    return None, None
+
+
+def far_leg(R, ents, atomic, centre, n_total, key_bytes):
+    """far = 8192 on the configs[1] world: ~500 K visible instances, the large pack path (SURVEY 8d asks for both far values)"""
+    p = R.Pipeline(16384, atomic, max_instances=max(1 << 16, len(ents) // 2))
+    p.register_model_instances(ents)
+    stats = p.stats()
+    cam = R.Camera(centre, (0.0, 0.0, -1.0), 8192.0).to_c()
+    sync_frames(p, cam, 8)
+    us, vis, _ = sync_frames(p, cam, 48)
+    kt = kernel_times(p, cam, 12)
+    per = pipelined_frames(p, cam, 16); per = pipelined_frames(p, cam, 64)
+    V, S, slots = vis["total"], vis["n_visible_sections"], stats["n_section_slots"]
+    b_scan = key_bytes * slots + 4 * ((slots + 511) // 512) + 41 * S + 16 * V
+    b_pack = (8 + 4 + 64 + 68) * V               # list entry + id + matrix read, id + matrix written
+    dev = kt["cull"] + kt["pack"]
+    p.close()
+    return {"workload": "configs[1] world (fresh upload), far=8192", "visible_sections": S, "visible_instances": V,
+            "frame_ms_median_sync": float(np.median(us)) * 1e-3, "entities_per_s_sync": n_total / (float(np.median(us)) * 1e-6),
+            "pipelined_ms_per_frame": per * 1e3, "entities_per_s_pipelined": n_total / per,
+            "kernel_us": kt,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "scan": {"kernel": "k_scan_cull", "us": kt["cull"], "bytes_compulsory": b_scan, "frac": b_scan / (kt["cull"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["cull"] > 0 else None},
+                         "pack": {"kernel": "instance pack (large path)", "us": kt["pack"], "bytes_compulsory": b_pack, "frac": b_pack / (kt["pack"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["pack"] > 0 else None},
+                         "frame": {"us": dev, "bytes_compulsory": b_scan + b_pack, "frac": (b_scan + b_pack) / (dev * 1e-6) / 1e9 / HBM_PEAK_GBS if dev > 0 else None,
+                                   "bytes_survey_8d": 40 * stats["n_sections"] + 8 * stats["n_entities"] + 132 * V,
+                                   "frac_survey_8d": (40 * stats["n_sections"] + 8 * stats["n_entities"] + 132 * V) / (dev * 1e-6) / 1e9 / HBM_PEAK_GBS if dev > 0 else None}}}
+
+
+def spinner_leg(R, a, atomic):
+    """configs[2]: the 10,077,696-entity world with every 100th entity a rotating body (100,777 dynamic entities)"""
+    from render_engine_amd import synthetic
+    first = (16384 // atomic - a.axis) // 2
+    ents = synthetic.lattice_world(cells_per_axis=a.axis, first_cell=first, atomic=atomic, spinner_every=100)
+    n = len(ents)
+    p = R.Pipeline(16384, atomic, max_instances=max(1 << 16, n // 2))
+    p.register_model_instances(ents)
+    st = p.stats()
+    del ents
+    c = (first + a.axis / 2.0) * atomic
+    out = {"workload": "configs[2]: %d entities incl. %d rotating bodies (space_logic asteroid spin), ECS tick + cull" % (n, st["n_dynamic"])}
+    B_TICK = 184                                     # SURVEY 8d: 80 B read + 104 B written per ticking entity
+    # (the static render cache of this upload freezes with the first camera, far=1000: the wide camera afterwards draws the rotating bodies it
+    # sees plus the static entities cached then -- it is here for the tick: >= 10 K visible rotating bodies)
+    legs = [("far_1000", R.Camera((c, c, c), (0, 0, -1), 1000.0), False),
+            ("far_1000_tick_all", R.Camera((c, c, c), (0, 0, -1), 1000.0), True),
+            ("wide_camera", R.Camera((c, c, (first + a.axis) * atomic - 100.0), (0, 0, -1), 16384.0), False)]
+    for name, cam, tick_all in legs:
+        camc = cam.to_c()
+        sync_frames(p, camc, 6, tick_all)
+        us, vis, tr = sync_frames(p, camc, 40, tick_all)
+        kt = kernel_times(p, camc, 10, tick_all)
+        per = pipelined_frames(p, camc, 8, tick_all); per = pipelined_frames(p, camc, 48, tick_all)
+        med = float(np.median(us))
+        out[name] = {"camera": "far=%g%s" % (cam.far_draw_distance, ", every dynamic entity ticks (RE_TICK_ALL_DYNAMIC)" if tick_all else ", entities of visible active sections tick (reference semantics)"),
+                     "visible_instances": vis["total"], "entities_ticked": tr["n_changed"],
+                     "frame_ms_median_sync": med * 1e-3, "entities_per_s_sync": n / (med * 1e-6),
+                     "pipelined_ms_per_frame": per * 1e3, "entities_per_s_pipelined": n / per, "kernel_us": kt,
+                     "tick_roofline": {"bound": "hbm", "kernel": "k_tick", "us": kt["tick"], "bytes_per_entity_survey_8d": B_TICK, "bytes": B_TICK * tr["n_changed"],
+                                       "frac": B_TICK * tr["n_changed"] / (kt["tick"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["tick"] > 0 else None}}
+    p.close()
+    return out
+
+
+def lighting_leg(headline, steps=20, warmup=3):
+    """configs[4]: deferred lighting of a 4096 x 4096 synthetic G-buffer with 4096 radius ('spot') lights as a HIP compute kernel"""
+    import oracle as ro
+    from render_engine_amd import lighting
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    W = H = 4096; NL = 4096
+    t0 = time.time()
+    pos, nrm, alb = lighting.synthetic_gbuffer(W, H)
+    L = lighting.synthetic_lights(n_spot=NL, n_point=0)
+    dl = lighting.DeferredLighting(W, H, max_spot_lights=NL, max_point_lights=64)
+    dl.upload_gbuffer(pos, nrm, alb); dl.set_lights(L)
+    t_setup = time.time() - t0
+    for _ in range(warmup):
+        dl.run()
+    us = [dl.run() for _ in range(steps)]
+    t = float(np.median(us))
+    keep = []
+    S = lighting.fill_lights_struct(ro.LightsC(), L, keep)
+    pairs = ro.lighting_spot_pairs(pos, S)             # exact count of (pixel, light within its radius) pairs: the oracle is the counter, not the thing measured
+    # sampled check of the full-size image against the CPU evaluation of the GLSL (tolerance 1e-4, BASELINE.json)
+    idx = (np.arange(2048, dtype=np.uint64) * np.uint64(8191 * 4099 + 7) % np.uint64(W * H)).astype(np.uint32)
+    err = float(np.abs(dl.read_pixels(idx) - ro.deferred_lighting(pos, nrm, alb, S, idx=idx)).max())
+    if err > 1e-4:
+        raise SystemExit("lighting: GPU image differs from the CPU evaluation of the GLSL by %g" % err)
+    dl.close()
+    npix = W * H
+    flops = pairs * 150 + 20 * npix                  # SURVEY 8d: ~75 flop per evaluated (pixel, light) term, the spot term is evaluated twice, + 20 per pixel epilogue
+    bytes_ = npix * (16 + 16 + 4 + 16)               # gPosition + gNormal RGBA32F, gAlbedoSpec RGBA8 read; FragColor RGBA32F written (gLightPosition is not needed)
+    tf, gb = flops / (t * 1e-6) / 1e12, bytes_ / (t * 1e-6) / 1e9
+    binds = "fp32 VALU" if tf / VALU_PEAK_TFLOPS > gb / HBM_PEAK_GBS else "HBM"
+    res = {"workload": "configs[4]: deferred lighting, %dx%d synthetic G-buffer, %d radius-40 'spot' lights (second_pass_frag.glsl:20-139)" % (W, H, NL),
+           "kernel": "k_deferred_lighting", "kernel_us": t, "pixels_per_s": npix / (t * 1e-6),
+           "pixel_light_pairs_in_radius": pairs, "pairs_per_pixel": pairs / npix, "flop_model": "150 flop per pair (75 per evaluated term, spot term twice) + 20 per pixel",
+           "gflops": flops / (t * 1e-6) / 1e9, "valu_frac": tf / VALU_PEAK_TFLOPS, "valu_peak_tflops": VALU_PEAK_TFLOPS,
+           "gbs": gb, "hbm_frac": gb / HBM_PEAK_GBS, "hbm_bytes": bytes_, "binding_bound": binds,
+           "max_abs_err_vs_cpu_glsl_2048_pixels": err, "tolerance": 1e-4, "setup_s": t_setup}
+    if not headline:
+        return res
+    return {"metric": "deferred-lighting pixels/sec (configs[4])", "value": res["pixels_per_s"], "unit": "pixels/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": t * 1e-3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": res["workload"]},
+            "roofline": {"bound": "hbm", "note": "the kernel is fp32-VALU bound (no MFMA: per-light branchy shading), so this HBM fraction is low by construction; the VALU fraction is in `lighting`",
+                         "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None},
+            "lighting": res}
+
+
+def cpu_baseline(a, atomic, n_total, dims, first, gpu_frame):
     """The CPU oracle (oracle/, a port of the reference algorithm: hash-map spatial index, candidate-box
     enumeration + probe in chunks of 25, per-entity 64-byte append, sequential apply_change), timed on
-    the host cores of this box over a bounded sample."""
+    the host cores of this box over a bounded sample -- and used as the checker of the full-size GPU frame."""
     import oracle as ro
     from render_engine_amd import synthetic, Camera
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import to_oracle, oracle_camera
     ax = min(a.cpu_sample_axis, a.axis)
-    first = (16384 // atomic - ax) // 2
-    ents = synthetic.lattice_world(cells_per_axis=ax, first_cell=first, atomic=atomic, spinner_every=a.spinner_every)
+    off = (a.axis - ax) // 2
+    # the sub-lattice around the camera, with the SAME entities as the full world (ids, sizes, positions): section (i, j, k) of the sample is
+    # section (off + i, off + j, off + k) of the world
+    full_ids = synthetic.sub_box_indices(dims, (off, off, off), (ax, ax, ax))
+    ents = synthetic.box_world(dims, first_cell=first, atomic=atomic, spinner_every=a.spinner_every, indices=full_ids)
+    ents["id"] = np.arange(len(ents), dtype=np.uint32)            # dense ids for the oracle's tables; full_ids maps back
     try:
         avail = len(os.sched_getaffinity(0))
     except Exception:
@@ -276,9 +422,26 @@ def cpu_baseline(a, atomic, n_total):
     par = max(1, min(avail, 16))                   # a 1-GPU box gives this job a 16-core share; rayon would size its pool to the cores it may use
     w = ro.World(16384, atomic, threads=1)
     w.register(to_oracle(ents))
-    c = (first + ax / 2.0) * atomic
-    cam = oracle_camera(Camera((c, c, c), (0.0, 0.0, -1.0), a.far))
+    c = (first + a.axis / 2.0) * atomic
+    pcam = Camera((c, c, c), (0.0, 0.0, -1.0), a.far)
+    cam = oracle_camera(pcam)
     L, h = w.L, w.h
+    # ---- full-size self-check: the 10,077,696-entity GPU frame against the oracle on the sub-lattice that contains every candidate section
+    check = None
+    if gpu_frame is not None:
+        vis_o = w.cull(cam); o = w.render(cam)
+        ids_o = np.sort(full_ids[o["ids"].astype(np.int64)].astype(np.uint32))
+        ids_g = np.sort(gpu_frame["ids"])
+        ok = (gpu_frame["total"] == o["total"] and gpu_frame["n_visible_vec"] == len(vis_o) and gpu_frame["n_visible_sections"] == len(np.unique(vis_o))
+              and len(ids_g) == len(ids_o) and bool(np.all(ids_g == ids_o)))
+        if ok:                                       # matrices, bit for bit, per entity
+            og, oo = np.argsort(gpu_frame["ids"], kind="stable"), np.argsort(full_ids[o["ids"].astype(np.int64)], kind="stable")
+            ok = bool(np.all(gpu_frame["mats"][og].view(np.uint32) == o["mats"][oo].view(np.uint32)))
+        check = {"ok": ok, "visible_sections": int(gpu_frame["n_visible_sections"]), "visible_instances": int(gpu_frame["total"]),
+                 "oracle_visible_sections": int(len(np.unique(vis_o))), "oracle_visible_instances": int(o["total"]),
+                 "what": "visible_sections, visible_sections_vec, visible_instances, the sorted entity-id set and every 4x4 matrix (bit-exact) of the %d-entity GPU frame against the CPU oracle on the %d^3 sub-lattice around the camera (same entities, ids mapped back)" % (n_total, ax)}
+        if not ok:
+            raise SystemExit("bench.py: full-size check FAILED: " + json.dumps(check))
     def frame():
         L.ro_frame_cull(h, C.byref(cam), 0, None)
         L.ro_frame_render(h, C.byref(cam), 0, 0, None, None, 0, None, None)
@@ -328,7 +491,7 @@ def cpu_baseline(a, atomic, n_total):
             "sample": ("%d frames over the %d^3-section sub-lattice (%d entities) centred on the camera: it contains every world section the "
                        "reference's candidate-box enumeration touches at far=%g, and the hash-based CPU path does no work for sections outside "
                        "the box, so its frame time equals that of the full %d-entity world; value = %d / that frame time"
-                       % (n, ax, len(ents), a.far, n_total, n_total))}, opt
+                       % (n, ax, len(ents), a.far, n_total, n_total))}, opt, check
 
 
 if __name__ == "__main__":

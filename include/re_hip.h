@@ -191,6 +191,13 @@ int re_cull_pack(re_ctx *ctx, const re_camera *cam, uint32_t flags, re_visible *
 int re_tick(re_ctx *ctx, float delta_time, uint32_t flags, re_tick_result *out);
 int re_wait(re_ctx *ctx, re_visible *out_visible /*nullable*/, re_tick_result *out_tick /*nullable*/);
 
+/* n frames of the reference's frame loop (threads/render_thread.rs:217-250 -> Pipeline::execute) from native code: re_cull_pack(cam, cull_flags)
+ * followed by re_tick(dt, tick_flags), n times -- nothing but the two calls above in a loop, so that a measurement does not pay for an interpreter
+ * between them.  wall_us (nullable, n floats) receives the wall time of each frame; last_visible / last_tick (nullable) the results of the last one
+ * when its call was synchronous. */
+int re_run_frames(re_ctx *ctx, const re_camera *cam, float delta_time, uint32_t cull_flags, uint32_t tick_flags, uint32_t n,
+                  float *wall_us, re_visible *last_visible, re_tick_result *last_tick);
+
 /* Copy the packed instance buffer to host memory (the persistent-mapped GL buffer of
  * RenderSystem::get_instanced_mapped_buffers, render_system/render_system.rs:210-214).  At most
  * capacity_instances are written; *n_written receives the count (truncate-and-report). */
@@ -222,6 +229,10 @@ int re_set_output_count(re_ctx *ctx, uint32_t *d_count);
 #define RE_CHANGE_DELETE       1u  /* DeleteRequest (:156-172) */
 #define RE_CHANGE_MAKE_STATIC  2u  /* MakeObjectStatic (:112-122) */
 #define RE_CHANGE_WAKE_UP      3u  /* WakeUpRequest (:123-133) */
+#define RE_CHANGE_REMOVE_COMPONENT 4u /* RemoveComponent((EntityId, TypeIdentifier)) (:151-154) -> ECS::remove_component_type_id_internal (objects/ecs.rs:523-556):
+                                       * component = RE_C_ROTATION, RE_C_SCALE, RE_C_VELOCITY, RE_C_ACCELERATION, RE_C_ROTATION_VEL or RE_C_ROTATION_ACC.  The
+                                       * presence bit is cleared and nothing else happens (no matrix recompute); later reads of Rotation / Scale see the default
+                                       * (movement_components.rs:41-55), kinematics skip an absent velocity component (logic_flow.rs:366-448). */
 typedef struct re_change { uint32_t kind, entity_id, component, reserved; float value[4]; } re_change;
 /* out: n_changed = entities whose matrix/AABB were recomputed, n_rebucket = of those, entities that changed section,
  * n_out_of_bounds = entities removed because they left the world */
@@ -244,8 +255,34 @@ int re_apply_changes(re_ctx *ctx, const re_change *changes, uint32_t n, uint32_t
 typedef struct { uint32_t this_entity, other_entity; } re_collision;
 int re_collide(re_ctx *ctx, uint32_t flags /*0*/, re_collision *pairs, uint32_t capacity, uint32_t *n_total);
 
-/* ECS read-back for user logic (LogicFunction reads components through &ECS, exports/logic_components.rs:15-18) */
+/* ECS read-back for user logic (LogicFunction reads components through &ECS, exports/logic_components.rs:15-18).  A component the entity does not
+ * carry (never written, or removed by RE_CHANGE_REMOVE_COMPONENT) yields RE_E_ARG == ECS::get_copy -> None (objects/ecs.rs:653-664). */
 int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst);
+
+/* ---- ECS presence semantics (objects/ecs.rs:61-72, 348-367, 457-556) ----
+ * The reference keeps one bitset per entity: bit i is set once the i-th REGISTERED component type has been written for the entity and cleared by
+ * remove_component / remove_entity.  Bit positions are registration order: ECS::new registers TypeIdentifier first (ecs.rs:141), LogicFlow::new the
+ * engine's components after it (flows/logic_flow.rs:83-110).  re_ecs_bitset returns that bitset (bitsets[entity][0..4] as one little-endian word). */
+#define RE_ECS_BIT_TYPE_IDENTIFIER      0   /* the entity-type marker (write_entity_type); not tracked here: always 0 */
+#define RE_ECS_BIT_CAN_CAUSE_COLLISIONS 2
+#define RE_ECS_BIT_HAS_MOVED            3
+#define RE_ECS_BIT_POSITION             4
+#define RE_ECS_BIT_VELOCITY             5
+#define RE_ECS_BIT_ACCELERATION         6
+#define RE_ECS_BIT_HAS_ROTATED          7
+#define RE_ECS_BIT_ROTATION             8
+#define RE_ECS_BIT_VELOCITY_ROTATION    9
+#define RE_ECS_BIT_ACCELERATION_ROTATION 10
+#define RE_ECS_BIT_SCALE                11
+#define RE_ECS_BIT_TRANSFORMATION       12
+#define RE_ECS_BIT_MODEL_ID             13
+#define RE_ECS_BIT_STATIC_AABB          15
+#define RE_ECS_BIT_ORIGINAL_AABB        16
+#define RE_ECS_BIT_ALWAYS_EXECUTE_LOGIC 20
+int re_ecs_bitset(re_ctx *ctx, uint32_t entity_id, uint32_t *bits);   /* 0 for an entity that was removed (remove_entity clears every bit, ecs.rs:557-600) */
+/* ECS::get_indexes_for_components (objects/ecs.rs:238-285): the entities that carry ALL the given components (RE_C_*), in ascending EntityId (the
+ * reference returns a BTreeSet).  *n = their number; the first `capacity` ids are written.  Runs on the GPU over the presence column. */
+int re_ecs_query(re_ctx *ctx, const int *components, uint32_t n_components, uint32_t *entity_ids, uint32_t capacity, uint32_t *n);
 /* entity ids removed because they left the world without OutOfBoundsLogic (update_entity_in_tree, entity_change_helpers.rs:
  * 325-351) by ticks and change batches since the previous call; the call drains the list */
 int re_get_out_of_bounds(re_ctx *ctx, uint32_t *entity_ids, uint32_t capacity, uint32_t *n);
@@ -258,6 +295,8 @@ typedef struct {
     uint32_t n_seal_waits;      /* result blocks in mapped host memory (frame result + InstanceRange table, tick counters, collision header) whose
                                  * seal did not agree when the polled "done" word became visible.  0 while the publication protocol holds. */
     uint32_t n_sync_fallbacks;  /* of those, blocks that only agreed after a stream synchronise */
+    uint32_t n_section_slots;   /* slots of the resident section table == keys the visibility scan streams per frame (world sections + padding / spare slots) */
+    uint32_t reserved2;
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,
@@ -269,7 +308,7 @@ int re_debug_get_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, float 
 int re_debug_get_visible_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n);
 /* device time of the kernels of the last synchronous cull_pack / tick, microseconds (hipEvent on the ctx stream).  The first call
  * switches the event recording on (it costs ~12 us per synchronous frame, so it is off until asked for) and returns zeros; call again
- * after the next frame. */
+ * after the next frame.  A call with three NULL pointers switches the recording off again. */
 int re_get_timings(re_ctx *ctx, float *cull_us, float *pack_us, float *tick_us);
 /* per-launch HIP-event timing of the dominant kernel (the section-key scan + cull) over a timed region, sampling every
  * `every`-th launch (0 or 1 = all): re_timing_begin(ctx, max_launches, every); ...frames...;

@@ -68,6 +68,15 @@ def deferred_lighting(pos, nrm, alb, lights_struct, idx=None):
     return out
 
 
+def lighting_spot_pairs(pos, lights_struct):
+    """number of (pixel, spot light) pairs within the light radius: the pairs whose lighting terms the shader evaluates (exact)"""
+    L = lib()
+    pos = np.ascontiguousarray(pos, np.float32)
+    L.ro_lighting_spot_pairs.restype = C.c_uint64
+    L.ro_lighting_spot_pairs.argtypes = [C.c_uint32, C.c_void_p, C.POINTER(LightsC)]
+    return int(L.ro_lighting_spot_pairs(len(pos), pos.ctypes.data, C.byref(lights_struct)))
+
+
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or \
             os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("re_oracle.c", "re_cpu_soa.c", "re_oracle.h")):

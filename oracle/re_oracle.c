@@ -1501,6 +1501,19 @@ uint32_t ro_apply_changes(ro_world *w, const ro_change *ch, uint32_t n, int end_
             else if (pos || rot || scl) { u32set_add(&kinematics, id); u32set_del(&only_translation, id); }
             break;
         }
+        case RO_CHANGE_REMOVE_COMPONENT:                         /* RemoveComponent((entity, type)) -> ecs.remove_component_type_id_internal (entity_change_helpers.rs:151-154,
+                                                                   objects/ecs.rs:523-556): the presence bit is cleared, nothing else happens; later reads see the default */
+            if (!e->alive) break;
+            switch (c->component) {
+            case 1: e->flags &= ~RO_F_HAS_ROT; e->rot[0] = 1.0f; e->rot[1] = e->rot[2] = e->rot[3] = 0.0f; break;     /* Rotation::default (movement_components.rs:41-47) */
+            case 2: e->flags &= ~RO_F_HAS_SCALE; e->scale[0] = e->scale[1] = e->scale[2] = 1.0f; break;                /* Scale::default (:49-55) */
+            case 3: e->flags &= ~RO_F_HAS_VEL; break;
+            case 4: e->flags &= ~RO_F_HAS_ACC; break;
+            case 5: e->flags &= ~RO_F_HAS_ROTVEL; break;
+            case 6: e->flags &= ~RO_F_HAS_ROTACC; break;
+            default: break;
+            }
+            break;
         case RO_CHANGE_DELETE:
             ro_tree_remove(w, id);
             u32set_del(&kinematics, id); u32set_del(&only_translation, id); u32set_add(&deleted, id);
@@ -1616,4 +1629,54 @@ void ro_deferred_lighting(uint32_t npix, const float *gpos, const float *gnormal
         }
         out[4 * j] = c[0]; out[4 * j + 1] = c[1]; out[4 * j + 2] = c[2]; out[4 * j + 3] = 1.0f;
     }
+}
+
+/* Work count of config 5: the number of (pixel, spot light) pairs with |light - frag| <= radius, i.e. the pairs whose lighting
+ * terms calculateSpotLights evaluates (second_pass_frag.glsl:93-114; the shader calls it twice per pixel).  Exact: the lights are binned on an
+ * x-z grid with cells of the largest radius, and every pixel tests the lights of the 3 x 3 cells around it with the shader's own predicate. */
+uint64_t ro_lighting_spot_pairs(uint32_t npix, const float *gpos, const ro_lights *L) {
+    const uint32_t ns = L->n_spot;
+    if (!ns || !npix) return 0;
+    float rmax = 0.0f, x0 = INFINITY, x1 = -INFINITY, z0 = INFINITY, z1 = -INFINITY;
+    for (uint32_t i = 0; i < ns; i++) {
+        if (L->spot_radius[i] > rmax) rmax = L->spot_radius[i];
+        const float *lp = L->spot_pos + 3 * i;
+        if (lp[0] < x0) x0 = lp[0]; if (lp[0] > x1) x1 = lp[0]; if (lp[2] < z0) z0 = lp[2]; if (lp[2] > z1) z1 = lp[2];
+    }
+    if (!(rmax > 0.0f)) rmax = 1.0f;
+    const float cell = rmax * 1.0001f;
+    long gx = (long)floorf((x1 - x0) / cell) + 1, gz = (long)floorf((z1 - z0) / cell) + 1;
+    if (gx < 1) gx = 1; if (gz < 1) gz = 1;
+    if (gx * gz > (1L << 24)) { gx = gx > 4096 ? 4096 : gx; gz = gz > 4096 ? 4096 : gz; }      /* (cells then cover more than one radius: still exact, only slower) */
+    const float cx = (x1 - x0) / (float)gx > cell ? (x1 - x0) / (float)gx : cell, cz = (z1 - z0) / (float)gz > cell ? (z1 - z0) / (float)gz : cell;
+    uint32_t *start = (uint32_t *)calloc((size_t)(gx * gz) + 1, 4), *items = (uint32_t *)malloc((size_t)ns * 4), *cell_of = (uint32_t *)malloc((size_t)ns * 4);
+    for (uint32_t i = 0; i < ns; i++) {
+        const float *lp = L->spot_pos + 3 * i;
+        long ix = (long)floorf((lp[0] - x0) / cx), iz = (long)floorf((lp[2] - z0) / cz);
+        if (ix >= gx) ix = gx - 1; if (iz >= gz) iz = gz - 1; if (ix < 0) ix = 0; if (iz < 0) iz = 0;
+        cell_of[i] = (uint32_t)(iz * gx + ix); start[cell_of[i] + 1]++;
+    }
+    for (long c = 0; c < gx * gz; c++) start[c + 1] += start[c];
+    uint32_t *fill = (uint32_t *)calloc((size_t)(gx * gz), 4);
+    for (uint32_t i = 0; i < ns; i++) items[start[cell_of[i]] + fill[cell_of[i]]++] = i;
+    uint64_t total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : total)
+#endif
+    for (long p = 0; p < (long)npix; p++) {
+        const float *frag = gpos + 4 * p;
+        long ix = (long)floorf((frag[0] - x0) / cx), iz = (long)floorf((frag[2] - z0) / cz);
+        for (long dz = -1; dz <= 1; dz++) for (long dx = -1; dx <= 1; dx++) {
+            const long jx = ix + dx, jz = iz + dz;
+            if (jx < 0 || jz < 0 || jx >= gx || jz >= gz) continue;
+            const long c = jz * gx + jx;
+            for (uint32_t k = start[c]; k < start[c + 1]; k++) {
+                const uint32_t i = items[k]; const float *lp = L->spot_pos + 3 * i;
+                float d[3] = { lp[0] - frag[0], lp[1] - frag[1], lp[2] - frag[2] };
+                if (!(v3_len(d) > L->spot_radius[i])) total++;
+            }
+        }
+    }
+    free(start); free(items); free(cell_of); free(fill);
+    return total;
 }

@@ -184,6 +184,7 @@ uint32_t ro_find_related(const ro_world *w, uint64_t key, uint32_t cap, uint64_t
 #define RO_CHANGE_DELETE      1u
 #define RO_CHANGE_MAKE_STATIC 2u
 #define RO_CHANGE_WAKE_UP     3u
+#define RO_CHANGE_REMOVE_COMPONENT 4u   /* component = 1..6 (Rotation, Scale, Velocity, Acceleration, VelocityRotation, AccelerationRotation) */
 typedef struct { uint32_t kind, entity_id, component, pad; float value[4]; } ro_change;
 uint32_t ro_apply_changes(ro_world *w, const ro_change *changes, uint32_t n, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
 
@@ -205,6 +206,8 @@ typedef struct {
 /* gpos/gnormal: RGBA32F (4 floats per pixel), galbedo: RGBA8; out: RGBA32F.  Only pixels listed in idx (n of them) when idx != NULL. */
 void ro_deferred_lighting(uint32_t npix, const float *gpos, const float *gnormal, const uint8_t *galbedo, const ro_lights *L,
                           const uint32_t *idx, uint32_t n, float *out);
+/* work count of config 5: (pixel, spot light) pairs within the light radius (exact; lights binned on an x-z grid) */
+uint64_t ro_lighting_spot_pairs(uint32_t npix, const float *gpos, const ro_lights *L);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,10 @@ CFG_FULL_REBUILD = 0x1
 CFG_TIGHT_SLACK = 0x2
 CFG_PROBE = 0x4
 CFG_PROBE_ALWAYS = 0x8
-CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP = 0, 1, 2, 3
+CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP, CHANGE_REMOVE_COMPONENT = 0, 1, 2, 3, 4
+# bit positions of re_ecs_bitset == registration order of the reference (ECS::new + LogicFlow::new)
+ECS_BIT = dict(TYPE_IDENTIFIER=0, CAN_CAUSE_COLLISIONS=2, HAS_MOVED=3, POSITION=4, VELOCITY=5, ACCELERATION=6, HAS_ROTATED=7, ROTATION=8, VELOCITY_ROTATION=9,
+               ACCELERATION_ROTATION=10, SCALE=11, TRANSFORMATION=12, MODEL_ID=13, STATIC_AABB=15, ORIGINAL_AABB=16, ALWAYS_EXECUTE_LOGIC=20)
 
 
 class TickResult(C.Structure):
@@ -62,7 +65,7 @@ class Stats(C.Structure):
     _fields_ = [("n_entities", C.c_uint32), ("n_dynamic", C.c_uint32), ("n_sections", C.c_uint32),
                 ("n_shared_sections", C.c_uint32), ("max_level", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("n_probe_frames", C.c_uint32), ("n_table_rebuilds", C.c_uint32), ("n_fused_frames", C.c_uint32), ("reserved", C.c_uint32),
-                ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32)]
+                ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32), ("n_section_slots", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class LightingConfig(C.Structure):
@@ -79,7 +82,7 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_collide", "re_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
@@ -111,11 +114,14 @@ def load():
     L.re_cull_pack.restype = C.c_int; L.re_cull_pack.argtypes = [vp, C.POINTER(CameraC), C.c_uint32, C.POINTER(Visible)]
     L.re_tick.restype = C.c_int; L.re_tick.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(TickResult)]
     L.re_wait.restype = C.c_int; L.re_wait.argtypes = [vp, C.POINTER(Visible), C.POINTER(TickResult)]
+    L.re_run_frames.restype = C.c_int; L.re_run_frames.argtypes = [vp, C.POINTER(CameraC), C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(Visible), C.POINTER(TickResult)]
     L.re_collide.restype = C.c_int; L.re_collide.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.re_apply_changes.restype = C.c_int; L.re_apply_changes.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(TickResult)]
     L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]
     L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]
     L.re_read_component.restype = C.c_int; L.re_read_component.argtypes = [vp, C.c_uint32, C.c_int, vp]
+    L.re_ecs_bitset.restype = C.c_int; L.re_ecs_bitset.argtypes = [vp, C.c_uint32, _u32p]
+    L.re_ecs_query.restype = C.c_int; L.re_ecs_query.argtypes = [vp, C.POINTER(C.c_int), C.c_uint32, vp, C.c_uint32, _u32p]
     L.re_get_out_of_bounds.restype = C.c_int; L.re_get_out_of_bounds.argtypes = [vp, vp, C.c_uint32, _u32p]
     L.re_get_stats.restype = C.c_int; L.re_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.re_debug_get_sections.restype = C.c_int; L.re_debug_get_sections.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, _u32p]

@@ -83,9 +83,11 @@ struct re_ctx {
     uint32_t n_rebuilds = 0;
     bool has_rotvel = false; uint32_t n_dead = 0;         // n_dead: rows removed by out-of-bounds ticks (upper bound on uncounted reservations)
     bool ids_identity = false;                           // entity id == row index (dense ids): no lookup table needed
+    std::vector<uint32_t> id_to_row;                     // otherwise, ids below 4n: direct table (rows are not in id order once the dynamic entities lead)
     std::vector<std::pair<uint32_t, uint32_t>> id_rows;  // otherwise (id, row) sorted by id
     bool row_of(uint32_t id, uint32_t *row) const {
         if (ids_identity) { if (id >= n) return false; *row = id; return true; }
+        if (!id_to_row.empty()) { if (id >= id_to_row.size() || id_to_row[id] == 0xFFFFFFFFu) return false; *row = id_to_row[id]; return true; }
         auto p = std::lower_bound(id_rows.begin(), id_rows.end(), std::make_pair(id, 0u));
         if (p == id_rows.end() || p->first != id) return false;
         *row = p->second; return true;
@@ -121,6 +123,9 @@ struct re_ctx {
     // groups
     uint32_t ngclass = 0, nslots = 0;
     DevBuf<uint32_t> d_gc_model, d_gc_rs, d_gc_sort, d_group_count, d_group_begin, d_group_fill;
+    // large visible sets, group tables of <= COUNT_SLOTS_MAX slots: instance counts / running fills per (cursor shard, group slot), two parities alternating by
+    // large-pack frame.  k_pack_large of one frame clears the other parity's arrays for the next; `dirty` tracks arrays that hold something nobody will clear.
+    DevBuf<uint32_t> d_gcount, d_gfill; bool gc_dirty[2] = { false, false }; uint32_t large_seq = 0;
     // frame
     uint32_t frame = 0; bool have_cull = false;
     DevBuf<uint32_t> d_rows_gc; std::vector<uint32_t> h_sh_begin;   // group class per row-pool entry; pool offsets of the shared sections' members
@@ -219,6 +224,7 @@ static void free_world(re_ctx *c) {
     c->d_cell_stamp.release(a); c->d_rows.release(a); c->d_cell_flags.release(a); c->d_sh_cells.release(a); c->d_sh_owner.release(a); c->d_sh_aabb.release(a);
     c->d_sh_begin.release(a); c->d_sh_nact.release(a); c->d_sh_nstat.release(a); c->d_sh_cached.release(a); c->d_sh_dirty.release(a);
     c->d_gc_model.release(a); c->d_gc_rs.release(a); c->d_gc_sort.release(a); c->d_group_count.release(a); c->d_group_begin.release(a); c->d_group_fill.release(a);
+    c->d_gcount.release(a); c->d_gfill.release(a); c->gc_dirty[0] = c->gc_dirty[1] = false;
     c->d_item_row.release(a); c->d_item_slot.release(a); c->d_out_ids.release(a); c->d_out_mats.release(a);
     c->d_hdr.release(a); c->d_th.release(a); c->d_params.release(a); c->d_movers.release(a); c->d_oob.release(a);
     if (c->h_block) { (void)hipHostFree(c->h_block); c->h_block = nullptr; }      // one block: frame result, speculation word, tick counters, group table
@@ -268,15 +274,8 @@ static int upload_row_gc(re_ctx *c, const std::vector<Pair32> &pairs) {
     return RE_OK;
 }
 
-// the dynamic table's copy of row_cell (the tick reads it coalesced instead of gathering row_cell[row])
-static int upload_dyn_cells(re_ctx *c) {
-    if (!c->ndyn) return RE_OK;
-    std::vector<uint32_t> dc(c->ndyn);
-    for (uint32_t j = 0; j < c->ndyn; j++) dc[j] = c->h_row_cell[c->h_dyn_row[j]];
-    if (c->d_dyn_cell.n < c->ndyn) HIPCHK(c, c->d_dyn_cell.alloc(c->ndyn, &c->dev_bytes));
-    HIPCHK(c, hipMemcpy(c->d_dyn_cell.p, dc.data(), (size_t)c->ndyn * 4, hipMemcpyHostToDevice));
-    return RE_OK;
-}
+// (the dynamic entities are the first ndyn rows: the tick reads row_cell[j] itself, there is no separate copy to keep in step)
+static int upload_dyn_cells(re_ctx *) { return RE_OK; }
 
 // ------------------------------------------------------------------------------------------------
 // World-section structure from the per-row section keys (the spatial hash as key-sorted arrays).
@@ -300,7 +299,12 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     std::vector<SortRec> recs; recs.reserve(n);
     for (uint32_t r = 0; r < n; r++) if (row_nk[r] == 1) recs.push_back({ row_key[r], ((uint64_t)((flags[r] & F_STATIC) ? 1 : 0) << 32) | c->h_id[r], r });
     auto cmp = [](const SortRec &a, const SortRec &b) { return a.key != b.key ? a.key < b.key : a.sub < b.sub; };
-    if (!std::is_sorted(recs.begin(), recs.end(), cmp)) std::sort(recs.begin(), recs.end(), cmp);
+    if (!std::is_sorted(recs.begin(), recs.end(), cmp)) {
+        // rows are the dynamic entities followed by the others, each part in upload order: two sorted runs in a key-ordered world
+        auto mid = std::partition_point(recs.begin(), recs.end(), [&](const SortRec &a) { return a.row < c->ndyn; });
+        if (std::is_sorted(recs.begin(), mid, cmp) && std::is_sorted(mid, recs.end(), cmp)) std::inplace_merge(recs.begin(), mid, recs.end(), cmp);
+        else std::sort(recs.begin(), recs.end(), cmp);
+    }
     // --- shared sections, indexed by first appearance in row order (== creation order of a fresh tree)
     std::sort(shrec.begin(), shrec.end(), [](const SharedRec &a, const SharedRec &b) { return a.row < b.row; });
     std::map<SharedId, uint32_t> shmap; std::vector<SharedId> shids; std::vector<std::vector<uint32_t>> sh_act, sh_sta;
@@ -541,11 +545,25 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     std::vector<uint32_t> flags(n), gclass(n);
     std::vector<uint32_t> dyn_row; std::vector<float> dvel, dacc, drv, dra;
     std::unordered_map<GroupKey, uint32_t, GroupKeyHash> gmap; std::vector<GroupKey> gkeys;
-    c->h_id.assign(E->entity_id, E->entity_id + n);
-    c->ids_identity = true; c->id_rows.clear();
-    for (uint32_t r = 0; r < n && c->ids_identity; r++) if (E->entity_id[r] != r) c->ids_identity = false;
+    // Row order: the dynamic entities (Velocity or VelocityRotation) first, otherwise upload order.  Row j of every per-entity column then IS
+    // dynamic entity j, and the tick reads and writes contiguous streams (k_tick) instead of gathering 12..64-byte pieces per entity.
+    std::vector<uint32_t> perm; bool permuted = false;
+    {
+        uint32_t nd = 0; bool prefix = true;
+        for (uint32_t i = 0; i < n; i++) if (E->flags[i] & (F_HAS_VEL | F_HAS_ROTVEL)) { if (i != nd) prefix = false; nd++; }
+        if (nd && !prefix) {
+            perm.resize(n); uint32_t a = 0, b = nd;
+            for (uint32_t i = 0; i < n; i++) { if (E->flags[i] & (F_HAS_VEL | F_HAS_ROTVEL)) perm[a++] = i; else perm[b++] = i; }
+            permuted = true;
+        }
+    }
+    auto src = [&](uint32_t r) -> size_t { return permuted ? perm[r] : r; };
+    c->h_id.resize(n); for (uint32_t r = 0; r < n; r++) c->h_id[r] = E->entity_id[src(r)];
+    c->ids_identity = true; c->id_rows.clear(); c->id_to_row.clear();
+    for (uint32_t r = 0; r < n && c->ids_identity; r++) if (c->h_id[r] != r) c->ids_identity = false;
     for (uint32_t r = 0; r < n; r++) {
-        uint32_t fl = E->flags[r] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
+        const size_t i = src(r);
+        uint32_t fl = E->flags[i] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
         flags[r] = fl;
         if ((fl & F_HAS_ROT) && !E->rotation) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROT but rotation == NULL", r);
         if ((fl & F_HAS_SCALE) && !E->scale) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_SCALE but scale == NULL", r);
@@ -554,29 +572,35 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
         if ((fl & F_HAS_ROTVEL) && !E->rotation_velocity) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROTVEL but rotation_velocity == NULL", r);
         if ((fl & F_HAS_ROTACC) && !E->rotation_acceleration) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROTACC but rotation_acceleration == NULL", r);
         if (fl & F_HAS_ROT) {
-            const float *a = E->rotation + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]);
+            const float *a = E->rotation + i * 4; float nn = norm3(a[0], a[1], a[2]);
             rot[r * 4 + 0] = a[0] / nn; rot[r * 4 + 1] = a[1] / nn; rot[r * 4 + 2] = a[2] / nn; rot[r * 4 + 3] = a[3];
         } else { rot[r * 4 + 0] = 1.f; rot[r * 4 + 1] = 0.f; rot[r * 4 + 2] = 0.f; rot[r * 4 + 3] = 0.f; }           // Rotation::default
-        if (fl & F_HAS_SCALE) { scl[r * 3 + 0] = E->scale[r * 3 + 0]; scl[r * 3 + 1] = E->scale[r * 3 + 1]; scl[r * 3 + 2] = E->scale[r * 3 + 2]; }
+        if (fl & F_HAS_SCALE) { scl[r * 3 + 0] = E->scale[i * 3 + 0]; scl[r * 3 + 1] = E->scale[i * 3 + 1]; scl[r * 3 + 2] = E->scale[i * 3 + 2]; }
         else { scl[r * 3 + 0] = scl[r * 3 + 1] = scl[r * 3 + 2] = 1.f; }                                          // Scale::default
-        GroupKey gk{ E->model_index[r], E->render_system ? E->render_system[r] : 0u, E->sortable ? E->sortable[r] : 0u };
+        GroupKey gk{ E->model_index[i], E->render_system ? E->render_system[i] : 0u, E->sortable ? E->sortable[i] : 0u };
         auto it = gmap.find(gk);
         if (it == gmap.end()) { it = gmap.emplace(gk, (uint32_t)gkeys.size()).first; gkeys.push_back(gk); }
         gclass[r] = it->second;
         if (fl & (F_HAS_VEL | F_HAS_ROTVEL)) {
             dyn_row.push_back(r);
-            for (int k = 0; k < 3; k++) { dvel.push_back((fl & F_HAS_VEL) ? E->velocity[r * 3 + k] : 0.f); dacc.push_back((fl & F_HAS_ACC) ? E->acceleration[r * 3 + k] : 0.f); }
+            for (int k = 0; k < 3; k++) { dvel.push_back((fl & F_HAS_VEL) ? E->velocity[i * 3 + k] : 0.f); dacc.push_back((fl & F_HAS_ACC) ? E->acceleration[i * 3 + k] : 0.f); }
             float rv[4] = { 1.f, 0.f, 0.f, 0.f }, ra[4] = { 1.f, 0.f, 0.f, 0.f };
-            if (fl & F_HAS_ROTVEL) { const float *a = E->rotation_velocity + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]); rv[0] = a[0] / nn; rv[1] = a[1] / nn; rv[2] = a[2] / nn; rv[3] = a[3]; }
-            if (fl & F_HAS_ROTACC) { const float *a = E->rotation_acceleration + (size_t)r * 4; float nn = norm3(a[0], a[1], a[2]); ra[0] = a[0] / nn; ra[1] = a[1] / nn; ra[2] = a[2] / nn; ra[3] = a[3]; }
+            if (fl & F_HAS_ROTVEL) { const float *a = E->rotation_velocity + i * 4; float nn = norm3(a[0], a[1], a[2]); rv[0] = a[0] / nn; rv[1] = a[1] / nn; rv[2] = a[2] / nn; rv[3] = a[3]; }
+            if (fl & F_HAS_ROTACC) { const float *a = E->rotation_acceleration + i * 4; float nn = norm3(a[0], a[1], a[2]); ra[0] = a[0] / nn; ra[1] = a[1] / nn; ra[2] = a[2] / nn; ra[3] = a[3]; }
             for (int k = 0; k < 4; k++) { drv.push_back(rv[k]); dra.push_back(ra[k]); }
         }
     }
     if (!c->ids_identity) {
-        c->id_rows.resize(n);
-        for (uint32_t r = 0; r < n; r++) c->id_rows[r] = { E->entity_id[r], r };
-        std::sort(c->id_rows.begin(), c->id_rows.end());
-        for (uint32_t r = 1; r < n; r++) if (c->id_rows[r].first == c->id_rows[r - 1].first) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity id %u", c->id_rows[r].first);
+        uint32_t max_id = 0; for (uint32_t r = 0; r < n; r++) max_id = std::max(max_id, c->h_id[r]);
+        if ((uint64_t)max_id < 4ull * n + 1024ull) {                           // dense enough: a direct id -> row table
+            c->id_to_row.assign((size_t)max_id + 1, 0xFFFFFFFFu);
+            for (uint32_t r = 0; r < n; r++) { if (c->id_to_row[c->h_id[r]] != 0xFFFFFFFFu) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity id %u", c->h_id[r]); c->id_to_row[c->h_id[r]] = r; }
+        } else {
+            c->id_rows.resize(n);
+            for (uint32_t r = 0; r < n; r++) c->id_rows[r] = { c->h_id[r], r };
+            std::sort(c->id_rows.begin(), c->id_rows.end());
+            for (uint32_t r = 1; r < n; r++) if (c->id_rows[r].first == c->id_rows[r - 1].first) return c->fail(RE_E_ARG, "re_upload_entities: duplicate entity id %u", c->id_rows[r].first);
+        }
     }
     c->h_flags = flags; c->h_dyn_row = dyn_row; c->has_rotvel = false;
     c->user_row = ROW_CELL_NONE; for (uint32_t r = 0; r < n; r++) if (flags[r] & F_USER) { c->user_row = r; break; }
@@ -592,14 +616,19 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, c->d_row_key.alloc(n, acct)); HIPCHK(c, c->d_row_nk.alloc(n, acct)); HIPCHK(c, c->d_shrec.alloc(n, acct)); HIPCHK(c, c->d_counter.alloc(4, acct));
     HIPCHK(c, c->d_dyn_row.alloc(c->ndyn, acct)); HIPCHK(c, c->d_dyn_vel.alloc((size_t)c->ndyn * 3, acct)); HIPCHK(c, c->d_dyn_acc.alloc((size_t)c->ndyn * 3, acct));
     HIPCHK(c, c->d_dyn_rotvel.alloc((size_t)c->ndyn * 4, acct)); HIPCHK(c, c->d_dyn_rotacc.alloc((size_t)c->ndyn * 4, acct));
+    std::vector<float> pos_p, orig_p;                                          // the caller's arrays in row order (only when the rows were permuted)
+    if (permuted) {
+        pos_p.resize((size_t)n * 3); orig_p.resize((size_t)n * 6);
+        for (uint32_t r = 0; r < n; r++) { const size_t i = perm[r]; memcpy(&pos_p[(size_t)r * 3], E->position + i * 3, 12); memcpy(&orig_p[(size_t)r * 6], E->original_aabb + i * 6, 24); }
+    }
     if (n) {
-        HIPCHK(c, hipMemcpyAsync(c->d_id.p, E->entity_id, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_id.p, c->h_id.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_gclass.p, gclass.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_flags.p, flags.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_pos.p, E->position, (size_t)n * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_pos.p, permuted ? pos_p.data() : E->position, (size_t)n * 12, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_rot.p, rot.data(), (size_t)n * 16, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_scale.p, scl.data(), (size_t)n * 12, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemcpyAsync(c->d_orig.p, E->original_aabb, (size_t)n * 24, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_orig.p, permuted ? orig_p.data() : E->original_aabb, (size_t)n * 24, hipMemcpyHostToDevice, st));
     }
     if (c->ndyn) {
         HIPCHK(c, hipMemcpyAsync(c->d_dyn_row.p, dyn_row.data(), (size_t)c->ndyn * 4, hipMemcpyHostToDevice, st));
@@ -621,6 +650,11 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
         }
         HIPCHK(c, hipMemsetAsync(c->d_group_count.p, 0, (size_t)std::max(c->nslots, 1u) * 4, st));
         HIPCHK(c, hipMemsetAsync(c->d_group_fill.p, 0, (size_t)std::max(c->nslots, 1u) * 4, st));
+        if (c->nslots <= COUNT_SLOTS_MAX) {
+            const size_t words = 2u * CURSOR_SHARDS * (size_t)std::max(c->nslots, 1u);
+            HIPCHK(c, c->d_gcount.alloc(words, acct)); HIPCHK(c, c->d_gfill.alloc(words, acct));
+            HIPCHK(c, hipMemsetAsync(c->d_gcount.p, 0, words * 4, st)); HIPCHK(c, hipMemsetAsync(c->d_gfill.p, 0, words * 4, st));
+        }
     }
     // TRS -> matrix, AABB, section keys on the GPU
     HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 16, st));
@@ -800,7 +834,7 @@ static FrameHeader *frame_header(re_ctx *c, uint32_t frame) { return c->d_hdr.p 
 static ItemSink item_sink(re_ctx *c, uint32_t frame) {
     const size_t half = (size_t)(frame & 1u) * c->item_cap;
     ItemSink K; K.item_row = c->d_item_row.p + half; K.item_slot = c->d_item_slot.p + half; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
-    K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; return K;
+    K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0; return K;
 }
 static SharedArrays shared_arrays(re_ctx *c) {
     SharedArrays S; S.n = c->nsh; S.cells = c->d_sh_cells.p; S.aabb = c->d_sh_aabb.p; S.begin = c->d_sh_begin.p; S.nact = c->d_sh_nact.p; S.nstat = c->d_sh_nstat.p;
@@ -808,12 +842,40 @@ static SharedArrays shared_arrays(re_ctx *c) {
 }
 
 // multi-kernel pack for large visible sets: count -> scan -> scatter
-static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next) {
+// The counts of the large-pack frame about to be issued live in parity `par` of d_gcount / d_gfill: both must be clear before anything adds to them.
+static int prepare_group_counts(re_ctx *c, uint32_t par) {
+    if (!c->gc_dirty[par]) return RE_OK;
+    const size_t words = (size_t)CURSOR_SHARDS * std::max(c->nslots, 1u);
+    HIPCHK(c, hipMemsetAsync(c->d_gcount.p + par * words, 0, words * 4, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_gfill.p + par * words, 0, words * 4, c->stream));
+    c->gc_dirty[par] = false;
+    return RE_OK;
+}
+static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next, bool counted_by_scan = false) {
     const uint32_t nshards = CURSOR_SHARDS, seg_cap = c->item_cap / nshards;
     const ItemSink KS = item_sink(c, c->lane_seq);
     hipStream_t st = c->stream;
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
+    if (c->nslots <= COUNT_SLOTS_MAX && c->d_gcount.p) {
+        // one launch: the counts per (cursor shard, group slot) come from the scan itself (counted_by_scan) or from a counting pass over the instance list
+        const uint32_t par = c->large_seq & 1u; const size_t words = (size_t)CURSOR_SHARDS * std::max(c->nslots, 1u);
+        if (!counted_by_scan) {
+            int rc = prepare_group_counts(c, par); if (rc != RE_OK) return rc;
+            const uint32_t parts = std::max(1u, std::min(64u, (c->pred_total / nshards + 2047u) / 2048u));
+            hipLaunchKernelGGL(k_emit_count_sharded, dim3(nshards * parts), dim3(256), (size_t)std::max(c->nslots, 1u) * 4, st, hdr, KS.item_slot, nshards, seg_cap, c->d_gcount.p + par * words, c->nslots, c->d_spec.p);
+        }
+        PackLargeArgs A{}; A.hdr = hdr; A.hdr_next = hdr_next; A.th = c->d_th.p; A.gcount = c->d_gcount.p + par * words; A.gfill = c->d_gfill.p + par * words;
+        A.zero_a = c->d_gcount.p + (par ^ 1u) * words; A.zero_b = c->d_gfill.p + (par ^ 1u) * words; A.zero_words = (uint32_t)words;
+        A.nslots = c->nslots; A.out_cap = out_cap; A.range_cap = c->nslots; A.frame = c->frame; A.item_row = KS.item_row; A.item_slot = KS.item_slot; A.nshards = nshards; A.seg_cap = seg_cap;
+        A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats; A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p;
+        A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count;
+        const uint32_t grid = std::min(8192u, std::max(64u, c->pred_total / PACK_LARGE_TILE + 2u * nshards));     // workgroups loop over the tiles: any grid is correct
+        hipLaunchKernelGGL(k_pack_large, dim3(grid), dim3(256), 0, st, A);
+        HIPCHK(c, hipGetLastError());
+        c->gc_dirty[par] = true; c->gc_dirty[par ^ 1u] = false;                // this frame's arrays stay as they are; the other parity's were cleared by the launch
+        c->large_seq++;
+        return RE_OK;
+    }
     uint32_t grid = std::min(2048u, (c->item_cap + 255u) / 256u);
     size_t lds = c->nslots <= LDS_HIST_SLOTS ? (size_t)std::max(c->nslots, 1u) * 4 : 4;
     // few workgroups for the count: every workgroup flushes its LDS histogram with one global atomic per non-empty group,
@@ -977,6 +1039,15 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     ScanCullArgs SA; SA.B = c->PB; SA.B32 = c->PB32; SA.cell_key64 = c->d_cell_key.p; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p; SA.cell_nghost = c->d_cell_nghost.p;
     SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c, c->lane_seq); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
+    // a large visible set is expected: the scan counts the instances per (cursor shard, group slot) while it expands them, so the pack is one launch
+    const bool count_in_scan = !small && c->nslots <= COUNT_SLOTS_MAX && c->d_gcount.p != nullptr;
+    size_t scan_lds = 0;
+    if (count_in_scan) {
+        const uint32_t par = c->large_seq & 1u;
+        int rc = prepare_group_counts(c, par); if (rc != RE_OK) return rc;
+        SA.K.group_count = c->d_gcount.p + (size_t)par * CURSOR_SHARDS * std::max(c->nslots, 1u); SA.K.count_nslots = c->nslots;
+        scan_lds = (size_t)(CULL_THREADS / 64) * c->nslots * 4;
+    }
     static_assert(alignof(ScanCullArgs) == 8, "SCAN_CULL_ARGS_OFFSET assumes 8-byte alignment");
 #ifdef RE_EXP_STAMPS
     if (!c->d_timeline.p) HIPCHK(c, c->d_timeline.alloc((size_t)scan_grid * 4 * 8, nullptr));
@@ -1027,10 +1098,10 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         hipExtLaunchKernelGGL(k_scan_cull_fused<false>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (c->deferred_grid << 8),
                               SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
     else if (c->key32)
-        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     else
-        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), 0, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     if (fuse) { c->deferred_pack = false; c->n_fused_frames++; }
     HIPCHK(c, hipGetLastError());
@@ -1049,7 +1120,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         } else
             hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->lane_seq), c->n + c->ghost_cap);
     } else {
-        int rc = launch_pack_large(c, hdr, hdr_next);
+        int rc = launch_pack_large(c, hdr, hdr_next, count_in_scan);
         if (rc != RE_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
@@ -1291,12 +1362,11 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     uint64_t *acct = &c->dev_bytes;
     {
         std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
-        std::vector<Pair32> p_dyncell;                                       // the dynamic table's copy of row_cell
-        for (const Pair32 &pr : p_rowcell) { auto it = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), pr.idx); if (it != c->h_dyn_row.end() && *it == pr.idx) p_dyncell.push_back(Pair32{ (uint32_t)(it - c->h_dyn_row.begin()), pr.val }); }
+        std::vector<Pair32> p_dyncell;                                       // (unused since the dynamic rows lead the row arrays: row_cell itself is what the tick reads)
         std::vector<Pair32> p_rowsgc; p_rowsgc.reserve(p_rows.size());         // the group class travels with every pool entry written
         for (const Pair32 &pr : p_rows) p_rowsgc.push_back(Pair32{ pr.idx, effective_gclass(c, pr.val) });
         std::vector<Pair32> *v32[9] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell, &p_rowsgc, &p_ng };
-        uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_dyn_cell.p, c->d_rows_gc.p, c->d_cell_nghost.p };
+        uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_row_cell.p, c->d_rows_gc.p, c->d_cell_nghost.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
         size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
@@ -1591,8 +1661,8 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[3], st));
     if (c->ndyn) {
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
-        hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
-                           row_arrays(c), c->d_dyn_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
+        hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
+                           row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
                            (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame);
         c->th_clean = false;
         c->tick_published = !(flags & RE_TICK_ASYNC);
@@ -1644,6 +1714,10 @@ static int resolve(re_ctx *c) {
         c->pending.clear();
         if (!replay.empty()) {
             HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream)); c->th_clean = false;
+            if (c->d_gcount.p) {                                              // a cancelled pack cleared nothing: start the replay from clean count / fill arrays
+                HIPCHK(c, hipMemsetAsync(c->d_gcount.p, 0, c->d_gcount.n * 4, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_gfill.p, 0, c->d_gfill.n * 4, c->stream));
+                c->gc_dirty[0] = c->gc_dirty[1] = false;
+            }
             c->cull_inflight = false;
             uint32_t *keep_ids = c->ext_out_ids; float *keep_mats = c->ext_out_mats; uint32_t keep_cap = c->ext_out_cap, *keep_cnt = c->ext_out_count;
             for (const auto &pc : replay) {
@@ -1751,6 +1825,20 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
                 writes[{ r, ch.component }] = v;
                 if (pos && !rot && !scl) { if (!kin.count(r)) trans.insert(r); }
                 else if (pos || rot || scl) { kin.insert(r); trans.erase(r); }
+                break;
+            }
+            case RE_CHANGE_REMOVE_COMPONENT: {                                 // ecs.remove_component_type_id_internal: presence bit off, nothing recomputed
+                if (deleted.count(r)) break;
+                uint32_t j = 0;
+                switch (ch.component) {
+                    case RE_C_ROTATION: writes[{ r, (uint32_t)RE_C_ROTATION }] = { 1.f, 0.f, 0.f, 0.f }; flag_op(r, F_HAS_ROT, 0); break;       // later reads see Rotation::default
+                    case RE_C_SCALE: writes[{ r, (uint32_t)RE_C_SCALE }] = { 1.f, 1.f, 1.f, 0.f }; flag_op(r, F_HAS_SCALE, 0); break;         // Scale::default
+                    case RE_C_VELOCITY: case RE_C_ACCELERATION: case RE_C_ROTATION_VEL: case RE_C_ROTATION_ACC:
+                        writes.erase({ r, ch.component });
+                        if (dyn_index(r, j)) flag_op(r, ch.component == RE_C_VELOCITY ? F_HAS_VEL : ch.component == RE_C_ACCELERATION ? F_HAS_ACC : ch.component == RE_C_ROTATION_VEL ? F_HAS_ROTVEL : F_HAS_ROTACC, 0);
+                        break;                                                  // (an entity without a slot in the dynamic table never carried it: no effect, like the reference)
+                    default: return c->fail(RE_E_ARG, "re_apply_changes: component %u cannot be removed (change %u)", ch.component, i);
+                }
                 break;
             }
             case RE_CHANGE_DELETE:
@@ -1902,7 +1990,7 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
                                    c->d_params.p, c->d_col_hdr.p, c->d_col_shared.p, COL_SHARED_CAP);
     hipLaunchKernelGGL(k_col_tops, dim3(COL_REGION_CAP / 256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_region.p, COL_REGION_CAP, c->d_col_high.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP,
                        c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_col_near.p, COL_REGION_CAP);
-    hipLaunchKernelGGL(k_col_moved, dim3((c->ndyn + 1 + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_dyn_cell.p, c->user_row, user_cell, row_arrays(c), c->d_cell_key.p,
+    hipLaunchKernelGGL(k_col_moved, dim3((c->ndyn + 1 + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_row.p, c->d_row_cell.p /* dynamic rows are the first ndyn rows */, c->user_row, user_cell, row_arrays(c), c->d_cell_key.p,
                        c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_row_moved.p,
                        tab_key, tab_min, c->col_tab_size - 1u);
     hipLaunchKernelGGL(k_col_pairs, dim3(256), dim3(256), 0, st, c->d_col_hdr.p, c->d_col_moved.p, c->col_moved_cap, c->d_col_near.p, COL_REGION_CAP, c->d_col_shared.p, COL_SHARED_CAP,
@@ -1949,6 +2037,23 @@ extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_t
     return rc;
 }
 
+// The frame loop of the reference (threads/render_thread.rs:217-250 -> Pipeline::execute, flows/pipeline.rs:212-276) driven from native code,
+// for measurement without an interpreter between the calls: exactly the two public entry points, n times.
+extern "C" int re_run_frames(re_ctx *c, const re_camera *cam, float dt, uint32_t cull_flags, uint32_t tick_flags, uint32_t n, float *wall_us, re_visible *last_visible, re_tick_result *last_tick) {
+    if (!c) return RE_E_ARG;
+    if (!cam) return c->fail(RE_E_ARG, "re_run_frames: camera is NULL");
+    re_visible vis{}; re_tick_result tr{};
+    for (uint32_t f = 0; f < n; f++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = re_cull_pack(c, cam, cull_flags, &vis); if (rc != RE_OK) return rc;
+        rc = re_tick(c, dt, tick_flags, &tr); if (rc != RE_OK) return rc;
+        if (wall_us) wall_us[f] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (last_visible && !(cull_flags & RE_CULL_ASYNC)) *last_visible = vis;
+    if (last_tick && !(tick_flags & RE_TICK_ASYNC)) *last_tick = tr;
+    return RE_OK;
+}
+
 extern "C" int re_copy_visible(re_ctx *c, uint32_t *ids_host, float *mats_host, uint32_t capacity, uint32_t *n_written) {
     if (!c || !c->h_res) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1988,6 +2093,12 @@ extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, v
         j = (uint32_t)(p - c->h_dyn_row.begin()); return true;
     };
     uint32_t j = 0;
+    {   // ECS::get_copy -> None for a component the entity does not carry (objects/ecs.rs:653-664, check_component_written :348-367)
+        static const uint32_t need[] = { 0, F_HAS_ROT, F_HAS_SCALE, F_HAS_VEL, F_HAS_ACC, F_HAS_ROTVEL, F_HAS_ROTACC };
+        if (component >= RE_C_ROTATION && component <= RE_C_ROTATION_ACC && !(c->h_flags[r] & need[component]))
+            return c->fail(RE_E_ARG, "re_read_component: entity %u does not carry component %d", entity_id, component);
+        if ((c->h_flags[r] & F_DEAD) && component != RE_C_FLAGS) return c->fail(RE_E_ARG, "re_read_component: entity %u was removed", entity_id);
+    }
     switch (component) {
         case RE_C_POSITION: HIPCHK(c, hipMemcpy(dst, c->d_pos.p + (size_t)r * 3, 12, hipMemcpyDeviceToHost)); break;
         case RE_C_ROTATION: HIPCHK(c, hipMemcpy(dst, c->d_rot.p + (size_t)r * 4, 16, hipMemcpyDeviceToHost)); break;
@@ -2005,6 +2116,64 @@ extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, v
     return RE_OK;
 }
 
+// ---- ECS presence semantics (objects/ecs.rs): see include/re_hip.h
+static uint32_t ecs_bits_of_flags(uint32_t fl) {
+    if (fl & F_DEAD) return 0u;                                               // remove_entity clears every component (ecs.rs:557-600)
+    uint32_t b = (1u << RE_ECS_BIT_POSITION) | (1u << RE_ECS_BIT_TRANSFORMATION) | (1u << RE_ECS_BIT_MODEL_ID) | (1u << RE_ECS_BIT_STATIC_AABB) | (1u << RE_ECS_BIT_ORIGINAL_AABB);
+    if (fl & F_CAN_COLLIDE) b |= 1u << RE_ECS_BIT_CAN_CAUSE_COLLISIONS;
+    if (fl & F_HAS_MOVED) b |= 1u << RE_ECS_BIT_HAS_MOVED;
+    if (fl & F_HAS_VEL) b |= 1u << RE_ECS_BIT_VELOCITY;
+    if (fl & F_HAS_ACC) b |= 1u << RE_ECS_BIT_ACCELERATION;
+    if (fl & F_HAS_ROTATED) b |= 1u << RE_ECS_BIT_HAS_ROTATED;
+    if (fl & F_HAS_ROT) b |= 1u << RE_ECS_BIT_ROTATION;
+    if (fl & F_HAS_ROTVEL) b |= 1u << RE_ECS_BIT_VELOCITY_ROTATION;
+    if (fl & F_HAS_ROTACC) b |= 1u << RE_ECS_BIT_ACCELERATION_ROTATION;
+    if (fl & F_HAS_SCALE) b |= 1u << RE_ECS_BIT_SCALE;
+    if (fl & F_ALWAYS_EXEC) b |= 1u << RE_ECS_BIT_ALWAYS_EXECUTE_LOGIC;
+    return b;
+}
+extern "C" int re_ecs_bitset(re_ctx *c, uint32_t entity_id, uint32_t *bits) {
+    if (!c || !bits) return RE_E_ARG;
+    uint32_t r = 0;
+    if (!c->row_of(entity_id, &r)) return c->fail(RE_E_ARG, "re_ecs_bitset: unknown entity %u", entity_id);
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
+    uint32_t fl = 0;
+    HIPCHK(c, hipMemcpy(&fl, c->d_flags.p + r, 4, hipMemcpyDeviceToHost));     // the device column is the truth (HasMoved / HasRotated are maintained by the tick)
+    *bits = ecs_bits_of_flags(fl);
+    return RE_OK;
+}
+extern "C" int re_ecs_query(re_ctx *c, const int *components, uint32_t n_components, uint32_t *ids, uint32_t capacity, uint32_t *n_out) {
+    if (!c || (n_components && !components) || (capacity && !ids)) return RE_E_ARG;
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_ecs_query: no world uploaded");
+    uint32_t need = 0;
+    for (uint32_t k = 0; k < n_components; k++) {
+        switch (components[k]) {
+            case RE_C_POSITION: case RE_C_TRANSFORMATION: case RE_C_STATIC_AABB: case RE_C_ORIGINAL_AABB: break;     // written for every registered entity
+            case RE_C_ROTATION: need |= F_HAS_ROT; break; case RE_C_SCALE: need |= F_HAS_SCALE; break;
+            case RE_C_VELOCITY: need |= F_HAS_VEL; break; case RE_C_ACCELERATION: need |= F_HAS_ACC; break;
+            case RE_C_ROTATION_VEL: need |= F_HAS_ROTVEL; break; case RE_C_ROTATION_ACC: need |= F_HAS_ROTACC; break;
+            default: return c->fail(RE_E_ARG, "re_ecs_query: component %d was never registered", components[k]);   // the reference panics (get_indexes_for_components unwraps)
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
+    const uint32_t cap = std::max(c->n, 1u);
+    DevBuf<uint32_t> d_out, d_cnt; HIPCHK(c, d_out.alloc(cap, nullptr)); HIPCHK(c, d_cnt.alloc(1, nullptr));
+    HIPCHK(c, hipMemsetAsync(d_cnt.p, 0, 4, c->stream));
+    if (c->n) hipLaunchKernelGGL(k_query_flags, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->n, c->d_flags.p, c->d_id.p, need, d_out.p, cap, d_cnt.p);
+    HIPCHK(c, hipGetLastError());
+    uint32_t cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<uint32_t> found(cnt);
+    if (cnt) HIPCHK(c, hipMemcpy(found.data(), d_out.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    d_out.release(nullptr); d_cnt.release(nullptr);
+    std::sort(found.begin(), found.end());                                     // BTreeSet<EntityId>: ascending
+    for (uint32_t i = 0; i < cnt && i < capacity; i++) ids[i] = found[i];
+    if (n_out) *n_out = cnt;
+    return RE_OK;
+}
+
 extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity, uint32_t *n) {
     if (!c || !c->h_th) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2018,7 +2187,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->reserved2 = 0;
     return RE_OK;
 }
 
@@ -2072,6 +2241,7 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
 
 extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *tick_us) {
     if (!c) return RE_E_ARG;
+    if (!cull_us && !pack_us && !tick_us) { c->timings_on = false; c->timings_pending = false; return RE_OK; }   // all NULL: switch the recording off again
     c->timings_on = true;                                                     // from now on synchronous frames are timed
     if (c->timings_pending) {
         HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));

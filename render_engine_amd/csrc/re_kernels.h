@@ -119,7 +119,11 @@ struct ItemSink {
     uint32_t *item_row, *item_slot; uint32_t item_cap;
     uint32_t nshards, seg_cap;              // instance list = nshards segments of seg_cap slots, one cursor each
     const uint32_t *rows, *rows_gc;         // the row pool and, entry for entry, the row's group class (0xFFFFFFFF: not drawn -- removed or hidden)
+    uint32_t *group_count; uint32_t count_nslots;   // large visible sets: the expansion also counts the instances per (cursor shard, group slot) -- [nshards][count_nslots],
+                                            // through a per-wave LDS histogram flushed once per wave -- so that the pack needs no counting pass (nullptr / 0: off)
 };
+constexpr uint32_t COUNT_SLOTS_MAX = 512;   // group slots the in-scan counting (and k_pack_large) handle; larger tables take the count / scan / scatter kernels
+constexpr uint32_t PACK_LARGE_TILE = 512;   // instances per workgroup iteration of k_pack_large
 struct PackArgs {                           // what k_pack_small needs besides the item list
     uint32_t nslots, out_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
@@ -153,13 +157,26 @@ template <bool K32> __global__ void k_scan_cull_fused(const void *keys, uint32_t
 extern template __global__ void k_scan_cull_fused<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
 extern template __global__ void k_scan_cull_fused<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
 __global__ void k_emit_count(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots, const SpecState *spec);
+__global__ void k_emit_count_sharded(const FrameHeader *hdr, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, uint32_t *group_count, uint32_t nslots, const SpecState *spec);
+// The pack of a large visible set in ONE launch behind the scan (which counted the instances per (shard, group), see ItemSink): every workgroup
+// scans the counts itself, workgroup 0 publishes the InstanceRange table and the frame result, and each workgroup moves tiles of one cursor shard.
+struct PackLargeArgs {
+    const FrameHeader *hdr; FrameHeader *hdr_next; TickHeader *th;
+    const uint32_t *gcount; uint32_t *gfill;            // [nshards][nslots]: this frame's counts (read only), running fill per (shard, group)
+    uint32_t *zero_a, *zero_b; uint32_t zero_words;     // the other frame parity's count / fill arrays: cleared here for the next frame (may be null)
+    uint32_t nslots, out_cap, range_cap, frame;
+    const uint32_t *item_row, *item_slot; uint32_t nshards, seg_cap;
+    const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
+    const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; const SpecState *spec; uint32_t *out_count;
+};
+__global__ void k_pack_large(PackLargeArgs A);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
                              uint32_t *out_count, uint32_t out_cap, uint32_t frame);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap, const SpecState *spec);
-__global__ void k_tick(uint32_t ndyn, const uint32_t *dyn_row, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
-                       const uint32_t *dyn_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
+__global__ void k_tick(uint32_t ndyn, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
+                       const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame);
 // Probe path of the visibility query (opt-in, RE_CFG_PROBE): instead of streaming every section key, enumerate the cells of the two
@@ -215,6 +232,8 @@ __global__ void k_scatter64(uint32_t m, const Pair64 *pairs, uint64_t *dst);
 __global__ void k_flag_ops(uint32_t m, const FlagOp *ops, uint8_t *flags);
 __global__ void k_fold_tight_list(uint32_t m, const uint32_t *slots, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
                                   const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many);
+// ECS::get_indexes_for_components over the presence column: ids of the live rows whose flag word has every bit of need_mask
+__global__ void k_query_flags(uint32_t n, const uint32_t *flags, const uint32_t *row_id, uint32_t need_mask, uint32_t *out_ids, uint32_t cap, uint32_t *count);
 __global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
 
 }  // namespace re

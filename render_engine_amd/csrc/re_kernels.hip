@@ -164,15 +164,19 @@ __device__ __forceinline__ uint32_t shard_item_index(uint32_t t, const ShardMap 
 constexpr uint32_t EMIT_MAX = 4u;                              // sections one lane can hold per reservation (rounds of 64 visible sections per slice)
 
 // row0 / gc0: entry rb of the pool, fetched by the caller ahead of the cursor atomic (k == 0 when first == 0)
+// hist: the wave's LDS histogram of group slots (in-scan counting, see ItemSink), or nullptr: then a counting frame adds straight to
+// K.group_count[shard][slot] (the few instances of shared sections)
 __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t first, uint32_t stride, uint32_t n, uint32_t off, uint32_t lod, uint32_t seg_base, const ItemSink &K,
-                                            bool have0 = false, uint32_t row0 = 0, uint32_t gc0 = 0) {
+                                            uint32_t *hist, uint32_t shard, bool have0 = false, uint32_t row0 = 0, uint32_t gc0 = 0) {
     for (uint32_t k = first; k < n; k += stride) {
         uint32_t t = off + k;
         if (t < K.seg_cap) {
             const uint32_t e = rb + (k % cnt);
             const bool pre = have0 && e == rb;
             const uint32_t row = pre ? row0 : K.rows[e], gc = pre ? gc0 : K.rows_gc[e];
-            K.item_row[seg_base + t] = row; K.item_slot[seg_base + t] = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
+            const uint32_t slot = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
+            K.item_row[seg_base + t] = row; K.item_slot[seg_base + t] = slot;
+            if (K.group_count && slot < K.count_nslots) { if (hist) atomicAdd(&hist[slot], 1u); else atomicAdd(&K.group_count[shard * K.count_nslots + slot], 1u); }
         }
     }
 }
@@ -180,7 +184,7 @@ __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t 
 // Every lane brings up to EMIT_MAX visible sections {row range, count, lod | multiplicity << 8}.  ONE 64-bit
 // atomic per call reserves their instances.
 __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MAX], const uint32_t (&cnt)[EMIT_MAX], const uint32_t (&lodm)[EMIT_MAX],
-                                                    FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint) {
+                                                    FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint, uint32_t *hist = nullptr) {
     uint32_t mine = 0, nsec = 0;
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) { uint32_t n = cnt[j] * ((lodm[j] >> 8) & 3u); mine += n; nsec += n ? 1u : 0u; }
@@ -202,11 +206,11 @@ __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MA
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) {
         const uint32_t m = (lodm[j] >> 8) & 3u, lod = lodm[j] & 7u, n = cnt[j] * m;
-        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K, true, row0[j], gc0[j]);
+        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K, hist, shard, true, row0[j], gc0[j]);
         uint64_t wide = __ballot(n > WIDE);
         while (wide) {                                          // wave-cooperative expansion of crowded sections
             int src = __ffsll((long long)wide) - 1; wide &= wide - 1;
-            expand_rows(__shfl(rb[j], src, 64), __shfl(cnt[j], src, 64), lane_id(), 64u, __shfl(n, src, 64), __shfl(off, src, 64), __shfl(lod, src, 64), seg_base, K);
+            expand_rows(__shfl(rb[j], src, 64), __shfl(cnt[j], src, 64), lane_id(), 64u, __shfl(n, src, 64), __shfl(off, src, 64), __shfl(lod, src, 64), seg_base, K, hist, shard);
         }
         off += n;
     }
@@ -399,6 +403,10 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const LevelBox la = P.box[0][lv0], lb = P.box[1][lv0];      // scalar loads from the kernel-argument segment
                 uint32_t vis_map_acc = 0, vis_vec_acc = 0, cand_acc = 0, nv = 0;
+                // in-scan counting of a large visible set (ItemSink::group_count): this wave's histogram of group slots in dynamic LDS
+                extern __shared__ uint32_t s_dyn[];
+                uint32_t *hist = K.group_count ? s_dyn + wid * K.count_nslots : nullptr;
+                if (hist) for (uint32_t i = lane; i < K.count_nslots; i += 64u) hist[i] = 0u;
                 // stage A -- pure arithmetic on the keys (no memory round trip): the exact box tests and the two cullers on the section's grid
                 // box; the visible sections (index | multiplicity << 30) are compacted in place over the front of the list
 #pragma unroll 1
@@ -448,7 +456,12 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
                             }
                         }
                     }
-                    emit_sections_multi(rbv, cntv, lodv, hdr, K, wave);     // one reservation per slice of 512 visible sections
+                    emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, hist);     // one reservation per slice of 256 visible sections
+                }
+                if (hist && nv) {                                           // flush: one atomic per non-empty group slot and wave, into the counts of this wave's cursor shard
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    uint32_t *gc = K.group_count + (K.nshards > 1u ? (wave & (CURSOR_SHARDS - 1u)) : 0u) * K.count_nslots;
+                    for (uint32_t i = lane; i < K.count_nslots; i += 64u) { const uint32_t v = hist[i]; if (v) atomicAdd(&gc[i], v); }
                 }
 #ifdef RE_EXP_STAMPS
                 tl_emit = wall_clock64();
@@ -794,6 +807,163 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameHeader *hdr, co
     }
 }
 
+// Fallback counting pass for k_pack_large when the scan did not count (the host predicted a small visible set, or the probe path ran):
+// per (cursor shard, group slot), LDS histogram per workgroup over one shard's segment.
+__global__ __launch_bounds__(256) void k_emit_count_sharded(const FrameHeader *hdr, const uint32_t *__restrict__ item_slot, uint32_t nshards, uint32_t seg_cap,
+                                                            uint32_t *__restrict__ group_count, uint32_t nslots, const SpecState *spec) {
+    extern __shared__ uint32_t s_hist[];
+    if (spec->stale) return;
+    const uint32_t shard = blockIdx.x % nshards, part = blockIdx.x / nshards, parts = gridDim.x / nshards;
+    uint32_t n = (uint32_t)(hdr->cursors[shard * 8u] >> 32); if (n > seg_cap) n = seg_cap;
+    for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    for (uint32_t t = part * blockDim.x + threadIdx.x; t < n; t += parts * blockDim.x) {
+        const uint32_t slot = item_slot[shard * seg_cap + t];
+        if (slot < nslots) atomicAdd(&s_hist[slot], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) { const uint32_t v = s_hist[i]; if (v) atomicAdd(&group_count[shard * nslots + i], v); }
+}
+
+// The pack of a large visible set (specify_type_ids! callback + MappedBuffer::write_data_serialized + the InstanceRange table:
+// prelude/layout_update_macros.rs:15-21, render_components/mapped_buffer.rs:166-189, flows/render_flow.rs:939-992) in ONE launch.
+// The instance counts per (cursor shard, group slot) are there already (counted by the scan, or by k_emit_count_sharded), so
+//   * every workgroup scans them itself (<= 8 x 512 words from L2): group begins, and where its own shard starts inside every group;
+//   * workgroup 0 writes the InstanceRange table + the frame result to the host (publish_to_host) and clears the next frame's headers;
+//   * every workgroup moves tiles of PACK_LARGE_TILE instances of ONE shard: rank inside the tile with LDS atomics, ONE global atomic per
+//     (tile, non-empty group) on the shard's own fill counter (contention: tiles of one shard only), then id + 64-byte matrix with 4 lanes per
+//     instance; the matrix loads are issued before the atomics return, so the tile costs two dependent round trips (list entry -> matrix).
+__global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
+    constexpr uint32_t NT = 256, TILE = PACK_LARGE_TILE, PER = TILE / NT, PASSES = TILE / 64u;
+    __shared__ uint32_t s_gbase[COUNT_SLOTS_MAX];             // where this workgroup's shard starts inside each group (absolute instance index)
+    __shared__ uint32_t s_hist[COUNT_SLOTS_MAX], s_tbase[COUNT_SLOTS_MAX];
+    __shared__ uint32_t s_pos[TILE], s_row[TILE];
+    __shared__ uint32_t s_wsum[4], s_wcnt[4], s_whash[4], s_carry, s_gcarry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, bid = blockIdx.x, nslots = A.nslots, nsh = A.nshards;
+    if (A.spec->stale) {                                    // cancelled frame (SpecState)
+        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; publish_to_host(&A.hres->done_frame, A.frame); }
+        return;
+    }
+    // ---- the cursors: instances per shard, tiles per shard
+    uint32_t n[CURSOR_SHARDS], raw_items = 0, raw_sec = 0, ntiles = 0, tile0[CURSOR_SHARDS + 1];
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+        const unsigned long long cur = k < nsh ? A.hdr->cursors[k * 8] : 0ull;
+        const uint32_t v = (uint32_t)(cur >> 32);
+        raw_sec += (uint32_t)cur; raw_items += v;
+        n[k] = v < A.seg_cap ? v : A.seg_cap; tile0[k] = ntiles; ntiles += (n[k] + TILE - 1u) / TILE;
+    }
+    tile0[CURSOR_SHARDS] = ntiles;
+    if (bid != 0 && bid >= ntiles) return;
+    if (tid == 0) { s_carry = 0; s_gcarry = 0; }
+    __syncthreads();
+    // ---- scan of the group counts (every workgroup): group begins; workgroup 0 also emits the InstanceRange table
+    uint32_t my_hash = 0;
+    for (uint32_t base = 0; base < nslots; base += NT) {
+        const uint32_t i = base + tid;
+        uint32_t v = 0;
+        if (i < nslots) for (uint32_t k = 0; k < nsh; k++) v += A.gcount[k * nslots + i];
+        const uint32_t nz = v ? 1u : 0u;
+        const uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
+        if (lane == 63) { s_wsum[wid] = incl; s_wcnt[wid] = incn; }
+        __syncthreads();
+        uint32_t woff = 0, wcn = 0;
+        for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
+        const uint32_t begin = s_carry + woff + incl - v, gidx = s_gcarry + wcn + incn - nz;
+        if (i < nslots) {
+            s_gbase[i] = begin;
+            if (v && bid == 0 && gidx < A.range_cap) {
+                const uint32_t gc = i >> 3, lod = i & 7u;
+                InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
+                A.ranges[gidx] = r;
+                const uint32_t w0 = gidx * (uint32_t)(sizeof(InstanceRange) / 4u);
+                my_hash ^= table_word_hash(r.model_index, w0) ^ table_word_hash(r.render_system, w0 + 1u) ^ table_word_hash(r.sortable, w0 + 2u) ^ table_word_hash(r.begin, w0 + 3u) ^ table_word_hash(r.count, w0 + 4u);
+            }
+        }
+        __syncthreads();
+        if (tid == NT - 1) { s_carry = begin + v; s_gcarry = gidx + nz; }
+        __syncthreads();
+    }
+    if (bid == 0) {
+        // every wave's table stores have left the wave before the barrier in front of the publication (publish_to_host)
+        for (int d = 32; d >= 1; d >>= 1) my_hash ^= __shfl_xor(my_hash, d, 64);
+        if (lane == 0) s_whash[wid] = my_hash;
+        wait_own_stores();
+        __syncthreads();
+        if (wid == 0) {
+            const FrameCounts fc = load_frame_counts(A.hdr);
+            if (lane == 0) {
+                const uint32_t table_hash = s_whash[0] ^ s_whash[1] ^ s_whash[2] ^ s_whash[3];
+                HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;
+                r.n_groups = s_gcarry < A.range_cap ? s_gcarry : A.range_cap; r.total = s_carry; r.overflow = 0; r.n_entries = raw_sec; r.n_items = raw_items;
+                r.table_hash = result_seal(table_hash | 1u, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items);
+                *A.hres = r;
+                if (A.out_count) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
+                publish_to_host(&A.hres->done_frame, A.frame);
+            }
+        }
+        for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(A.hdr_next)[i] = 0u;      // next frame's cursors / counters
+        for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(A.th)[i] = 0u;
+        for (uint32_t i = tid; i < A.zero_words; i += NT) { if (A.zero_a) A.zero_a[i] = 0u; if (A.zero_b) A.zero_b[i] = 0u; }   // the other parity's counts / fills: nobody reads or adds to them during this launch
+    }
+    // ---- tiles
+    for (uint32_t tile = bid; tile < ntiles; tile += gridDim.x) {                // workgroup-uniform
+        uint32_t shard = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < CURSOR_SHARDS; k++) if (tile >= tile0[k]) shard = k;
+        uint32_t n_sh = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) if (k == shard) n_sh = n[k];
+        const uint32_t j0 = (tile - tile0[shard]) * TILE;
+        // round trip 1: the tile's list entries
+        uint32_t slot[PER], row[PER];
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            const uint32_t j = j0 + q * NT + tid;
+            slot[q] = 0xFFFFFFFFu; row[q] = 0;
+            if (j < n_sh) { const uint32_t ii = shard * A.seg_cap + j; slot[q] = A.item_slot[ii]; row[q] = A.item_row[ii]; }
+        }
+        __syncthreads();                                                        // (the previous tile is done with the LDS arrays)
+        for (uint32_t i = tid; i < nslots; i += NT) s_hist[i] = 0;
+        __syncthreads();
+        uint32_t rank[PER];
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            if (slot[q] >= nslots) slot[q] = 0xFFFFFFFFu;
+            rank[q] = slot[q] != 0xFFFFFFFFu ? atomicAdd(&s_hist[slot[q]], 1u) : 0u;
+            s_row[q * NT + tid] = row[q];
+        }
+        __syncthreads();
+        // round trip 2, three kinds of requests in flight together: the ids, the matrices (4 lanes per instance), the shard's fill counters
+        uint32_t ids[PER];
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) ids[q] = slot[q] != 0xFFFFFFFFu ? A.row_id[row[q]] : 0u;
+        float4 mat[PASSES];
+        const uint32_t part = tid & 3u, li = tid >> 2;
+#pragma unroll
+        for (uint32_t ps = 0; ps < PASSES; ps++) mat[ps] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
+        for (uint32_t i = tid; i < nslots; i += NT) {
+            const uint32_t cnt = s_hist[i];
+            uint32_t before = 0;                                               // instances of this group in the shards in front of this one
+            for (uint32_t k = 0; k < shard; k++) before += A.gcount[k * nslots + i];
+            s_tbase[i] = s_gbase[i] + before + (cnt ? atomicAdd(&A.gfill[shard * nslots + i], cnt) : 0u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            const uint32_t pos = slot[q] != 0xFFFFFFFFu ? s_tbase[slot[q]] + rank[q] : 0xFFFFFFFFu;
+            s_pos[q * NT + tid] = pos;
+            if (pos < A.out_cap) A.out_ids[pos] = ids[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t ps = 0; ps < PASSES; ps++) {
+            const uint32_t pp = s_pos[ps * 64u + li];
+            if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
+        }
+    }
+}
+
 // K2 (small visible sets, the common case at the reference's draw distance: ~10^3 instances): the whole pack in ONE
 // launch of a few workgroups with no communication between them.  == specify_type_ids! callback +
 // MappedBuffer::write_data_serialized + the InstanceRange table (prelude/layout_update_macros.rs:15-21,
@@ -1013,52 +1183,12 @@ __device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
     float n = norm3(v[0], v[1], v[2]); o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
 }
 
-__device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
-                                            float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc, RowArrays R, const uint32_t *__restrict__ dyn_cell,
-                                            const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
-                                            const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb, const FrameParams &P, float dt, uint32_t tick_all,
-                                            uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                            SpecState *spec, SpecState *h_spec, uint32_t tick_frame);
-
-__global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
-                                              float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
-                                              RowArrays R, const uint32_t *__restrict__ dyn_cell,
-                                              const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
-                                              const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
-                                              const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
-    // An EARLIER tick left the tree stale: this frame is replayed by the host.  The flag a workgroup of THIS tick raises when it finds a
-    // mover must not stop the workgroups of the same tick that start later (they would skip their entities for good): the frame travels
-    // with the flag in one 64-bit word.
-    {
-        const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(spec);
-        if ((uint32_t)w != 0u && (uint32_t)(w >> 32) != tick_frame) return;     // tick_frame: the frame this tick was issued for (a cancelled frame never wrote its parameters, so Pp->frame would be the stale one's)
-    }
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    // No completion ticket: the counters stay in device memory (the host copies the 16 bytes when it synchronises), and a workgroup
-    // that finds a mover or an entity leaving the world raises `stale` itself -- idempotent stores, any number of workgroups may do it.
-    tick_entity(j, ndyn, dyn_row, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, dyn_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, *Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec, tick_frame);
-}
-
-// The tick's counters for the host: a one-wave kernel behind k_tick copies them into mapped host memory and then publishes the tick's
-// sequence number there; the host polls that word instead of synchronising the stream and copying (and does not depend on what a
-// stream synchronise considers finished).
-__global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t a = th->n_changed, b = th->n_rebucket, c2 = th->n_oob;
-    h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
-    publish_to_host(&h_th->ticket, seq);
-}
-
-// update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + update_entity_in_tree (:325-351) for one entity whose
-// Position / Rotation / Scale changed: new TransformationMatrix and StaticAABB, out-of-bounds handling, and -- only when the
-// spatial-hash section differs (entity_exists_in_section, bounding_box_tree_v2.rs:765-782) -- an entry in the re-bucket list.
-__device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, uint32_t nfl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
-                                                     RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells,
-                                                     uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                                     SpecState *spec = nullptr, SpecState *h_spec = nullptr, uint32_t frame = 0) {
-    // update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262)
+// update_aabb_after_kinematic_change (entity_change_helpers.rs:217-262) + the decision of update_entity_in_tree (:325-351) for one entity whose
+// Position / Rotation / Scale changed: new TransformationMatrix and StaticAABB; returns 0 when the entity stays in its spatial-hash section
+// (entity_exists_in_section, bounding_box_tree_v2.rs:765-782), 1 when it changes section (re-bucket list), 2 when it leaves the world without
+// OutOfBoundsLogic (ecs.remove_entity, :347; the tree keeps the stale entry -- the caller marks the row dead).  No atomics here.
+__device__ __forceinline__ uint32_t place_core(uint32_t r, uint32_t fl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
+                                                RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells, uint32_t outline, uint32_t atomic) {
     Aabb orig = R.orig[r], a;
     float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
     if (translation_only) {
@@ -1077,13 +1207,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
     // update_entity_in_tree -> add_entity (:325-351): same section => nothing else happens
     Aabb bv = a;
     bool oob = normalize_aabb(&bv, (float)outline);
-    if (oob && !(fl & F_OOB_LOGIC)) {
-        uint32_t slot = atomicAdd(&th->n_oob, 1u);
-        if (slot < list_cap) oob_rows[slot] = r;
-        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; post_to_host64(reinterpret_cast<unsigned long long *>(h_spec), w); }   // {stale = 1, stale_frame = frame} in one store     // the host must retire the row before any later frame runs
-        R.flags[r] = nfl | F_DEAD; R.gclass[r] = 0xFFFFFFFFu;                                              // ecs.remove_entity (:347); the tree keeps the stale entry
-        return;
-    }
+    if (oob && !(fl & F_OOB_LOGIC)) { R.gclass[r] = 0xFFFFFFFFu; return 2u; }
     uint64_t keys[8];
     int nk = assign_sections(bv, atomic, keys);
     bool same;
@@ -1097,25 +1221,56 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
             if (k < nk) same = c >= 0 && cell_key[c] == keys[k]; else same = c < 0;
         }
     }
-    if (!same) {
+    return same ? 0u : 1u;
+}
+// the same for one entity of a change batch (k_apply_rows): per-lane list reservations (a batch is small)
+__device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, uint32_t nfl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
+                                                     RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells,
+                                                     uint32_t outline, uint32_t atomic, TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap) {
+    const uint32_t status = place_core(r, fl, rc, pos, rot, translation_only, R, cell_key, sh_cells, outline, atomic);
+    if (status == 2u) {
+        uint32_t slot = atomicAdd(&th->n_oob, 1u);
+        if (slot < list_cap) oob_rows[slot] = r;
+        R.flags[r] = nfl | F_DEAD;
+    } else if (status == 1u) {
         uint32_t slot = atomicAdd(&th->n_rebucket, 1u);
         if (slot < list_cap) mover_rows[slot] = r | (translation_only ? 0x80000000u : 0u);   // bit 31: translation-only mover
-        if (spec) { const unsigned long long w = 1ull | ((unsigned long long)frame << 32); *reinterpret_cast<volatile unsigned long long *>(spec) = w; post_to_host64(reinterpret_cast<unsigned long long *>(h_spec), w); }   // {stale = 1, stale_frame = frame} in one store     // the host must patch the tree before any later frame runs
     }
 }
 
-__device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uint32_t *__restrict__ dyn_row, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
-                                            float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
-                                            RowArrays R, const uint32_t *__restrict__ dyn_cell,
-                                            const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
-                                            const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
-                                            const FrameParams &P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
-                                            TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
-    if (j >= ndyn) return;
-    const uint32_t r = dyn_row[j], rc = dyn_cell[j];           // both coalesced; the flag word and the section stamp are then fetched together
+// K3.  The rows of the dynamic entities (Velocity or VelocityRotation) are the FIRST ndyn rows of every per-entity column (the upload
+// sorts them to the front), so lane j works on row j: flags, section slot, Position, Rotation, Scale, OriginalAABB and the velocities are
+// read -- and TransformationMatrix, StaticAABB, Rotation written -- as contiguous streams (80 B read + 104 B written per
+// ticking entity); the only gathers are the section stamp (the visibility gate) and, for ticking entities, the key of their section.
+// Counters: one atomic per wave (ballot + mbcnt), as in the cull kernel.
+__global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+                                              float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
+                                              RowArrays R, const uint32_t *__restrict__ row_cell,
+                                              const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                              const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
+                                              const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
+                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
+                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
+    // An EARLIER tick left the tree stale: this frame is replayed by the host.  The flag a workgroup of THIS tick raises when it finds a
+    // mover must not stop the workgroups of the same tick that start later (they would skip their entities for good): the frame travels
+    // with the flag in one 64-bit word.
+    {
+        const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(spec);
+        if ((uint32_t)w != 0u && (uint32_t)(w >> 32) != tick_frame) return;     // tick_frame: the frame this tick was issued for (a cancelled frame never wrote its parameters, so Pp->frame would be the stale one's)
+    }
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = j;
+    const bool in = j < ndyn;
+    const FrameParams &P = *Pp;
+    // ---- round trip 1: everything indexed by the row, coalesced
+    const uint32_t fl = in ? R.flags[r] : F_DEAD, rc = in ? row_cell[r] : ROW_CELL_NONE;
+    float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f };
+    if (in) {
+        pos[0] = R.pos[r * 3 + 0]; pos[1] = R.pos[r * 3 + 1]; pos[2] = R.pos[r * 3 + 2];
+        const float4 q = reinterpret_cast<const float4 *>(R.rot)[r]; rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
+    }
+    // ---- the visibility gate (logic_flow.rs:216-223, 308-358): one gathered word per entity, none with RE_TICK_ALL_DYNAMIC
     const bool unique_cell = rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED);
-    const uint32_t stamp = unique_cell ? cell_stamp[rc] : 0u;    // requested together with the flag word: one round trip decides most entities
-    uint32_t fl = R.flags[r];
+    const uint32_t stamp = (unique_cell && !tick_all) ? cell_stamp[rc] : 0u;
     // reset_has_changed_component (logic_flow.rs:776-801)
     uint32_t nfl = fl & ~(F_HAS_MOVED | F_HAS_ROTATED);
     bool run = false;
@@ -1123,72 +1278,102 @@ __device__ __forceinline__ void tick_entity(uint32_t j, uint32_t ndyn, const uin
     else if (tick_all) run = rc != ROW_CELL_NONE;
     else if (rc == ROW_CELL_NONE) run = false;
     else if (!(rc & ROW_CELL_SHARED)) {
-        bool vis = (stamp >> 2) == P.frame;
+        const bool vis = (stamp >> 2) == P.frame;
         // visible loop: local (non-static) entities of active visible sections; always-execute entities
         // only when their section is NOT in visible_sections_map (find_always_execute_entities :803-836)
         run = (!(fl & F_STATIC) && vis) || ((fl & F_ALWAYS_EXEC) && !vis);
     } else {
-        uint32_t s = rc & ~ROW_CELL_SHARED;
+        const uint32_t s = rc & ~ROW_CELL_SHARED;
         bool anyvis = false, act = false;
         for (int k = 0; k < 8; k++) {
-            int32_t c = sh_cells[s * 8 + k];
+            const int32_t c = sh_cells[s * 8 + k];
             if (c >= 0 && (cell_stamp[c] >> 2) == P.frame) { anyvis = true; if (!(cell_flags[c] & CF_STATIC_SECTION)) act = true; }
         }
         bool inview = false;
         if (act && !(fl & F_STATIC)) {
-            Aabb sa = sh_aabb[s];
+            const Aabb sa = sh_aabb[s];
             inview = logic_aabb_in_view(P.lookahead, P.cam[0], P.cam[1], P.cam[2], sa) || frustum_aabb_visible(P.planes, sa);   // logic_flow.rs:338-339
         }
         run = (!(fl & F_STATIC) && act && inview) || ((fl & F_ALWAYS_EXEC) && !anyvis);
     }
-    if (!run) { if (nfl != fl) R.flags[r] = nfl; return; }
-
+    // ---- apply_kinematics (logic_flow.rs:366-448)
     bool pos_set = false, rot_set = false;
-    float pos[3] = { R.pos[r * 3 + 0], R.pos[r * 3 + 1], R.pos[r * 3 + 2] };
-    float rot[4] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2], R.rot[r * 4 + 3] };
-    if (fl & F_HAS_VEL) {
-        float v[3] = { dyn_vel[j * 3 + 0], dyn_vel[j * 3 + 1], dyn_vel[j * 3 + 2] };
-        if (fl & F_HAS_ACC) {
-            float a[3] = { dyn_acc[j * 3 + 0], dyn_acc[j * 3 + 1], dyn_acc[j * 3 + 2] };
-            if (norm3(a[0], a[1], a[2]) != 0.0f) {                            // :384  velocity += acceleration * dt
-                dyn_vel[j * 3 + 0] = v[0] + a[0] * dt; dyn_vel[j * 3 + 1] = v[1] + a[1] * dt; dyn_vel[j * 3 + 2] = v[2] + a[2] * dt;
+    if (run) {
+        if (fl & F_HAS_VEL) {
+            const float v[3] = { dyn_vel[j * 3 + 0], dyn_vel[j * 3 + 1], dyn_vel[j * 3 + 2] };
+            if (fl & F_HAS_ACC) {
+                const float a[3] = { dyn_acc[j * 3 + 0], dyn_acc[j * 3 + 1], dyn_acc[j * 3 + 2] };
+                if (norm3(a[0], a[1], a[2]) != 0.0f) {                            // :384  velocity += acceleration * dt
+                    dyn_vel[j * 3 + 0] = v[0] + a[0] * dt; dyn_vel[j * 3 + 1] = v[1] + a[1] * dt; dyn_vel[j * 3 + 2] = v[2] + a[2] * dt;
+                }
+            }
+            if (norm3(v[0], v[1], v[2]) != 0.0f) {                                // :394  position += OLD velocity * dt (change requests are deferred)
+                pos[0] = pos[0] + v[0] * dt; pos[1] = pos[1] + v[1] * dt; pos[2] = pos[2] + v[2] * dt;
+                pos_set = true;
             }
         }
-        if (norm3(v[0], v[1], v[2]) != 0.0f) {                                // :394  position += OLD velocity * dt (change requests are deferred)
-            pos[0] = pos[0] + v[0] * dt; pos[1] = pos[1] + v[1] * dt; pos[2] = pos[2] + v[2] * dt;
-            pos_set = true;
-        }
-    }
-    if (fl & F_HAS_ROTVEL) {
-        float w[4] = { dyn_rotvel[j * 4 + 0], dyn_rotvel[j * 4 + 1], dyn_rotvel[j * 4 + 2], dyn_rotvel[j * 4 + 3] };
-        if (fl & F_HAS_ROTACC) {
-            float a[4] = { dyn_rotacc[j * 4 + 0], dyn_rotacc[j * 4 + 1], dyn_rotacc[j * 4 + 2], dyn_rotacc[j * 4 + 3] };
-            if (a[3] != 0.0f) {                                               // :418
-                float sc[3] = { a[0] * dt, a[1] * dt, a[2] * dt }, nrm[3], sum[3], out[3];
+        if (fl & F_HAS_ROTVEL) {
+            const float4 wq = reinterpret_cast<const float4 *>(dyn_rotvel)[j];
+            const float w[4] = { wq.x, wq.y, wq.z, wq.w };
+            if (fl & F_HAS_ROTACC) {
+                const float4 aq = reinterpret_cast<const float4 *>(dyn_rotacc)[j];
+                const float a[4] = { aq.x, aq.y, aq.z, aq.w };
+                if (a[3] != 0.0f) {                                               // :418
+                    float sc[3] = { a[0] * dt, a[1] * dt, a[2] * dt }, nrm[3], sum[3], out[3];
+                    normalize3(sc, nrm);
+                    sum[0] = w[0] + nrm[0]; sum[1] = w[1] + nrm[1]; sum[2] = w[2] + nrm[2];
+                    normalize3(sum, out);
+                    reinterpret_cast<float4 *>(dyn_rotvel)[j] = make_float4(out[0], out[1], out[2], w[3] + a[3] * dt);
+                }
+            }
+            if (w[3] != 0.0f) {                                                   // :429  rotation += OLD rotation velocity * dt
+                float sc[3] = { w[0] * dt, w[1] * dt, w[2] * dt }, nrm[3], sum[3], out[3];
                 normalize3(sc, nrm);
-                sum[0] = w[0] + nrm[0]; sum[1] = w[1] + nrm[1]; sum[2] = w[2] + nrm[2];
+                sum[0] = rot[0] + nrm[0]; sum[1] = rot[1] + nrm[1]; sum[2] = rot[2] + nrm[2];
                 normalize3(sum, out);
-                dyn_rotvel[j * 4 + 0] = out[0]; dyn_rotvel[j * 4 + 1] = out[1]; dyn_rotvel[j * 4 + 2] = out[2]; dyn_rotvel[j * 4 + 3] = w[3] + a[3] * dt;
+                rot[0] = out[0]; rot[1] = out[1]; rot[2] = out[2]; rot[3] = rot[3] + w[3] * dt;
+                rot_set = true;
             }
-        }
-        if (w[3] != 0.0f) {                                                   // :429  rotation += OLD rotation velocity * dt
-            float sc[3] = { w[0] * dt, w[1] * dt, w[2] * dt }, nrm[3], sum[3], out[3];
-            normalize3(sc, nrm);
-            sum[0] = rot[0] + nrm[0]; sum[1] = rot[1] + nrm[1]; sum[2] = rot[2] + nrm[2];
-            normalize3(sum, out);
-            rot[0] = out[0]; rot[1] = out[1]; rot[2] = out[2]; rot[3] = rot[3] + w[3] * dt;
-            rot_set = true;
         }
     }
     if (pos_set) nfl |= F_HAS_MOVED;
     if (rot_set) nfl |= F_HAS_ROTATED;
-    if (nfl != fl) R.flags[r] = nfl;
-    if (!pos_set && !rot_set) return;
-    atomicAdd(&th->n_changed, 1u);
-    if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
-    if (rot_set) { R.rot[r * 4 + 0] = rot[0]; R.rot[r * 4 + 1] = rot[1]; R.rot[r * 4 + 2] = rot[2]; R.rot[r * 4 + 3] = rot[3]; }
+    const bool changed = pos_set || rot_set;
+    uint32_t status = 0;                                                          // 1: the entity changes section (re-bucket list), 2: it leaves the world
+    if (changed) {
+        if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
+        if (rot_set) reinterpret_cast<float4 *>(R.rot)[r] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+        status = place_core(r, fl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic);
+        if (status == 2u) nfl |= F_DEAD;
+    }
+    if (in && nfl != fl) R.flags[r] = nfl;
+    // ---- counters and lists: one atomic per wave and counter
+    const uint64_t mc = __ballot(changed), mr = __ballot(status == 1u), mo = __ballot(status == 2u);
+    if (mc) {
+        const uint32_t lane = lane_id();
+        uint32_t base_r = 0, base_o = 0;
+        if (lane == 0) {
+            atomicAdd(&th->n_changed, (uint32_t)__popcll(mc));
+            if (mr) base_r = atomicAdd(&th->n_rebucket, (uint32_t)__popcll(mr));
+            if (mo) base_o = atomicAdd(&th->n_oob, (uint32_t)__popcll(mo));
+            if (mr | mo) {                                                        // {stale = 1, stale_frame = frame} in one store: the host must patch the tree / retire the rows before any later frame runs
+                const unsigned long long w = 1ull | ((unsigned long long)tick_frame << 32);
+                *reinterpret_cast<volatile unsigned long long *>(spec) = w; post_to_host64(reinterpret_cast<unsigned long long *>(h_spec), w);
+            }
+        }
+        if (mr) { base_r = __shfl(base_r, 0, 64); if (status == 1u) { const uint32_t slot = base_r + mbcnt(mr); if (slot < list_cap) mover_rows[slot] = r | ((pos_set && !rot_set) ? 0x80000000u : 0u); } }   // bit 31: translation-only mover
+        if (mo) { base_o = __shfl(base_o, 0, 64); if (status == 2u) { const uint32_t slot = base_o + mbcnt(mo); if (slot < list_cap) oob_rows[slot] = r; } }
+    }
+}
 
-    place_changed_entity(r, fl, nfl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap, spec, h_spec, tick_frame);
+// The tick's counters for the host: a one-wave kernel behind k_tick copies them into mapped host memory and then publishes the tick's
+// sequence number there; the host polls that word instead of synchronising the stream and copying (and does not depend on what a
+// stream synchronise considers finished).
+__global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t a = th->n_changed, b = th->n_rebucket, c2 = th->n_oob;
+    h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
+    publish_to_host(&h_th->ticket, seq);
 }
 
 // section decision (add_entity with add_if_out_bounds = true: the box is clamped) for a list of rows, from their current StaticAABB;
@@ -1301,6 +1486,20 @@ __global__ __launch_bounds__(256) void k_fold_tight_list(uint32_t m, const uint3
         for (uint32_t k = 0; k < n; k++) { Aabb e = ent_aabb[rows[b + k]]; u = (k == 0) ? e : combine_aabb(u, e); }
     }
     cell_tight[c] = u;
+}
+
+// ECS::get_indexes_for_components (objects/ecs.rs:238-285) on the presence column: wave-ballot compaction of the matching live rows' ids
+__global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ row_id, uint32_t need_mask,
+                                                     uint32_t *__restrict__ out_ids, uint32_t cap, uint32_t *count) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t fl = r < n ? flags[r] : F_DEAD;
+    const bool hit = !(fl & F_DEAD) && (fl & need_mask) == need_mask;
+    const uint64_t m = __ballot(hit);
+    if (!m) return;
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = __shfl(base, 0, 64);
+    if (hit) { const uint32_t slot = base + mbcnt(m); if (slot < cap) out_ids[slot] = row_id[r]; }
 }
 
 // gathers the visible sections of the last cull for re_debug_get_visible_sections

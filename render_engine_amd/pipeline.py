@@ -210,6 +210,15 @@ class Pipeline:
         self._check(self._L.re_tick(self._h, np.float32(delta_time), flags, C.byref(tr)), "re_tick")
         return None if asynchronous else dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
 
+    def run_frames(self, camera, n, delta_time=0.016, cull_flags=0, tick_flags=0):
+        """n frames of cull_and_pack + tick driven from native code (re_run_frames): per-frame wall times in microseconds, and the last
+        frame's results when the calls were synchronous"""
+        cam = camera if isinstance(camera, _capi.CameraC) else camera.to_c()
+        us = np.zeros(max(n, 1), np.float32); vis = _capi.Visible(); tr = _capi.TickResult()
+        self._check(self._L.re_run_frames(self._h, C.byref(cam), np.float32(delta_time), cull_flags, tick_flags, n, us.ctypes.data, C.byref(vis), C.byref(tr)), "re_run_frames")
+        sync = not (cull_flags & _capi.CULL_ASYNC)
+        return us[:n], (self._visible_to_py(vis, copy=False) if sync and n else None), dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
+
     def apply_changes(self, changes):
         """helper_things/entity_change_helpers.rs:32-189 for the change requests of user logic.
         `changes`: structured array CHANGE_DT (kind, entity_id, component, reserved, value[4])."""
@@ -249,6 +258,28 @@ class Pipeline:
         self._check(self._L.re_read_component(self._h, entity_id, component, v.ctypes.data), "re_read_component")
         return v
 
+    def has_component(self, entity_id, component):
+        """ECS::check_component_written (objects/ecs.rs:348-367)"""
+        bit = {_capi.C_POSITION: "POSITION", _capi.C_ROTATION: "ROTATION", _capi.C_SCALE: "SCALE", _capi.C_VELOCITY: "VELOCITY", _capi.C_ACCELERATION: "ACCELERATION",
+               _capi.C_ROTATION_VEL: "VELOCITY_ROTATION", _capi.C_ROTATION_ACC: "ACCELERATION_ROTATION", _capi.C_TRANSFORMATION: "TRANSFORMATION",
+               _capi.C_STATIC_AABB: "STATIC_AABB", _capi.C_ORIGINAL_AABB: "ORIGINAL_AABB"}[component]
+        return bool(self.ecs_bitset(entity_id) >> _capi.ECS_BIT[bit] & 1)
+
+    def ecs_bitset(self, entity_id):
+        """ecs.bitsets[entity] (objects/ecs.rs:61-72) in the reference's registration order"""
+        b = C.c_uint32()
+        self._check(self._L.re_ecs_bitset(self._h, entity_id, C.byref(b)), "re_ecs_bitset")
+        return b.value
+
+    def get_indexes_for_components(self, components):
+        """ECS::get_indexes_for_components (objects/ecs.rs:238-285): ascending entity ids carrying all the components"""
+        comps = (C.c_int * max(len(components), 1))(*components)
+        n = C.c_uint32()
+        self._check(self._L.re_ecs_query(self._h, comps, len(components), None, 0, C.byref(n)), "re_ecs_query")
+        ids = np.zeros(max(n.value, 1), np.uint32)
+        self._check(self._L.re_ecs_query(self._h, comps, len(components), ids.ctypes.data, n.value, C.byref(n)), "re_ecs_query")
+        return ids[:n.value]
+
     def out_of_bounds(self, cap=4096):
         ids = np.zeros(cap, np.uint32); n = C.c_uint32()
         self._check(self._L.re_get_out_of_bounds(self._h, ids.ctypes.data, cap, C.byref(n)), "re_get_out_of_bounds")
@@ -276,6 +307,9 @@ class Pipeline:
         a, b, c = C.c_float(), C.c_float(), C.c_float()
         self._check(self._L.re_get_timings(self._h, C.byref(a), C.byref(b), C.byref(c)), "re_get_timings")
         return dict(cull=a.value, pack=b.value, tick=c.value)
+
+    def timings_off(self):
+        self._check(self._L.re_get_timings(self._h, None, None, None), "re_get_timings")
 
     def timing_begin(self, max_launches, every=1):
         self._check(self._L.re_timing_begin(self._h, max_launches, every), "re_timing_begin")

@@ -34,8 +34,18 @@ def lattice_world(cells_per_axis=216, first_cell=20, atomic=64, index_range=None
     return box_world((cells_per_axis,) * 3, first_cell, atomic, index_range, spinner_every, n_models, straddler_fraction, mover_every)
 
 
+def sub_box_indices(dims, sub_first, sub_dims):
+    """entity indices (== ids) of the sub-box [sub_first, sub_first + sub_dims) of a box_world(dims), in ascending order; sub_first
+    is relative to the box's first section (x, z, y order like dims)"""
+    nx, nz, ny = dims
+    ax = np.arange(sub_first[0], sub_first[0] + sub_dims[0], dtype=np.uint64)
+    az = np.arange(sub_first[1], sub_first[1] + sub_dims[1], dtype=np.uint64)
+    ay = np.arange(sub_first[2], sub_first[2] + sub_dims[2], dtype=np.uint64)
+    return ((ax[:, None, None] * np.uint64(nz) + az[None, :, None]) * np.uint64(ny) + ay[None, None, :]).reshape(-1)
+
+
 def box_world(dims, first_cell=20, atomic=64, index_range=None, spinner_every=0, n_models=8,
-              straddler_fraction=0.0, mover_every=0):
+              straddler_fraction=0.0, mover_every=0, indices=None):
     """Config 2/3: one entity per level-0 section of a cubic lattice (uniform spatial-hash fill).
 
     dims = (nx, nz, ny) sections per axis.  Entity i sits in section (cx,cz,cy) = first_cell +
@@ -50,7 +60,7 @@ def box_world(dims, first_cell=20, atomic=64, index_range=None, spinner_every=0,
     nx, nz, ny = dims
     n_total = nx * nz * ny
     lo, hi = (0, n_total) if index_range is None else index_range
-    idx = np.arange(lo, hi, dtype=np.uint64)
+    idx = np.arange(lo, hi, dtype=np.uint64) if indices is None else np.asarray(indices, np.uint64)   # `indices`: any subset of the box (ids stay those of the full world)
     n = len(idx)
     cx = (idx // np.uint64(nz * ny)).astype(np.int64) + first_cell
     cz = ((idx // np.uint64(ny)) % np.uint64(nz)).astype(np.int64) + first_cell
@@ -89,6 +99,8 @@ def box_world(dims, first_cell=20, atomic=64, index_range=None, spinner_every=0,
         for k in range(3):
             e["vel"][:, k] = np.where(mv, np.float32(60.0) * (uniform(SEED_MIX, idx, 1 + k) - np.float32(0.5)), 0).astype(np.float32)
     ext = h * scale[:, 0]                                        # world-space half extent
+    if spinner_every:                                            # the 2-corner AABB of a box rotating about +y reaches h * sqrt(2) in x and z: keep it inside the section at every angle
+        ext = np.where(spin, ext * np.float32(1.4143), ext).astype(np.float32)
     span = (np.float32(atomic) - np.float32(2.0) * ext) * np.float32(0.999)
     span = np.maximum(span, np.float32(0.0))
     a = np.float32(atomic)

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.TickResult) == 12
     assert C.sizeof(_capi.Entities) == 8 + 13 * 8
     assert C.sizeof(_capi.Visible) == 5 * 4 + 4 + 3 * 8
-    assert C.sizeof(_capi.Stats) == 5 * 4 + 4 + 8 + 6 * 4            # 5 counts, padding, device_bytes, 6 counters
+    assert C.sizeof(_capi.Stats) == 5 * 4 + 4 + 8 + 8 * 4            # 5 counts, padding, device_bytes, 8 counters
 
 
 def test_fails_loudly_without_a_device():

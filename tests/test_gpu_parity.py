@@ -74,12 +74,16 @@ def check_entities(R, p, w, ents):
         np.testing.assert_array_equal(p.read_component(eid, C.C_TRANSFORMATION), o["mat"], err_msg=f"mat of {eid}")
         np.testing.assert_array_equal(p.read_component(eid, C.C_STATIC_AABB), o["aabb"])
         np.testing.assert_array_equal(p.read_component(eid, C.C_POSITION), o["pos"])
-        np.testing.assert_array_equal(p.read_component(eid, C.C_ROTATION), o["rot"])
         assert (fl & (C.F_HAS_MOVED | C.F_HAS_ROTATED)) == (o["flags"] & (C.F_HAS_MOVED | C.F_HAS_ROTATED)), eid
-        if int(e["flags"]) & C.F_HAS_ROTVEL:
-            np.testing.assert_array_equal(p.read_component(eid, C.C_ROTATION_VEL), o["rotvel"])
-        if int(e["flags"]) & C.F_HAS_VEL:
-            np.testing.assert_array_equal(p.read_component(eid, C.C_VELOCITY), o["vel"])
+        # components an entity does not carry read as None (ECS::get_copy): the presence bits agree with the oracle's, the values where present
+        present = C.F_HAS_ROT | C.F_HAS_SCALE | C.F_HAS_VEL | C.F_HAS_ACC | C.F_HAS_ROTVEL | C.F_HAS_ROTACC
+        assert (fl & present) == (o["flags"] & present), (eid, hex(fl), hex(o["flags"]))
+        for bit, comp, key in ((C.F_HAS_ROT, C.C_ROTATION, "rot"), (C.F_HAS_ROTVEL, C.C_ROTATION_VEL, "rotvel"), (C.F_HAS_VEL, C.C_VELOCITY, "vel")):
+            if fl & bit:
+                np.testing.assert_array_equal(p.read_component(eid, comp), o[key])
+            else:
+                with pytest.raises(R.RenderEngineError):
+                    p.read_component(eid, comp)
 
 
 def test_library_loaded_and_fails_loudly(R):
@@ -192,6 +196,29 @@ def test_pack_paths_agree(R):
     w.close(); w2.close()
 
 
+def test_large_pack_paths_by_group_table_size(R):
+    """the pack of a large visible set: group tables of <= 512 slots take the one-launch pack (k_pack_large; the scan counts the instances per
+    group while it expands them, or k_emit_count_sharded does when the scan did not expect a large set), larger tables the count / scan /
+    scatter kernels.  Movers and spinners in between: counted frames, cancelled / replayed frames and uncounted frames alternate."""
+    for n_models, expect_slots in ((8, 64), (100, 800)):
+        ents = R.synthetic.lattice_world(cells_per_axis=30, first_cell=113, n_models=n_models, spinner_every=7, mover_every=11)
+        p, w = build_pair(R, ents)
+        assert len(np.unique(ents["model_index"])) * 8 == expect_slots
+        cam = R.Camera((8192, 8192, 9300), (0, 0, -1), 4000.0)
+        for f in range(6):
+            forced = f % 3 != 2
+            g, o = check_frame(R, p, w, cam, bool(f & 1), force_large_pack=forced)
+            n_o, oob_o = w.tick(oracle_camera(cam), 0.05); t = p.tick(0.05)
+            assert t["n_changed"] == n_o
+        assert g["total"] > 8192                                   # (2 x total > 16383: the unforced frames take the predicted-large path as well)
+        # asynchronous frames through the large pack, speculation across ticks included
+        for f in range(4):
+            p.cull_and_pack(cam, asynchronous=True, copy=False, force_large_pack=True); p.tick(0.05, asynchronous=True)
+            oc = oracle_camera(cam); w.cull(oc); w.render(oc); w.tick(oc, 0.05)
+        check_frame(R, p, w, cam, False, force_large_pack=True)
+        p.close(); w.close()
+
+
 def test_async_frames_match_sync(R):
     ents = R.synthetic.lattice_world(cells_per_axis=32, first_cell=112, spinner_every=5)
     p, w = build_pair(R, ents)
@@ -265,6 +292,8 @@ def random_changes(R, ents, rng, n, frozen, centre=(8192.0, 8192.0, 8192.0)):
             if comp in (C.C_ROTATION_VEL, C.C_ROTATION_ACC):
                 v[:3] = rng.uniform(-1, 1, 3) + np.array([1.5, 0, 0]); v[3] = rng.uniform(-1, 1)
             ch[i] = (C.CHANGE_MODIFY, rng.choice(dyn), comp, 0, tuple(v))
+        elif k < 0.81:       # RemoveComponent: presence bit off, nothing recomputed (Rotation is left alone: the reference unwraps it for entities with VelocityRotation)
+            ch[i] = (C.CHANGE_REMOVE_COMPONENT, rng.choice(free), rng.choice([C.C_SCALE, C.C_ACCELERATION, C.C_ROTATION_ACC, C.C_VELOCITY]), 0, (0, 0, 0, 0))
         elif k < 0.86:
             ch[i] = (C.CHANGE_MAKE_STATIC, rng.choice(ids), 0, 0, (0, 0, 0, 0))
         elif k < 0.94:
