@@ -869,7 +869,10 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         A.nslots = c->nslots; A.out_cap = out_cap; A.range_cap = c->nslots; A.frame = c->frame; A.item_row = KS.item_row; A.item_slot = KS.item_slot; A.nshards = nshards; A.seg_cap = seg_cap;
         A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats; A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p;
         A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count;
-        const uint32_t grid = std::min(8192u, std::max(64u, c->pred_total / PACK_LARGE_TILE + 2u * nshards));     // workgroups loop over the tiles: any grid is correct
+        // workgroup b takes tiles b >> 3, (b >> 3) + grid / 8, ... of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length
+        // (+25 %; a longer shard makes its workgroups loop, any grid that is a multiple of 8 is correct)
+        const uint32_t per_shard = (c->pred_total + c->pred_total / 4u) / nshards + PACK_LARGE_TILE;
+        const uint32_t grid = nshards * std::min(2048u, std::max(4u, (per_shard + PACK_LARGE_TILE - 1u) / PACK_LARGE_TILE));
         hipLaunchKernelGGL(k_pack_large, dim3(grid), dim3(256), 0, st, A);
         HIPCHK(c, hipGetLastError());
         c->gc_dirty[par] = true; c->gc_dirty[par ^ 1u] = false;                // this frame's arrays stay as they are; the other parity's were cleared by the launch

@@ -123,7 +123,7 @@ struct ItemSink {
                                             // through a per-wave LDS histogram flushed once per wave -- so that the pack needs no counting pass (nullptr / 0: off)
 };
 constexpr uint32_t COUNT_SLOTS_MAX = 512;   // group slots the in-scan counting (and k_pack_large) handle; larger tables take the count / scan / scatter kernels
-constexpr uint32_t PACK_LARGE_TILE = 512;   // instances per workgroup iteration of k_pack_large
+constexpr uint32_t PACK_LARGE_TILE = 1024;  // instances per workgroup iteration of k_pack_large (4 list entries per thread)
 struct PackArgs {                           // what k_pack_small needs besides the item list
     uint32_t nslots, out_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;

@@ -435,9 +435,10 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
                     uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
 #pragma unroll
                     for (uint32_t j = 0; j < EMIT_MAX; j++) {
-                        const uint32_t i = vbase + j * 64u + lane;
+                        const uint32_t i = vbase + lane * EMIT_MAX + j;     // a lane's EMIT_MAX sections are neighbours in the list: the instance list then keeps the
+                                                                            // sections' (key) order, and with it the row order of a world registered section by section
                         rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-                        if (vbase + j * 64u < nv) {                         // wave-uniform
+                        if (vbase + j < nv) {                               // wave-uniform (lane 0 holds the lowest entries)
                             const bool on = i < nv;
                             const uint32_t e = q_idx[on ? i : 0u], c = e & 0x3FFFFFFFu, mult = e >> 30;
                             const uint8_t f = cell_flags[c];
@@ -599,9 +600,9 @@ __global__ __launch_bounds__(CULL_THREADS) void k_probe_cull(ProbeArgs Q, ScanCu
                 uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
 #pragma unroll
                 for (uint32_t j = 0; j < EMIT_MAX; j++) {
-                    const uint32_t i = vbase + j * 64u + lane;
+                    const uint32_t i = vbase + lane * EMIT_MAX + j;         // (as in k_scan_cull: list order == section order)
                     rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-                    if (vbase + j * 64u < nv) {
+                    if (vbase + j < nv) {
                         const bool on = i < nv;
                         const uint32_t en = q_idx[on ? i : 0u], c = en & 0x3FFFFFFFu, mult = en >> 30;
                         const uint8_t f = cell_flags[c];
@@ -834,35 +835,45 @@ __global__ __launch_bounds__(256) void k_emit_count_sharded(const FrameHeader *h
 //     (tile, non-empty group) on the shard's own fill counter (contention: tiles of one shard only), then id + 64-byte matrix with 4 lanes per
 //     instance; the matrix loads are issued before the atomics return, so the tile costs two dependent round trips (list entry -> matrix).
 __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
-    constexpr uint32_t NT = 256, TILE = PACK_LARGE_TILE, PER = TILE / NT, PASSES = TILE / 64u;
-    __shared__ uint32_t s_gbase[COUNT_SLOTS_MAX];             // where this workgroup's shard starts inside each group (absolute instance index)
+    constexpr uint32_t NT = 256, TILE = PACK_LARGE_TILE, PER = TILE / NT, CHUNK = 8u, PASSES = TILE / 64u;
+    static_assert(PASSES % CHUNK == 0, "matrix passes go in chunks");
+    __shared__ uint32_t s_gbase[COUNT_SLOTS_MAX];             // first instance of each group (absolute)
     __shared__ uint32_t s_hist[COUNT_SLOTS_MAX], s_tbase[COUNT_SLOTS_MAX];
-    __shared__ uint32_t s_pos[TILE], s_row[TILE];
+    __shared__ uint32_t s_row[TILE], s_pos[TILE];
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_whash[4], s_carry, s_gcarry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, bid = blockIdx.x, nslots = A.nslots, nsh = A.nshards;
     if (A.spec->stale) {                                    // cancelled frame (SpecState)
         if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; publish_to_host(&A.hres->done_frame, A.frame); }
         return;
     }
-    // ---- the cursors: instances per shard, tiles per shard
-    uint32_t n[CURSOR_SHARDS], raw_items = 0, raw_sec = 0, ntiles = 0, tile0[CURSOR_SHARDS + 1];
+    // ---- workgroup b works on cursor shard b & 7, tiles (b >> 3), (b >> 3) + gridDim / 8, ... of that shard's segment: the mapping does not depend on
+    // the counts, so the first tile's list entries are requested together with the cursors and the group counts (entries beyond the shard's
+    // count are stale but harmless: masked below)
+    const uint32_t shard = bid & (CURSOR_SHARDS - 1u), tstride = gridDim.x >> 3;
+    uint32_t tile = bid >> 3, slot[PER], row[PER];
+#pragma unroll
+    for (uint32_t q = 0; q < PER; q++) {
+        const uint32_t j = tile * TILE + q * NT + tid;
+        slot[q] = 0xFFFFFFFFu; row[q] = 0;
+        if (j < A.seg_cap) { const uint32_t ii = shard * A.seg_cap + j; slot[q] = A.item_slot[ii]; row[q] = A.item_row[ii]; }
+    }
+    uint32_t n_sh = 0, raw_items = 0, raw_sec = 0;
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
         const unsigned long long cur = k < nsh ? A.hdr->cursors[k * 8] : 0ull;
         const uint32_t v = (uint32_t)(cur >> 32);
         raw_sec += (uint32_t)cur; raw_items += v;
-        n[k] = v < A.seg_cap ? v : A.seg_cap; tile0[k] = ntiles; ntiles += (n[k] + TILE - 1u) / TILE;
+        if (k == shard) n_sh = v < A.seg_cap ? v : A.seg_cap;
     }
-    tile0[CURSOR_SHARDS] = ntiles;
-    if (bid != 0 && bid >= ntiles) return;
+    if (bid != 0 && tile * TILE >= n_sh) return;
     if (tid == 0) { s_carry = 0; s_gcarry = 0; }
     __syncthreads();
     // ---- scan of the group counts (every workgroup): group begins; workgroup 0 also emits the InstanceRange table
     uint32_t my_hash = 0;
     for (uint32_t base = 0; base < nslots; base += NT) {
         const uint32_t i = base + tid;
-        uint32_t v = 0;
-        if (i < nslots) for (uint32_t k = 0; k < nsh; k++) v += A.gcount[k * nslots + i];
+        uint32_t v = 0, before = 0;                         // before: instances of this group in the shards in front of this workgroup's
+        if (i < nslots) for (uint32_t k = 0; k < nsh; k++) { const uint32_t cnt = A.gcount[k * nslots + i]; v += cnt; if (k < shard) before += cnt; }
         const uint32_t nz = v ? 1u : 0u;
         const uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
         if (lane == 63) { s_wsum[wid] = incl; s_wcnt[wid] = incn; }
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         for (uint32_t w = 0; w < wid; w++) { woff += s_wsum[w]; wcn += s_wcnt[w]; }
         const uint32_t begin = s_carry + woff + incl - v, gidx = s_gcarry + wcn + incn - nz;
         if (i < nslots) {
-            s_gbase[i] = begin;
+            s_gbase[i] = begin + before;                    // where this workgroup's shard starts inside the group
             if (v && bid == 0 && gidx < A.range_cap) {
                 const uint32_t gc = i >> 3, lod = i & 7u;
                 InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
@@ -906,60 +917,75 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(A.th)[i] = 0u;
         for (uint32_t i = tid; i < A.zero_words; i += NT) { if (A.zero_a) A.zero_a[i] = 0u; if (A.zero_b) A.zero_b[i] = 0u; }   // the other parity's counts / fills: nobody reads or adds to them during this launch
     }
-    // ---- tiles
-    for (uint32_t tile = bid; tile < ntiles; tile += gridDim.x) {                // workgroup-uniform
-        uint32_t shard = 0;
-#pragma unroll
-        for (uint32_t k = 1; k < CURSOR_SHARDS; k++) if (tile >= tile0[k]) shard = k;
-        uint32_t n_sh = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) if (k == shard) n_sh = n[k];
-        const uint32_t j0 = (tile - tile0[shard]) * TILE;
-        // round trip 1: the tile's list entries
-        uint32_t slot[PER], row[PER];
+    // ---- tiles of PER entries per thread: few, fat tiles -- one reservation per (tile, non-empty group) on the shard's own fill counters, and every
+    // thread keeps CHUNK 16-byte matrix loads in flight while it moves the tile (4 lanes per instance, list order)
+    const uint32_t part = tid & 3u, li = tid >> 2;
+    for (bool first = true; tile * TILE < n_sh; tile += tstride, first = false) {   // workgroup-uniform
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) {
-            const uint32_t j = j0 + q * NT + tid;
-            slot[q] = 0xFFFFFFFFu; row[q] = 0;
-            if (j < n_sh) { const uint32_t ii = shard * A.seg_cap + j; slot[q] = A.item_slot[ii]; row[q] = A.item_row[ii]; }
+            const uint32_t j = tile * TILE + q * NT + tid;
+            if (!first) { slot[q] = 0xFFFFFFFFu; row[q] = 0; if (j < n_sh) { const uint32_t ii = shard * A.seg_cap + j; slot[q] = A.item_slot[ii]; row[q] = A.item_row[ii]; } }
+            else if (j >= n_sh) { slot[q] = 0xFFFFFFFFu; row[q] = 0; }            // a stale entry beyond the shard's count
+            if (slot[q] >= nslots) slot[q] = 0xFFFFFFFFu;
         }
         __syncthreads();                                                        // (the previous tile is done with the LDS arrays)
         for (uint32_t i = tid; i < nslots; i += NT) s_hist[i] = 0;
         __syncthreads();
-        uint32_t rank[PER];
+        uint32_t rank[PER], ids[PER];
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) {
-            if (slot[q] >= nslots) slot[q] = 0xFFFFFFFFu;
             rank[q] = slot[q] != 0xFFFFFFFFu ? atomicAdd(&s_hist[slot[q]], 1u) : 0u;
             s_row[q * NT + tid] = row[q];
+            ids[q] = slot[q] != 0xFFFFFFFFu ? A.row_id[row[q]] : 0u;              // in flight with the reservations below
         }
         __syncthreads();
-        // round trip 2, three kinds of requests in flight together: the ids, the matrices (4 lanes per instance), the shard's fill counters
-        uint32_t ids[PER];
+        // requests in flight together from here: the ids (above), the first CHUNK of matrix loads, the reservations on the shard's fill counters
+        float4 mat[CHUNK];
 #pragma unroll
-        for (uint32_t q = 0; q < PER; q++) ids[q] = slot[q] != 0xFFFFFFFFu ? A.row_id[row[q]] : 0u;
-        float4 mat[PASSES];
-        const uint32_t part = tid & 3u, li = tid >> 2;
-#pragma unroll
-        for (uint32_t ps = 0; ps < PASSES; ps++) mat[ps] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
+        for (uint32_t ps = 0; ps < CHUNK; ps++)
+#ifdef RE_EXP_PACK_NOLOAD
+            mat[ps] = make_float4((float)s_row[ps * 64u + li], 0.f, 0.f, 0.f);
+#else
+            mat[ps] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
+#endif
         for (uint32_t i = tid; i < nslots; i += NT) {
             const uint32_t cnt = s_hist[i];
-            uint32_t before = 0;                                               // instances of this group in the shards in front of this one
-            for (uint32_t k = 0; k < shard; k++) before += A.gcount[k * nslots + i];
-            s_tbase[i] = s_gbase[i] + before + (cnt ? atomicAdd(&A.gfill[shard * nslots + i], cnt) : 0u);
+#ifdef RE_EXP_PACK_NOATOMIC
+            s_tbase[i] = s_gbase[i];
+#else
+            s_tbase[i] = s_gbase[i] + (cnt ? atomicAdd(&A.gfill[shard * nslots + i], cnt) : 0u);
+#endif
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) {
             const uint32_t pos = slot[q] != 0xFFFFFFFFu ? s_tbase[slot[q]] + rank[q] : 0xFFFFFFFFu;
             s_pos[q * NT + tid] = pos;
+#ifndef RE_EXP_PACK_NOSTORE
             if (pos < A.out_cap) A.out_ids[pos] = ids[q];
+#endif
         }
         __syncthreads();
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < PASSES; c0 += CHUNK) {
+            if (c0) {
 #pragma unroll
-        for (uint32_t ps = 0; ps < PASSES; ps++) {
-            const uint32_t pp = s_pos[ps * 64u + li];
-            if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
+                for (uint32_t ps = 0; ps < CHUNK; ps++)
+#ifdef RE_EXP_PACK_NOLOAD
+                    mat[ps] = make_float4((float)s_row[(c0 + ps) * 64u + li], 0.f, 0.f, 0.f);
+#else
+                    mat[ps] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[(c0 + ps) * 64u + li] * 16)[part];
+#endif
+            }
+#pragma unroll
+            for (uint32_t ps = 0; ps < CHUNK; ps++) {
+                const uint32_t pp = s_pos[(c0 + ps) * 64u + li];
+#ifndef RE_EXP_PACK_NOSTORE
+                if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
+#else
+                if (pp == 0x12345u && mat[ps].x == 1.5f) A.out_ids[0] = 1u;
+#endif
+            }
         }
     }
 }
@@ -1187,16 +1213,27 @@ __device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
 // Position / Rotation / Scale changed: new TransformationMatrix and StaticAABB; returns 0 when the entity stays in its spatial-hash section
 // (entity_exists_in_section, bounding_box_tree_v2.rs:765-782), 1 when it changes section (re-bucket list), 2 when it leaves the world without
 // OutOfBoundsLogic (ecs.remove_entity, :347; the tree keeps the stale entry -- the caller marks the row dead).  No atomics here.
+// what place_core reads from memory, so that a caller can request it early together with its own loads
+struct PlaceInputs { Aabb orig; float scl[3]; float c3w; uint64_t key; };
+__device__ __forceinline__ void place_prefetch(PlaceInputs &in, bool on, uint32_t r, uint32_t rc, const RowArrays &R, const uint64_t *__restrict__ cell_key) {
+    in.orig = Aabb{ 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; in.scl[0] = in.scl[1] = in.scl[2] = 1.f; in.c3w = 1.f; in.key = 0;
+    if (!on) return;
+    in.orig = R.orig[r];
+    in.scl[0] = R.scale[r * 3 + 0]; in.scl[1] = R.scale[r * 3 + 1]; in.scl[2] = R.scale[r * 3 + 2];
+    in.c3w = R.mat[(size_t)r * 16 + 15];
+    if (rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED)) in.key = cell_key[rc];
+}
 __device__ __forceinline__ uint32_t place_core(uint32_t r, uint32_t fl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
-                                                RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells, uint32_t outline, uint32_t atomic) {
-    Aabb orig = R.orig[r], a;
+                                                RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells, uint32_t outline, uint32_t atomic,
+                                                const PlaceInputs *pre = nullptr) {
+    Aabb orig = pre ? pre->orig : R.orig[r], a;
     float4 *mo = reinterpret_cast<float4 *>(R.mat + (size_t)r * 16);
     if (translation_only) {
         // translation-only fast path: column 3 xyz overwritten, OriginalAABB translated (rotation/scale ignored, :221-240)
-        float4 c3 = mo[3]; c3.x = pos[0]; c3.y = pos[1]; c3.z = pos[2]; mo[3] = c3;
+        float4 c3; c3.w = pre ? pre->c3w : mo[3].w; c3.x = pos[0]; c3.y = pos[1]; c3.z = pos[2]; mo[3] = c3;
         a.xmin = orig.xmin + pos[0]; a.xmax = orig.xmax + pos[0]; a.ymin = orig.ymin + pos[1]; a.ymax = orig.ymax + pos[1]; a.zmin = orig.zmin + pos[2]; a.zmax = orig.zmax + pos[2];
     } else {
-        float scl[3] = { R.scale[r * 3 + 0], R.scale[r * 3 + 1], R.scale[r * 3 + 2] };   // Scale::default() when absent (set at upload)
+        float scl[3] = { pre ? pre->scl[0] : R.scale[r * 3 + 0], pre ? pre->scl[1] : R.scale[r * 3 + 1], pre ? pre->scl[2] : R.scale[r * 3 + 2] };   // Scale::default() when absent (set at upload)
         float m[16];
         trs_matrix(pos, true, rot, rot[3], true, scl, m);                               // all three factors, defaults when absent (:245-250)
         mo[0] = make_float4(m[0], m[1], m[2], m[3]); mo[1] = make_float4(m[4], m[5], m[6], m[7]);
@@ -1208,11 +1245,21 @@ __device__ __forceinline__ uint32_t place_core(uint32_t r, uint32_t fl, uint32_t
     Aabb bv = a;
     bool oob = normalize_aabb(&bv, (float)outline);
     if (oob && !(fl & F_OOB_LOGIC)) { R.gclass[r] = 0xFFFFFFFFu; return 2u; }
+    // Short cut for the common case, an entity of a level-0 section that stays inside it (power-of-two atomic length): when both corners of
+    // the clamped box truncate to the section's own indices, add_entity's decision is that section again -- the extents are below one section
+    // length, so find_aabb_level_from_length_and_origin stops at level 0 with one section per axis, and find_unique_world_section_id
+    // divides the same minimum corner (bounding_box_tree_v2.rs:451-551).  Everything else takes the full decision below.
+    if (pre && rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED) && (atomic & (atomic - 1u)) == 0u && key_level(pre->key) == 0u) {
+        const float inv = 1.0f / (float)atomic;
+        const float cx = (float)key_x(pre->key), cy = (float)key_y(pre->key), cz = (float)key_z(pre->key);
+        if (truncf(bv.xmin * inv) == cx && truncf(bv.xmax * inv) == cx && truncf(bv.ymin * inv) == cy && truncf(bv.ymax * inv) == cy &&
+            truncf(bv.zmin * inv) == cz && truncf(bv.zmax * inv) == cz && bv.xmin <= bv.xmax && bv.ymin <= bv.ymax && bv.zmin <= bv.zmax) return 0u;
+    }
     uint64_t keys[8];
     int nk = assign_sections(bv, atomic, keys);
     bool same;
     if (rc == ROW_CELL_NONE) same = false;
-    else if (!(rc & ROW_CELL_SHARED)) same = (nk == 1) && keys[0] == cell_key[rc];
+    else if (!(rc & ROW_CELL_SHARED)) same = (nk == 1) && keys[0] == (pre ? pre->key : cell_key[rc]);
     else {
         uint32_t s = rc & ~ROW_CELL_SHARED;
         same = nk > 1;
@@ -1261,13 +1308,8 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = j;
     const bool in = j < ndyn;
     const FrameParams &P = *Pp;
-    // ---- round trip 1: everything indexed by the row, coalesced
+    // ---- round trip 1: flag word and section slot of the row (coalesced)
     const uint32_t fl = in ? R.flags[r] : F_DEAD, rc = in ? row_cell[r] : ROW_CELL_NONE;
-    float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f };
-    if (in) {
-        pos[0] = R.pos[r * 3 + 0]; pos[1] = R.pos[r * 3 + 1]; pos[2] = R.pos[r * 3 + 2];
-        const float4 q = reinterpret_cast<const float4 *>(R.rot)[r]; rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
-    }
     // ---- the visibility gate (logic_flow.rs:216-223, 308-358): one gathered word per entity, none with RE_TICK_ALL_DYNAMIC
     const bool unique_cell = rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED);
     const uint32_t stamp = (unique_cell && !tick_all) ? cell_stamp[rc] : 0u;
@@ -1296,16 +1338,30 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
         }
         run = (!(fl & F_STATIC) && act && inview) || ((fl & F_ALWAYS_EXEC) && !anyvis);
     }
+    if (!__ballot(run)) {                                                         // nobody in this wave ticks (the common wave of a visibility-gated tick): only the markers
+        if (in && nfl != fl) R.flags[r] = nfl;
+        return;
+    }
+    // ---- round trip 2: every component a ticking lane may need, requested together (all contiguous by row); whether a lane uses
+    // them is decided by its flag word afterwards -- no load below depends on another
+    float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f }, v[3] = { 0.f, 0.f, 0.f }, a[3] = { 0.f, 0.f, 0.f };
+    float4 wq = make_float4(1.f, 0.f, 0.f, 0.f), aq = make_float4(1.f, 0.f, 0.f, 0.f);
+    if (run) {
+        pos[0] = R.pos[r * 3 + 0]; pos[1] = R.pos[r * 3 + 1]; pos[2] = R.pos[r * 3 + 2];
+        const float4 q = reinterpret_cast<const float4 *>(R.rot)[r]; rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
+        if (fl & F_HAS_VEL) { v[0] = dyn_vel[j * 3 + 0]; v[1] = dyn_vel[j * 3 + 1]; v[2] = dyn_vel[j * 3 + 2]; }
+        if (fl & F_HAS_ACC) { a[0] = dyn_acc[j * 3 + 0]; a[1] = dyn_acc[j * 3 + 1]; a[2] = dyn_acc[j * 3 + 2]; }
+        if (fl & F_HAS_ROTVEL) wq = reinterpret_cast<const float4 *>(dyn_rotvel)[j];
+        if (fl & F_HAS_ROTACC) aq = reinterpret_cast<const float4 *>(dyn_rotacc)[j];
+    }
+    PlaceInputs pin;                                                              // what place_core needs from memory, requested in the same round trip
+    place_prefetch(pin, run, r, rc, R, cell_key);
     // ---- apply_kinematics (logic_flow.rs:366-448)
     bool pos_set = false, rot_set = false;
     if (run) {
         if (fl & F_HAS_VEL) {
-            const float v[3] = { dyn_vel[j * 3 + 0], dyn_vel[j * 3 + 1], dyn_vel[j * 3 + 2] };
-            if (fl & F_HAS_ACC) {
-                const float a[3] = { dyn_acc[j * 3 + 0], dyn_acc[j * 3 + 1], dyn_acc[j * 3 + 2] };
-                if (norm3(a[0], a[1], a[2]) != 0.0f) {                            // :384  velocity += acceleration * dt
-                    dyn_vel[j * 3 + 0] = v[0] + a[0] * dt; dyn_vel[j * 3 + 1] = v[1] + a[1] * dt; dyn_vel[j * 3 + 2] = v[2] + a[2] * dt;
-                }
+            if ((fl & F_HAS_ACC) && norm3(a[0], a[1], a[2]) != 0.0f) {            // :384  velocity += acceleration * dt
+                dyn_vel[j * 3 + 0] = v[0] + a[0] * dt; dyn_vel[j * 3 + 1] = v[1] + a[1] * dt; dyn_vel[j * 3 + 2] = v[2] + a[2] * dt;
             }
             if (norm3(v[0], v[1], v[2]) != 0.0f) {                                // :394  position += OLD velocity * dt (change requests are deferred)
                 pos[0] = pos[0] + v[0] * dt; pos[1] = pos[1] + v[1] * dt; pos[2] = pos[2] + v[2] * dt;
@@ -1313,18 +1369,13 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
             }
         }
         if (fl & F_HAS_ROTVEL) {
-            const float4 wq = reinterpret_cast<const float4 *>(dyn_rotvel)[j];
             const float w[4] = { wq.x, wq.y, wq.z, wq.w };
-            if (fl & F_HAS_ROTACC) {
-                const float4 aq = reinterpret_cast<const float4 *>(dyn_rotacc)[j];
-                const float a[4] = { aq.x, aq.y, aq.z, aq.w };
-                if (a[3] != 0.0f) {                                               // :418
-                    float sc[3] = { a[0] * dt, a[1] * dt, a[2] * dt }, nrm[3], sum[3], out[3];
-                    normalize3(sc, nrm);
-                    sum[0] = w[0] + nrm[0]; sum[1] = w[1] + nrm[1]; sum[2] = w[2] + nrm[2];
-                    normalize3(sum, out);
-                    reinterpret_cast<float4 *>(dyn_rotvel)[j] = make_float4(out[0], out[1], out[2], w[3] + a[3] * dt);
-                }
+            if ((fl & F_HAS_ROTACC) && aq.w != 0.0f) {                            // :418
+                float sc[3] = { aq.x * dt, aq.y * dt, aq.z * dt }, nrm[3], sum[3], out[3];
+                normalize3(sc, nrm);
+                sum[0] = w[0] + nrm[0]; sum[1] = w[1] + nrm[1]; sum[2] = w[2] + nrm[2];
+                normalize3(sum, out);
+                reinterpret_cast<float4 *>(dyn_rotvel)[j] = make_float4(out[0], out[1], out[2], w[3] + aq.w * dt);
             }
             if (w[3] != 0.0f) {                                                   // :429  rotation += OLD rotation velocity * dt
                 float sc[3] = { w[0] * dt, w[1] * dt, w[2] * dt }, nrm[3], sum[3], out[3];
@@ -1343,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     if (changed) {
         if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
         if (rot_set) reinterpret_cast<float4 *>(R.rot)[r] = make_float4(rot[0], rot[1], rot[2], rot[3]);
-        status = place_core(r, fl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic);
+        status = place_core(r, fl, rc, pos, rot, pos_set && !rot_set, R, cell_key, sh_cells, outline, atomic, &pin);
         if (status == 2u) nfl |= F_DEAD;
     }
     if (in && nfl != fl) R.flags[r] = nfl;
