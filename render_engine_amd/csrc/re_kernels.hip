@@ -435,10 +435,9 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
                     uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
 #pragma unroll
                     for (uint32_t j = 0; j < EMIT_MAX; j++) {
-                        const uint32_t i = vbase + lane * EMIT_MAX + j;     // a lane's EMIT_MAX sections are neighbours in the list: the instance list then keeps the
-                                                                            // sections' (key) order, and with it the row order of a world registered section by section
+                        const uint32_t i = vbase + j * 64u + lane;
                         rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-                        if (vbase + j < nv) {                               // wave-uniform (lane 0 holds the lowest entries)
+                        if (vbase + j * 64u < nv) {                         // wave-uniform
                             const bool on = i < nv;
                             const uint32_t e = q_idx[on ? i : 0u], c = e & 0x3FFFFFFFu, mult = e >> 30;
                             const uint8_t f = cell_flags[c];
@@ -600,9 +599,9 @@ __global__ __launch_bounds__(CULL_THREADS) void k_probe_cull(ProbeArgs Q, ScanCu
                 uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
 #pragma unroll
                 for (uint32_t j = 0; j < EMIT_MAX; j++) {
-                    const uint32_t i = vbase + lane * EMIT_MAX + j;         // (as in k_scan_cull: list order == section order)
+                    const uint32_t i = vbase + j * 64u + lane;
                     rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-                    if (vbase + j < nv) {
+                    if (vbase + j * 64u < nv) {
                         const bool on = i < nv;
                         const uint32_t en = q_idx[on ? i : 0u], c = en & 0x3FFFFFFFu, mult = en >> 30;
                         const uint8_t f = cell_flags[c];
