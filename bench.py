@@ -158,7 +158,30 @@ def main():
     camc = cam.to_c()
     tick_flags = F.TICK_ALL_DYNAMIC if a.tick_all else 0
     cull_flags = F.CULL_FORCE_LARGE_PACK if a.force_large_pack else 0
-    gather = parallel.SlabAllGather(p, SLAB_INSTANCES, dist) if world > 1 else None
+    # N > 1: the frame's one exchange step runs behind the C ABI (re_comm_init + re_allgather_visible: RCCL called by the library on the pipeline's
+    # stream).  The unique id travels over torch.distributed, which this script also uses for the barrier and the max over ranks.  Where the
+    # library cannot set the communicator up (e.g. the rehearsal with several ranks on one GPU) the torch.distributed harness takes over.
+    gather, exchange = None, "none"
+    if world > 1:
+        try:
+            box = [R.Pipeline.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            p.comm_init(box[0], rank, world, SLAB_INSTANCES)
+            exchange = "re_allgather_visible (RCCL behind the C ABI)"
+        except Exception as e:          # noqa: BLE001
+            ok = torch.tensor([0], dtype=torch.int32, device="cuda")
+            exchange = "torch.distributed all_gather_into_tensor (harness; re_comm_init failed: %s)" % str(e)[:120]
+        else:
+            ok = torch.tensor([1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:         # every rank takes the same path
+            try:
+                p._L.re_comm_destroy(p._h)
+            except Exception:           # noqa: BLE001
+                pass
+            gather = parallel.SlabAllGather(p, SLAB_INSTANCES, dist)
+            if not exchange.startswith("torch"):
+                exchange = "torch.distributed all_gather_into_tensor (harness; another rank could not set up the communicator)"
 
     def frames(n, record=None):
         """n synchronous frames; N > 1: the frame ends when the all-gathered visible-instance buffer is complete on this rank"""
@@ -245,7 +268,8 @@ def main():
             "frame_ms_median": med_us * 1e-3,
             "config": {"workload": wl, "entities": n_total, "sections": stats["n_sections"] * world, "dynamic_entities": stats["n_dynamic"] * world,
                        "visible_sections": n_entries, "visible_instances": V, "far": a.far, "frame": "synchronous re_cull_pack + re_tick%s" % (" (RE_TICK_ALL_DYNAMIC)" if a.tick_all else ""),
-                       "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one RCCL all_gather_into_tensor of fixed %d-instance slabs (count header written by the pack kernel), stream-ordered behind the pack" % SLAB_INSTANCES},
+                       "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one all-gather of fixed %d-instance slabs (header written by the pack kernel), stream-ordered behind the pack" % SLAB_INSTANCES,
+                       "exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": "k_probe_cull" if probed else "k_scan_cull", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY,
                          "bytes_compulsory": bytes_comp, "bytes_survey_8d": bytes_8d, "stream_key_bytes": key_bytes,

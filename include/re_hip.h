@@ -192,8 +192,8 @@ int re_tick(re_ctx *ctx, float delta_time, uint32_t flags, re_tick_result *out);
 int re_wait(re_ctx *ctx, re_visible *out_visible /*nullable*/, re_tick_result *out_tick /*nullable*/);
 
 /* n frames of the reference's frame loop (threads/render_thread.rs:217-250 -> Pipeline::execute) from native code: re_cull_pack(cam, cull_flags)
- * followed by re_tick(dt, tick_flags), n times -- nothing but the two calls above in a loop, so that a measurement does not pay for an interpreter
- * between them.  wall_us (nullable, n floats) receives the wall time of each frame; last_visible / last_tick (nullable) the results of the last one
+ * followed by re_tick(dt, tick_flags), n times -- nothing but the two calls above in a loop (with re_allgather_visible between them when the context has a
+ * communicator), so that a measurement does not pay for an interpreter between them.  wall_us (nullable, n floats) receives the wall time of each frame; last_visible / last_tick (nullable) the results of the last one
  * when its call was synchronous. */
 int re_run_frames(re_ctx *ctx, const re_camera *cam, float delta_time, uint32_t cull_flags, uint32_t tick_flags, uint32_t n,
                   float *wall_us, re_visible *last_visible, re_tick_result *last_tick);
@@ -206,9 +206,46 @@ int re_copy_visible(re_ctx *ctx, uint32_t *entity_ids_host, float *matrices_host
 /* Direct the packed output into caller-owned DEVICE buffers (e.g. the all-gather send slab);
  * NULLs restore the internal buffers. */
 int re_set_output_buffers(re_ctx *ctx, uint32_t *d_entity_ids, float *d_matrices, uint32_t capacity_instances);
-/* Optional DEVICE word that receives the number of instances written to the output buffers by every later re_cull_pack (the
- * header of an all-gather slab, so that the exchange needs no host round trip); NULL switches it off. */
+/* Optional header in DEVICE memory, FOUR consecutive words, filled by every later re_cull_pack (the header of an all-gather slab, so that the
+ * exchange needs no host round trip): {instances written to the output buffers, instances of the frame before truncation to the buffers'
+ * capacity, frame number, 0}.  A frame that cross-frame speculation cancelled (a tick found entities changing section; re_wait replays it) writes
+ * 0xFFFFFFFF into the first word instead.  NULL switches it off.
+ * The packed ids / matrices themselves are only STREAM-ORDERED: a synchronous re_cull_pack returns when the InstanceRange table and the counts are on the
+ * host, which is before the last id / matrix store has landed -- whatever reads d_entity_ids / d_matrices (a copy, a collective, a draw) must be ordered
+ * behind the pack on re_get_stream(ctx), as re_copy_visible and re_allgather_visible are. */
 int re_set_output_count(re_ctx *ctx, uint32_t *d_count);
+
+/* ---- multi-GPU exchange (BASELINE configs[3]): one process and one context per GPU, world sections sharded by contiguous key range, and ONE
+ * exchange step per frame -- the all-gather of every GPU's packed visible-instance buffer over RCCL / xGMI.  Nothing in the reference corresponds to it (it
+ * is a single-process program); it takes the place of RenderFlow handing its SortResult to the one render system (flows/render_flow.rs:401-410) when the
+ * world is spread over several GPUs.  RCCL is loaded at run time (librccl.so; RE_RCCL_LIBRARY overrides the path).
+ *   re_comm_unique_id  rank 0 creates the id (ncclGetUniqueId) and hands the 128 bytes to the other ranks over the host's own channel;
+ *   re_comm_init       every rank: ncclCommInitRank on the context's device + the send / receive slabs of `slab_instances` instances each
+ *                      ([4-word header | pad to 16 words | ids[cap] | matrices[cap * 16]]; size it for the EXPECTED visible set of a rank: xGMI is point to
+ *                      point, every rank's slab crosses every link once per frame);
+ *   re_comm_adopt      the same with a communicator (ncclComm_t) the host created itself.
+ * With a communicator, re_cull_pack packs every frame straight into the frame's send slab (two alternate; RE_CULL_DEFER_PACK / RE_CULL_TWO_LANES are
+ * ignored), and re_allgather_visible -- between re_cull_pack and re_tick -- enqueues the all-gather behind the pack on the context's stream and, unless
+ * RE_GATHER_ASYNC, waits for it.  Every rank ends with the same buffer in rank order.  If a rank's visible set outgrew its slab (every rank reads that
+ * from the gathered headers) a second, variable-length round follows: every rank packs its frame again, untruncated, and the full buffers are gathered
+ * padded to the largest count (out->overflowed = 1; the rank strides then differ).  A frame that cross-frame speculation had cancelled is replayed and
+ * gathered again (RE_GATHER_ASYNC + re_gather_wait: every rank must then call re_gather_wait for every frame). */
+#define RE_COMM_ID_BYTES 128
+#define RE_GATHER_ASYNC  0x1u
+typedef struct {
+    uint32_t n_ranks, overflowed;
+    const uint32_t *counts;            /* host memory, n_ranks entries: instances of each rank's frame */
+    const uint32_t *d_entity_ids;      /* DEVICE: rank r's ids start at d_entity_ids + r * ids_rank_stride */
+    uint32_t ids_rank_stride;          /* in uint32 elements */
+    const float *d_matrices;           /* DEVICE: rank r's 4x4 matrices (64 B each, column-major) start at d_matrices + r * matrices_rank_stride */
+    uint32_t matrices_rank_stride;     /* in float elements */
+} re_gathered;
+int re_comm_unique_id(uint8_t id[RE_COMM_ID_BYTES]);
+int re_comm_init(re_ctx *ctx, const uint8_t id[RE_COMM_ID_BYTES], int rank, int n_ranks, uint32_t slab_instances);
+int re_comm_adopt(re_ctx *ctx, void *nccl_comm, int rank, int n_ranks, uint32_t slab_instances);
+int re_comm_destroy(re_ctx *ctx);      /* also done by re_destroy */
+int re_allgather_visible(re_ctx *ctx, uint32_t flags, re_gathered *out /* nullable */);
+int re_gather_wait(re_ctx *ctx, re_gathered *out /* nullable */);
 
 /* Change requests returned by user logic (LogicFunction / CollisionFunction -> Vec<EntityChangeInformation>,
  * objects/entity_change_request.rs) == apply_change (helper_things/entity_change_helpers.rs:32-189) for the kinds that touch

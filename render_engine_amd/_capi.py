@@ -68,6 +68,14 @@ class Stats(C.Structure):
                 ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32), ("n_section_slots", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
+class Gathered(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("overflowed", C.c_uint32), ("counts", _u32p), ("d_entity_ids", C.c_void_p), ("ids_rank_stride", C.c_uint32),
+                ("d_matrices", C.c_void_p), ("matrices_rank_stride", C.c_uint32)]
+
+
+COMM_ID_BYTES, GATHER_ASYNC = 128, 0x1
+
+
 class LightingConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("width", C.c_uint32), ("height", C.c_uint32), ("max_spot_lights", C.c_uint32), ("max_point_lights", C.c_uint32)]
 
@@ -82,13 +90,28 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
            "re_lighting_run", "re_lighting_read", "re_lighting_read_pixels"]
 
 _lib = None
+_hip = None
+
+
+def device_to_host(ptr, nbytes):
+    """bytes of device memory (hipMemcpy through the HIP runtime the library itself links): used by tests / the bench to look at gathered buffers"""
+    global _hip
+    import numpy as np
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.restype = C.c_int; _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.zeros(max(nbytes, 1), np.uint8)
+    rc = _hip.hipMemcpy(out.ctypes.data, ptr, nbytes, 2)
+    if rc != 0:
+        raise RuntimeError(f"hipMemcpy failed ({rc})")
+    return out[:nbytes]
 
 
 def library_path():
@@ -115,6 +138,12 @@ def load():
     L.re_tick.restype = C.c_int; L.re_tick.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(TickResult)]
     L.re_wait.restype = C.c_int; L.re_wait.argtypes = [vp, C.POINTER(Visible), C.POINTER(TickResult)]
     L.re_run_frames.restype = C.c_int; L.re_run_frames.argtypes = [vp, C.POINTER(CameraC), C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, vp, C.POINTER(Visible), C.POINTER(TickResult)]
+    L.re_comm_unique_id.restype = C.c_int; L.re_comm_unique_id.argtypes = [vp]
+    L.re_comm_init.restype = C.c_int; L.re_comm_init.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
+    L.re_comm_adopt.restype = C.c_int; L.re_comm_adopt.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
+    L.re_comm_destroy.restype = C.c_int; L.re_comm_destroy.argtypes = [vp]
+    L.re_allgather_visible.restype = C.c_int; L.re_allgather_visible.argtypes = [vp, C.c_uint32, C.POINTER(Gathered)]
+    L.re_gather_wait.restype = C.c_int; L.re_gather_wait.argtypes = [vp, C.POINTER(Gathered)]
     L.re_collide.restype = C.c_int; L.re_collide.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.re_apply_changes.restype = C.c_int; L.re_apply_changes.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(TickResult)]
     L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]

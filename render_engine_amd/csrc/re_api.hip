@@ -63,6 +63,7 @@ struct re_ctx;
 static int flush_deferred_pack(re_ctx *c);
 static int drain_other_lane(re_ctx *c);
 static void free_second_lane(re_ctx *c);
+static void comm_release(re_ctx *c);
 struct re_ctx {
     re_config cfg{};
     int device = 0;
@@ -166,6 +167,16 @@ struct re_ctx {
     } park;
     bool park_ready = false, lane_busy = false; uint32_t lane_seq = 0, lane_id = 0, n_lane_switches = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
     re_tick_result last_tick{};
+    // what the last frame's pack was launched with, so that it can be run again into other output buffers (the second, variable-length round of the
+    // multi-GPU exchange when a rank's visible set outgrew its slab)
+    struct LastPack { int kind = 0; FrameHeader *hdr = nullptr, *hdr_next = nullptr; PackArgs A{}; ItemSink K{}; uint32_t grid = 0, nrows = 0, par = 0; PackLargeArgs L{}; } last_pack;   // kind: 1 k_pack_small, 2 k_pack_large, 3 count / scan / scatter
+    // multi-GPU exchange (re_comm_*, re_allgather_visible): an RCCL communicator, two send slabs [4-word header | pad to 16 words | ids[cap] | matrices[cap * 16]]
+    // alternating by frame, their receive buffers, and the buffers of the variable-length second round
+    struct Comm {
+        void *comm = nullptr; bool owned = false; int rank = 0, n = 1; uint32_t cap = 0, words = 0, seq = 0; int last = -1, pending = -1;
+        DevBuf<uint32_t> slab[2], recv[2], big_ids; DevBuf<float> big_mats; uint32_t big_cap = 0;
+        std::vector<uint32_t> h_hdr, counts; uint32_t n_second_rounds = 0, n_regathers = 0;
+    } comm;
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0; bool k1_timing = false;   // per-launch timing of k_scan_cull
 
@@ -238,6 +249,7 @@ extern "C" void re_destroy(re_ctx *c) {
     (void)hipSetDevice(c->device);
     if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm.comm) comm_release(c);
     free_world(c);
     if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }        // lives with the collision scratch lists (kept across uploads)
     for (auto &ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -875,6 +887,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         const uint32_t grid = nshards * std::min(2048u, std::max(4u, (per_shard + PACK_LARGE_TILE - 1u) / PACK_LARGE_TILE));
         hipLaunchKernelGGL(k_pack_large, dim3(grid), dim3(256), 0, st, A);
         HIPCHK(c, hipGetLastError());
+        c->last_pack.kind = 2; c->last_pack.L = A; c->last_pack.grid = grid; c->last_pack.par = par; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next;
         c->gc_dirty[par] = true; c->gc_dirty[par ^ 1u] = false;                // this frame's arrays stay as they are; the other parity's were cleared by the launch
         c->large_seq++;
         return RE_OK;
@@ -889,6 +902,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
     hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, KS.item_row, KS.item_slot, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
                        c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->d_spec.p);
     HIPCHK(c, hipGetLastError());
+    c->last_pack.kind = 3; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next;
     return RE_OK;
 }
 
@@ -1117,11 +1131,13 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         uint32_t pgrid = CURSOR_SHARDS * std::min(32u, (per_shard + 63u) / 64u);
         // RE_CULL_DEFER_PACK: in a world without dynamic entities nothing changes what the pack reads before the next visibility query,
         // so an asynchronous frame may leave its pack to the launch of the next one (k_scan_cull_fused)
-        if ((flags & RE_CULL_DEFER_PACK) && (flags & RE_CULL_ASYNC) && c->ndyn == 0 && !c->dirty_pending) {
+        if ((flags & RE_CULL_DEFER_PACK) && (flags & RE_CULL_ASYNC) && c->ndyn == 0 && !c->dirty_pending && !c->comm.comm) {
             FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->lane_seq); F.nrows = c->n + c->ghost_cap;
             c->deferred = F; c->deferred_grid = pgrid; c->deferred_pack = true;
-        } else
+        } else {
             hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->lane_seq), c->n + c->ghost_cap);
+            c->last_pack.kind = 1; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next; c->last_pack.A = A; c->last_pack.K = item_sink(c, c->lane_seq); c->last_pack.grid = pgrid; c->last_pack.nrows = c->n + c->ghost_cap;
+        }
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next, count_in_scan);
         if (rc != RE_OK) return rc;
@@ -1146,11 +1162,16 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
         // frame's on the GPU); anything else runs on one lane only and waits for the other one first
         const uint32_t need = RE_CULL_ASYNC | RE_CULL_DEFER_PACK | RE_CULL_TWO_LANES;
         const bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
-        if ((flags & need) == need && c->ndyn == 0 && !c->dirty_pending && small && c->have_cull) {
+        if ((flags & need) == need && c->ndyn == 0 && !c->dirty_pending && small && c->have_cull && !c->comm.comm) {
             int rc = ensure_second_lane(c); if (rc != RE_OK) return rc;
             switch_lane(c);
             c->lane_busy = true;
         } else { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
+    }
+    if (c->comm.comm) {                                                       // multi-GPU exchange: this frame packs straight into its send slab
+        const int b = (int)(c->comm.seq & 1u); uint32_t *sl = c->comm.slab[b].p;
+        c->ext_out_count = sl; c->ext_out_ids = sl + 16; c->ext_out_mats = reinterpret_cast<float *>(sl + 16 + c->comm.cap); c->ext_out_cap = c->comm.cap;
+        c->comm.last = b; c->comm.seq++;
     }
     int rc = issue_cull(c, cam, flags);
     if (rc != RE_OK || (flags & RE_CULL_ASYNC)) return rc;
@@ -2030,6 +2051,197 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
     return RE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU exchange behind the C ABI (BASELINE configs[3]): one process per GPU, sections sharded by contiguous key range, and
+// ONE exchange step per frame -- the all-gather of every GPU's packed visible-instance slab over RCCL / xGMI.  RCCL is loaded at run time
+// (a single-GPU host does not need it); the communicator is either created here from a unique id the host distributes over its own
+// channel (re_comm_unique_id / re_comm_init) or adopted from the host (re_comm_adopt).
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+namespace rccl {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;                                    // ncclSuccess == 0
+enum { Int32 = 2, Uint32 = 3, Float32 = 7 };                 // ncclDataType_t (rccl.h)
+static ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+static ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+static ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+static ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+static const char *(*GetErrorString)(ncclResult_t) = nullptr;
+static std::string load_error;
+static bool load() {
+    if (AllGather) return true;
+    void *h = nullptr;
+    const char *env = getenv("RE_RCCL_LIBRARY");
+    if (env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);           // the copy the process already uses (e.g. the one a framework brought along)
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) { load_error = std::string("RCCL could not be loaded: ") + (dlerror() ? dlerror() : "?"); return false; }
+    GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    auto ag = reinterpret_cast<decltype(AllGather)>(dlsym(h, "ncclAllGather"));
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !GetErrorString || !ag) { load_error = "RCCL: missing symbols"; return false; }
+    AllGather = ag;
+    return true;
+}
+}  // namespace rccl
+#define NCCLCHK(ctx, call) do { rccl::ncclResult_t r_ = (call); if (r_ != 0) return (ctx)->fail(RE_E_HIP, "%s failed: %s", #call, rccl::GetErrorString ? rccl::GetErrorString(r_) : "?"); } while (0)
+
+static void comm_release(re_ctx *c) {
+    re_ctx::Comm &m = c->comm;
+    if (m.comm && m.owned && rccl::CommDestroy) (void)rccl::CommDestroy(reinterpret_cast<rccl::ncclComm_t>(m.comm));
+    for (int b = 0; b < 2; b++) { m.slab[b].release(&c->dev_bytes); m.recv[b].release(&c->dev_bytes); }
+    m.big_ids.release(&c->dev_bytes); m.big_mats.release(&c->dev_bytes);
+    m = re_ctx::Comm{};
+    c->ext_out_ids = nullptr; c->ext_out_mats = nullptr; c->ext_out_cap = 0; c->ext_out_count = nullptr;
+}
+static int comm_setup(re_ctx *c, void *comm, bool owned, int rank, int n_ranks, uint32_t slab_instances) {
+    re_ctx::Comm &m = c->comm;
+    m.comm = comm; m.owned = owned; m.rank = rank; m.n = n_ranks; m.cap = std::max(slab_instances, 1u);
+    m.words = 16u + m.cap * 17u;
+    for (int b = 0; b < 2; b++) {
+        HIPCHK(c, m.slab[b].alloc(m.words, &c->dev_bytes)); HIPCHK(c, m.recv[b].alloc((size_t)m.words * n_ranks, &c->dev_bytes));
+        HIPCHK(c, hipMemset(m.slab[b].p, 0, (size_t)m.words * 4)); HIPCHK(c, hipMemset(m.recv[b].p, 0, (size_t)m.words * n_ranks * 4));
+    }
+    m.h_hdr.assign((size_t)n_ranks * 4, 0u); m.counts.assign(n_ranks, 0u); m.seq = 0; m.last = -1; m.pending = -1;
+    return RE_OK;
+}
+extern "C" int re_comm_unique_id(uint8_t *id) {
+    if (!id) return RE_E_ARG;
+    if (!rccl::load()) { g_create_error = rccl::load_error; return RE_E_UNSUPPORTED; }
+    rccl::ncclUniqueId u; memset(&u, 0, sizeof u);
+    rccl::ncclResult_t r = rccl::GetUniqueId(&u);
+    if (r != 0) { g_create_error = std::string("ncclGetUniqueId: ") + rccl::GetErrorString(r); return RE_E_HIP; }
+    memcpy(id, u.internal, RE_COMM_ID_BYTES);
+    return RE_OK;
+}
+extern "C" int re_comm_init(re_ctx *c, const uint8_t *id, int rank, int n_ranks, uint32_t slab_instances) {
+    if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? c->fail(RE_E_ARG, "re_comm_init: bad arguments") : RE_E_ARG;
+    if (!rccl::load()) return c->fail(RE_E_UNSUPPORTED, "%s", rccl::load_error.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm.comm) comm_release(c);
+    rccl::ncclUniqueId u; memcpy(u.internal, id, RE_COMM_ID_BYTES);
+    rccl::ncclComm_t comm = nullptr;
+    NCCLCHK(c, rccl::CommInitRank(&comm, n_ranks, u, rank));
+    return comm_setup(c, comm, true, rank, n_ranks, slab_instances);
+}
+extern "C" int re_comm_adopt(re_ctx *c, void *nccl_comm, int rank, int n_ranks, uint32_t slab_instances) {
+    if (!c || !nccl_comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? c->fail(RE_E_ARG, "re_comm_adopt: bad arguments") : RE_E_ARG;
+    if (!rccl::load()) return c->fail(RE_E_UNSUPPORTED, "%s", rccl::load_error.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm.comm) comm_release(c);
+    return comm_setup(c, nccl_comm, false, rank, n_ranks, slab_instances);
+}
+extern "C" int re_comm_destroy(re_ctx *c) {
+    if (!c) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    comm_release(c);
+    return RE_OK;
+}
+
+// The last frame's pack once more, into other output buffers (everything it reads -- instance list, cursors, group counts -- is still there until the
+// next visibility query): the second round of the exchange needs a rank's FULL packed set, not the slab's truncated prefix.
+static int repack_last_frame(re_ctx *c, uint32_t *ids, float *mats, uint32_t cap) {
+    hipStream_t st = c->stream;
+    re_ctx::LastPack &P = c->last_pack;
+    if (P.kind == 1) {
+        PackArgs A = P.A; A.out_ids = ids; A.out_mats = mats; A.out_cap = cap; A.out_count = nullptr;
+        hipLaunchKernelGGL(k_pack_small, dim3(P.grid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, P.hdr, P.hdr_next, c->d_th.p, A, P.K, P.nrows);
+    } else if (P.kind == 2) {
+        PackLargeArgs A = P.L; A.out_ids = ids; A.out_mats = mats; A.out_cap = cap; A.out_count = nullptr; A.zero_a = nullptr; A.zero_b = nullptr; A.zero_words = 0;
+        HIPCHK(c, hipMemsetAsync(A.gfill, 0, (size_t)CURSOR_SHARDS * std::max(c->nslots, 1u) * 4, st));      // the fills of the first run
+        hipLaunchKernelGGL(k_pack_large, dim3(P.grid), dim3(256), 0, st, A);
+    } else if (P.kind == 3) {
+        uint32_t *ki = c->ext_out_ids; float *km = c->ext_out_mats; uint32_t kc = c->ext_out_cap, *kn = c->ext_out_count;
+        c->ext_out_ids = ids; c->ext_out_mats = mats; c->ext_out_cap = cap; c->ext_out_count = nullptr;
+        int rc = launch_pack_large(c, P.hdr, P.hdr_next);                       // count / scan / scatter leave their scratch clean: they can simply run again
+        c->ext_out_ids = ki; c->ext_out_mats = km; c->ext_out_cap = kc; c->ext_out_count = kn;
+        if (rc != RE_OK) return rc;
+    } else return c->fail(RE_E_STATE, "repack: no frame has been packed yet");
+    HIPCHK(c, hipGetLastError());
+    return RE_OK;
+}
+
+static int gather_enqueue(re_ctx *c, int b) {
+    re_ctx::Comm &m = c->comm;
+    NCCLCHK(c, rccl::AllGather(m.slab[b].p, m.recv[b].p, m.words, rccl::Int32, reinterpret_cast<rccl::ncclComm_t>(m.comm), c->stream));
+    return RE_OK;
+}
+static int gather_finish(re_ctx *c, re_gathered *out) {
+    re_ctx::Comm &m = c->comm;
+    const int b = m.pending >= 0 ? m.pending : m.last;
+    if (b < 0) return c->fail(RE_E_STATE, "re_allgather_visible: no frame has been packed since re_comm_init");
+    m.pending = -1;
+    auto read_headers = [&]() -> int {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int r = 0; r < m.n; r++) HIPCHK(c, hipMemcpy(&m.h_hdr[(size_t)r * 4], m.recv[b].p + (size_t)r * m.words, 16, hipMemcpyDeviceToHost));
+        return RE_OK;
+    };
+    { int rc = read_headers(); if (rc != RE_OK) return rc; }
+    // A frame cancelled by cross-frame speculation left a marker in its slab header instead of a count (every rank reads the same headers, so every
+    // rank takes this branch together): settle the speculation here -- the replay packs into the same slab -- and gather again.
+    for (int round = 0; round < 4; round++) {
+        bool cancelled = false;
+        for (int r = 0; r < m.n; r++) cancelled |= m.h_hdr[(size_t)r * 4] == 0xFFFFFFFFu;
+        if (!cancelled) break;
+        { int rc = c->cull_inflight ? finish_cull(c, nullptr) : resolve(c); if (rc != RE_OK) return rc; }
+        m.n_regathers++;
+        { int rc = gather_enqueue(c, b); if (rc != RE_OK) return rc; }
+        { int rc = read_headers(); if (rc != RE_OK) return rc; }
+        if (round == 3) return c->fail(RE_E_STATE, "re_allgather_visible: a rank's frame stayed cancelled");
+    }
+    uint32_t max_total = 0; bool overflow = false;
+    for (int r = 0; r < m.n; r++) { const uint32_t total = m.h_hdr[(size_t)r * 4 + 1]; m.counts[r] = total; max_total = std::max(max_total, total); overflow |= total > m.cap; }
+    if (out) { out->n_ranks = (uint32_t)m.n; out->counts = m.counts.data(); out->overflowed = overflow ? 1u : 0u; }
+    if (!overflow) {
+        if (out) {
+            out->d_entity_ids = m.recv[b].p + 16; out->ids_rank_stride = m.words;
+            out->d_matrices = reinterpret_cast<const float *>(m.recv[b].p + 16 + m.cap); out->matrices_rank_stride = m.words;
+        }
+        return RE_OK;
+    }
+    // Second, variable-length round (rare: a slab is sized for the expected visible set of a rank): every rank packs its frame again, untruncated,
+    // into its full-size output buffer, and the buffers are gathered padded to the largest count.
+    if (max_total > c->out_cap) return c->fail(RE_E_CAPACITY, "re_allgather_visible: a rank packed %u instances, more than this rank's output buffer holds (%u)", max_total, c->out_cap);
+    { int rc = repack_last_frame(c, c->d_out_ids.p, c->d_out_mats.p, c->out_cap); if (rc != RE_OK) return rc; }
+    if (m.big_cap < max_total) {
+        m.big_ids.release(&c->dev_bytes); m.big_mats.release(&c->dev_bytes);
+        m.big_cap = max_total + max_total / 4u;
+        HIPCHK(c, m.big_ids.alloc((size_t)m.big_cap * m.n, &c->dev_bytes)); HIPCHK(c, m.big_mats.alloc((size_t)m.big_cap * m.n * 16, &c->dev_bytes));
+    }
+    NCCLCHK(c, rccl::AllGather(c->d_out_ids.p, m.big_ids.p, max_total, rccl::Uint32, reinterpret_cast<rccl::ncclComm_t>(m.comm), c->stream));
+    NCCLCHK(c, rccl::AllGather(c->d_out_mats.p, m.big_mats.p, (size_t)max_total * 16, rccl::Float32, reinterpret_cast<rccl::ncclComm_t>(m.comm), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    m.n_second_rounds++;
+    if (out) { out->d_entity_ids = m.big_ids.p; out->ids_rank_stride = max_total; out->d_matrices = m.big_mats.p; out->matrices_rank_stride = max_total * 16u; }
+    return RE_OK;
+}
+extern "C" int re_allgather_visible(re_ctx *c, uint32_t flags, re_gathered *out) {
+    if (!c) return RE_E_ARG;
+    if (!c->comm.comm) return c->fail(RE_E_STATE, "re_allgather_visible: no communicator (re_comm_init / re_comm_adopt)");
+    if (c->comm.last < 0) return c->fail(RE_E_STATE, "re_allgather_visible: call re_cull_pack first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm.pending >= 0) { int rc = gather_finish(c, nullptr); if (rc != RE_OK) return rc; }
+    // synchronous: the frame is settled first (a cancelled frame is replayed into the same slab), so the slab that goes out is the final one
+    if (!(flags & RE_GATHER_ASYNC) && c->cull_inflight) { int rc = finish_cull(c, nullptr); if (rc != RE_OK) return rc; }
+    { int rc = gather_enqueue(c, c->comm.last); if (rc != RE_OK) return rc; }       // on the context's stream: ordered behind the pack that fills the slab
+    c->comm.pending = c->comm.last;
+    if (flags & RE_GATHER_ASYNC) return RE_OK;
+    return gather_finish(c, out);
+}
+extern "C" int re_gather_wait(re_ctx *c, re_gathered *out) {
+    if (!c) return RE_E_ARG;
+    if (!c->comm.comm) return c->fail(RE_E_STATE, "re_gather_wait: no communicator");
+    HIPCHK(c, hipSetDevice(c->device));
+    return gather_finish(c, out);
+}
+
 extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_tick) {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2049,6 +2261,7 @@ extern "C" int re_run_frames(re_ctx *c, const re_camera *cam, float dt, uint32_t
     for (uint32_t f = 0; f < n; f++) {
         const auto t0 = std::chrono::steady_clock::now();
         int rc = re_cull_pack(c, cam, cull_flags, &vis); if (rc != RE_OK) return rc;
+        if (c->comm.comm) { rc = re_allgather_visible(c, (cull_flags & RE_CULL_ASYNC) ? RE_GATHER_ASYNC : 0u, nullptr); if (rc != RE_OK) return rc; }   // the frame's one exchange step
         rc = re_tick(c, dt, tick_flags, &tr); if (rc != RE_OK) return rc;
         if (wall_us) wall_us[f] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }

@@ -677,6 +677,19 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
 
 
 
+// The optional header of a caller-provided output slab (re_set_output_count; the all-gather send slab of the multi-GPU exchange): 4 words
+// {instances written, instances of the frame (before truncation to the slab), frame number, 0}.  A frame cancelled by cross-frame
+// speculation (SpecState) marks the header instead of leaving the previous frame's numbers there for a collective to ship.
+constexpr uint32_t SLAB_CANCELLED = 0xFFFFFFFFu;
+__device__ __forceinline__ void write_slab_header(uint32_t *out_count, uint32_t total, uint32_t cap, uint32_t frame) {
+    if (!out_count) return;
+    out_count[0] = total < cap ? total : cap; out_count[1] = total; out_count[2] = frame; out_count[3] = 0u;
+}
+__device__ __forceinline__ void cancel_slab_header(uint32_t *out_count, uint32_t frame) {
+    if (!out_count) return;
+    out_count[0] = SLAB_CANCELLED; out_count[1] = 0u; out_count[2] = frame; out_count[3] = 0u;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2a (large visible sets): per-group instance counts from the expanded item list.
 // ---------------------------------------------------------------------------------------------
@@ -706,7 +719,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
                                                      InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
                                                      uint32_t *out_count, uint32_t out_cap, uint32_t frame) {
     __shared__ uint32_t s_wsum[16], s_wcnt[16], s_whash[16];
-    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; publish_to_host(&hres->done_frame, frame); } return; }
+    if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; cancel_slab_header(out_count, frame); publish_to_host(&hres->done_frame, frame); } return; }
     __shared__ uint32_t s_carry, s_gcarry;
     if (threadIdx.x == 0) { s_carry = 0; s_gcarry = 0; }
     __syncthreads();
@@ -752,7 +765,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
         r.table_hash = result_seal(table_hash | 1u, frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items);
         *hres = r;                                              // mapped pinned host memory
-        if (out_count) *out_count = s_carry < out_cap ? s_carry : out_cap;
+        write_slab_header(out_count, s_carry, out_cap, frame);
         publish_to_host(&hres->done_frame, frame);
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
@@ -842,7 +855,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_whash[4], s_carry, s_gcarry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, bid = blockIdx.x, nslots = A.nslots, nsh = A.nshards;
     if (A.spec->stale) {                                    // cancelled frame (SpecState)
-        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; publish_to_host(&A.hres->done_frame, A.frame); }
+        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
         return;
     }
     // ---- workgroup b works on cursor shard b & 7, tiles (b >> 3), (b >> 3) + gridDim / 8, ... of that shard's segment: the mapping does not depend on
@@ -908,7 +921,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
                 r.n_groups = s_gcarry < A.range_cap ? s_gcarry : A.range_cap; r.total = s_carry; r.overflow = 0; r.n_entries = raw_sec; r.n_items = raw_items;
                 r.table_hash = result_seal(table_hash | 1u, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items);
                 *A.hres = r;
-                if (A.out_count) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
+                write_slab_header(A.out_count, s_carry, A.out_cap, A.frame);
                 publish_to_host(&A.hres->done_frame, A.frame);
             }
         }
@@ -1018,7 +1031,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     uint32_t direct_hash = 0;                                 // hash of the table words this thread stores straight to the host (a table too large to stage)
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; publish_to_host(&A.hres->done_frame, A.frame); }
+        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
         return;
     }
     const uint32_t nslots = A.nslots;
@@ -1129,7 +1142,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
                 r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
                 r.table_hash = table_hash ? result_seal(table_hash, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items) : 0u;
                 *A.hres = r;                                        // mapped pinned host memory
-                if (A.out_count && !overflow) *A.out_count = s_carry < A.out_cap ? s_carry : A.out_cap;
+                if (!overflow) write_slab_header(A.out_count, s_carry, A.out_cap, A.frame);
                 publish_to_host(&A.hres->done_frame, A.frame);      // the group table and the counters above are complete
             }
         }

@@ -49,6 +49,51 @@ def allgather_packed(ids, mats, n_local, dist, group=None):
     return ids_all, mats_all, counts
 
 
+HEADER_WORDS = 16                 # slab = [4-word header written by the pack kernel | pad to 16 words | ids[cap] | matrices[cap * 16]]
+SLAB_CANCELLED = -1               # header word 0 of a frame that cross-frame speculation cancelled (0xFFFFFFFF as int32)
+
+
+class SlabCancelled(RuntimeError):
+    """a rank's frame was cancelled by cross-frame speculation when its slab went out: settle (Pipeline.wait replays it into the same slab) and gather again"""
+
+
+class SlabOverflow(RuntimeError):
+    """a rank's visible set outgrew its slab: `totals` holds every rank's true count; gather the full buffers with allgather_packed"""
+
+    def __init__(self, totals, cap):
+        super().__init__(f"visible sets {totals} exceed the slab of {cap} instances")
+        self.totals, self.cap = totals, cap
+
+
+def slab_words(cap):
+    return HEADER_WORDS + cap * 17
+
+
+def fill_slab(slab, ids, mats, total, frame=0):
+    """what the pack kernel writes (tests build slabs on the CPU with it): header {written, total, frame, 0}, ids, matrices"""
+    cap = (slab.numel() - HEADER_WORDS) // 17
+    n = min(int(total), cap)
+    slab[0], slab[1], slab[2], slab[3] = n, int(total), int(frame), 0
+    slab[HEADER_WORDS:HEADER_WORDS + n] = ids[:n].to(torch.int32)
+    slab[HEADER_WORDS + cap:].view(torch.float32).view(cap, 16)[:n] = mats[:n]
+    return slab
+
+
+def parse_slabs(recv, world, cap):
+    """(ids, matrices, counts) in rank order from the all-gathered slabs; raises SlabCancelled / SlabOverflow from the headers every rank sees alike"""
+    words = slab_words(cap)
+    r = recv.view(world, words)
+    written = [int(c) for c in r[:, 0].tolist()]
+    totals = [int(c) for c in r[:, 1].tolist()]
+    if any(w == SLAB_CANCELLED for w in written):
+        raise SlabCancelled([k for k, w in enumerate(written) if w == SLAB_CANCELLED])
+    if any(t > cap for t in totals):
+        raise SlabOverflow(totals, cap)
+    ids = torch.cat([r[k, HEADER_WORDS:HEADER_WORDS + written[k]] for k in range(world)])
+    mats = torch.cat([r[k, HEADER_WORDS + cap:].view(torch.float32).view(cap, 16)[:written[k]] for k in range(world)])
+    return ids, mats, written
+
+
 class VisibleAllGather:
     """Binds a Pipeline's packed output to torch tensors (the all-gather send slab) and runs the
     per-frame exchange."""
@@ -62,8 +107,12 @@ class VisibleAllGather:
         self.last = None
 
     def exchange(self, n_written):
-        self.last = allgather_packed(self.ids, self.mats, n_written, self.dist)
-        torch.cuda.current_stream().synchronize()      # the send slab is rewritten by the next cull
+        # the packed ids / matrices are only stream-ordered behind a synchronous re_cull_pack (it returns when the group table is on the host, before
+        # the last matrix store): the collective runs on the pipeline's own stream
+        st = torch.cuda.ExternalStream(self.p.stream())
+        with torch.cuda.stream(st):
+            self.last = allgather_packed(self.ids, self.mats, n_written, self.dist)
+        st.synchronize()                               # the send slab is rewritten by the next cull
         return self.last
 
 
@@ -78,7 +127,7 @@ class SlabAllGather:
     xGMI is point to point: the direct all-gather moves each rank's slab over each link once, so the slab is sized
     for the expected visible set (a few thousand instances), not for the worst case."""
 
-    HEADER_WORDS = 16
+    HEADER_WORDS = HEADER_WORDS
 
     def __init__(self, pipeline, slab_instances, dist, group=None):
         self.p, self.dist, self.group, self.cap = pipeline, dist, group, int(slab_instances)
@@ -149,13 +198,14 @@ class SlabAllGather:
         torch.cuda.synchronize()
 
     def gathered(self, b):
-        """(ids, matrices, counts) of buffer b in rank order, after finish()"""
-        words = self.HEADER_WORDS + self.cap * 17
-        r = self.recv[b].view(self.world, words)
-        counts = [int(c) for c in r[:, 0].tolist()]
-        ids = torch.cat([r[k, self.HEADER_WORDS:self.HEADER_WORDS + min(counts[k], self.cap)] for k in range(self.world)])
-        mats = torch.cat([r[k, self.HEADER_WORDS + self.cap:].view(torch.float32).view(self.cap, 16)[:min(counts[k], self.cap)] for k in range(self.world)])
-        return ids, mats, counts
+        """(ids, matrices, counts) of buffer b in rank order, after finish().  Raises SlabCancelled when a rank's frame had been cancelled by cross-frame
+        speculation when its slab went out (call regather(b) after Pipeline.wait()) and SlabOverflow when a visible set outgrew the slab."""
+        return parse_slabs(self.recv[b], self.world, self.cap)
+
+    def regather(self, b):
+        """after Pipeline.wait() has replayed a cancelled frame into slab b: the all-gather of that slab once more (every rank, the headers are the same everywhere)"""
+        self._gather(b); self.finish()
+        return self.gathered(b)
 
 
 class SlabAllGatherLanes:
@@ -227,9 +277,4 @@ class SlabAllGatherLanes:
         return (self.frame - 1) % self.DEPTH
 
     def gathered(self, b):
-        words = self.HEADER_WORDS + self.cap * 17
-        r = self.recv[b].view(self.world, words)
-        counts = [int(c) for c in r[:, 0].tolist()]
-        ids = torch.cat([r[k, self.HEADER_WORDS:self.HEADER_WORDS + min(counts[k], self.cap)] for k in range(self.world)])
-        mats = torch.cat([r[k, self.HEADER_WORDS + self.cap:].view(torch.float32).view(self.cap, 16)[:min(counts[k], self.cap)] for k in range(self.world)])
-        return ids, mats, counts
+        return parse_slabs(self.recv[b], self.world, self.cap)

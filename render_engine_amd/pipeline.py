@@ -238,6 +238,44 @@ class Pipeline:
         self._check(self._L.re_collide(self._h, 0, pairs.ctypes.data, capacity, C.byref(n)), "re_collide")
         return pairs[:min(n.value, capacity)].copy(), n.value
 
+    # -- multi-GPU exchange (RCCL behind the C ABI) ---------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte id every rank passes to comm_init (the host distributes it over its own channel)"""
+        L = _capi.load()
+        buf = (C.c_uint8 * _capi.COMM_ID_BYTES)()
+        rc = L.re_comm_unique_id(buf)
+        if rc != _capi.RE_OK:
+            raise RenderEngineError(f"re_comm_unique_id failed ({rc}): {L.re_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, n_ranks, slab_instances):
+        buf = (C.c_uint8 * _capi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._L.re_comm_init(self._h, buf, rank, n_ranks, slab_instances), "re_comm_init")
+
+    def allgather_visible(self, asynchronous=False, copy=True):
+        g = _capi.Gathered()
+        self._check(self._L.re_allgather_visible(self._h, _capi.GATHER_ASYNC if asynchronous else 0, C.byref(g)), "re_allgather_visible")
+        return None if asynchronous else self._gathered_to_py(g, copy)
+
+    def gather_wait(self, copy=True):
+        g = _capi.Gathered()
+        self._check(self._L.re_gather_wait(self._h, C.byref(g)), "re_gather_wait")
+        return self._gathered_to_py(g, copy)
+
+    def _gathered_to_py(self, g, copy):
+        counts = [int(g.counts[r]) for r in range(g.n_ranks)]
+        out = dict(counts=counts, overflowed=bool(g.overflowed), d_entity_ids=g.d_entity_ids, d_matrices=g.d_matrices,
+                   ids_rank_stride=g.ids_rank_stride, matrices_rank_stride=g.matrices_rank_stride)
+        if copy:                                           # rank-ordered concatenation on the host
+            ids, mats = [], []
+            for r, n in enumerate(counts):
+                ids.append(_capi.device_to_host(g.d_entity_ids + 4 * r * g.ids_rank_stride, 4 * n).view(np.uint32))
+                mats.append(_capi.device_to_host(g.d_matrices + 4 * r * g.matrices_rank_stride, 64 * n).view(np.float32).reshape(n, 16))
+            out["ids"] = np.concatenate(ids) if ids else np.zeros(0, np.uint32)
+            out["mats"] = np.concatenate(mats) if mats else np.zeros((0, 16), np.float32)
+        return out
+
     def wait(self, copy=False):
         vis = _capi.Visible(); tr = _capi.TickResult()
         self._check(self._L.re_wait(self._h, C.byref(vis), C.byref(tr)), "re_wait")

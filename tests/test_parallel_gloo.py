@@ -38,7 +38,32 @@ def _worker(rank, world, port, q):
     ids = torch.zeros(cap, dtype=torch.int32); mats = torch.zeros(cap, 16)
     ids[:r["total"]] = torch.from_numpy(r["ids"].astype(np.int32)); mats[:r["total"]] = torch.from_numpy(r["mats"])
     ids_all, mats_all, counts = parallel.allgather_packed(ids, mats, r["total"], dist)
-    q.put((rank, r["total"], counts, ids_all.numpy().copy(), mats_all.numpy().copy()))
+    # ---- the fixed-slab exchange of the frame loop (SlabAllGather / re_allgather_visible): header {written, total, frame, 0} + ids + matrices
+    slab_res = {}
+    for name, scap in (("fits", 1024), ("overflow", 100)):
+        slab = parallel.fill_slab(torch.zeros(parallel.slab_words(scap), dtype=torch.int32), ids, mats, r["total"], frame=7)
+        recv = torch.zeros(parallel.slab_words(scap) * world, dtype=torch.int32)
+        dist.all_gather_into_tensor(recv, slab)
+        try:
+            si, sm, sc = parallel.parse_slabs(recv, world, scap)
+            slab_res[name] = ("ok", sc, si.numpy().copy(), sm.numpy().copy())
+        except parallel.SlabOverflow as e:                # every rank reads the same headers: all of them fall back to the variable-length gather
+            fi, fm, fc = parallel.allgather_packed(ids, mats, r["total"], dist)
+            slab_res[name] = ("overflow", e.totals, fi.numpy().copy(), fm.numpy().copy())
+    # a frame that cross-frame speculation cancelled on rank 1: the marker in its header makes every rank gather again after the replay
+    slab = parallel.fill_slab(torch.zeros(parallel.slab_words(1024), dtype=torch.int32), ids, mats, r["total"])
+    if rank == 1:
+        slab[0] = parallel.SLAB_CANCELLED
+    recv = torch.zeros(parallel.slab_words(1024) * world, dtype=torch.int32)
+    dist.all_gather_into_tensor(recv, slab)
+    try:
+        parallel.parse_slabs(recv, world, 1024); cancelled = None
+    except parallel.SlabCancelled as e:
+        cancelled = e.args[0]
+        slab = parallel.fill_slab(slab, ids, mats, r["total"])            # (the replay packs into the same slab)
+        dist.all_gather_into_tensor(recv, slab)
+        slab_res["regather"] = ("ok",) + tuple(x if isinstance(x, list) else x.numpy().copy() for x in [parallel.parse_slabs(recv, world, 1024)[k] for k in (2, 0, 1)])
+    q.put((rank, r["total"], counts, ids_all.numpy().copy(), mats_all.numpy().copy(), slab_res, cancelled))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -73,10 +98,22 @@ def test_two_rank_allgather_matches_single_process():
     w.cull(cam); full = w.render(cam)
     counts = res[0][2]
     assert counts == [res[0][1], res[1][1]] and sum(counts) == full["total"] and min(counts) > 0
-    for rank, n, cts, ids_all, mats_all in res:
+    for rank, n, cts, ids_all, mats_all, slab_res, cancelled in res:
         assert cts == counts
         np.testing.assert_array_equal(ids_all, res[0][3])            # every rank ends with the same buffer
         np.testing.assert_array_equal(mats_all, res[0][4])
+        # the slab exchange: a slab that fits reproduces the variable-length result; one that does not makes every rank see the overflow in the
+        # headers (true totals) and fall back; a cancelled frame is detected on every rank and gathered again
+        kind, sc, si, sm = slab_res["fits"]
+        assert kind == "ok" and sc == counts
+        np.testing.assert_array_equal(si.astype(np.uint32), res[0][3].astype(np.uint32)); np.testing.assert_array_equal(sm, res[0][4])
+        kind, totals, fi, fm = slab_res["overflow"]
+        assert kind == "overflow" and totals == counts and max(counts) > 100
+        np.testing.assert_array_equal(fi, res[0][3]); np.testing.assert_array_equal(fm, res[0][4])
+        assert cancelled == [1]
+        kind, rc, ri, rm = slab_res["regather"]
+        assert rc == counts
+        np.testing.assert_array_equal(ri.astype(np.uint32), res[0][3].astype(np.uint32)); np.testing.assert_array_equal(rm, res[0][4])
     ids_all, mats_all = res[0][3].astype(np.uint32), res[0][4]
     assert set(ids_all.tolist()) == set(full["ids"].tolist()) and len(ids_all) == full["total"]
     o1, o2 = np.argsort(ids_all), np.argsort(full["ids"])
