@@ -186,6 +186,12 @@ uint32_t    re_abi_version(void);
  * of entities whose AABB is out of bounds (they are not inserted; apply_choices prints an error). */
 int re_upload_entities(re_ctx *ctx, const re_entities *ents, uint32_t *n_rejected);
 
+/* Custom level-of-view bands of one model == register_model_with_render_system(.., custom_level_of_view, ..) (flows/render_flow.rs:1069-1076): instances of
+ * that model take their LOD from these bands instead of the camera's default ones (level_views.custom, render_flow.rs:495-499, 889-893;
+ * ModelId::level_of_view_adjusted_model_index, models/model_definitions.rs:31-59: first band with min <= d <= max, else 7).  At most 8 bands; n_lod == 0
+ * removes the model's bands.  Kept across re_upload_entities, like the model registration itself. */
+int re_set_model_lod(re_ctx *ctx, uint32_t model_index, uint32_t render_system, uint32_t n_lod, const float *lod_min, const float *lod_max);
+
 /* ---- frame ---- */
 int re_cull_pack(re_ctx *ctx, const re_camera *cam, uint32_t flags, re_visible *out);
 int re_tick(re_ctx *ctx, float delta_time, uint32_t flags, re_tick_result *out);

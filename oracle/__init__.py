@@ -263,6 +263,13 @@ class World:
         descs = np.ascontiguousarray(descs, ENTITY_DT)
         return self.L.ro_register_entities(self.h, len(descs), descs.ctypes.data)
 
+    def set_model_lod(self, model_index, render_system, lod_min, lod_max):
+        """custom level-of-view bands of one model (register_model_with_render_system, render_flow.rs:1069-1076)"""
+        lo = np.ascontiguousarray(lod_min, np.float32); hi = np.ascontiguousarray(lod_max, np.float32)
+        self.L.ro_set_model_lod.restype = None
+        self.L.ro_set_model_lod.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        self.L.ro_set_model_lod(self.h, model_index, render_system, len(lo), lo.ctypes.data, hi.ctypes.data)
+
     def tree_add(self, eid, box, add_if_oob=False, is_static=False):
         return self.L.ro_tree_add(self.h, eid, aabb(box), int(add_if_oob), int(is_static))
 

@@ -9,6 +9,7 @@
 #include "re_oracle.h"
 
 #include <math.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
@@ -364,6 +365,20 @@ uint32_t ro_lod_adjusted_model_index(uint32_t model_index, float d, uint32_t n, 
     return model_index | (lod << 25);
 }
 
+/* level_views.custom (flows/render_flow.rs:495-499, 889-893): a model registered with custom_level_of_view uses its own bands, any other the
+ * render system's default bands (the camera's).  Linear table: the sample registers a handful of models. */
+typedef struct { uint32_t model_index, render_system, n; float lmin[8], lmax[8]; } custom_lod_t;
+typedef struct { float one_thread[5]; float total_us; } tth_t;   /* TimeTakeHistory (helper_things/cpu_usage_reducer.rs:30-35) */
+static void tth_init(tth_t *h);
+static const custom_lod_t *custom_lod_find(const custom_lod_t *t, uint32_t nt, uint32_t model_index, uint32_t rs) {
+    for (uint32_t i = 0; i < nt; i++) if (t[i].model_index == model_index && t[i].render_system == rs) return &t[i];
+    return NULL;
+}
+static uint32_t lod_model_index(const custom_lod_t *t, uint32_t nt, const ro_camera *cam, uint32_t model_index, uint32_t rs, float d) {
+    const custom_lod_t *c = nt ? custom_lod_find(t, nt, model_index, rs) : NULL;
+    return c ? ro_lod_adjusted_model_index(model_index, d, c->n, c->lmin, c->lmax) : ro_lod_adjusted_model_index(model_index, d, cam->n_lod, cam->lod_min, cam->lod_max);
+}
+
 /* create_level_of_views (prelude/default_render_system.rs:240-256) */
 void ro_default_lod(float rd, float lmin[5], float lmax[5]) {
     float v1 = rd * 0.10f;
@@ -529,6 +544,8 @@ static void u32vec_push(u32vec *s, uint32_t x) {
 struct ro_world {
     uint32_t outline, atomic;
     int nthreads;
+    custom_lod_t *custom_lod; uint32_t n_custom_lod;         /* level_views.custom: see lod_model_index */
+    tth_t tth_render, tth_positions;                         /* VISIBLE_WORLD_SECTIONS_HISTORY (render_flow.rs:649), POSITION_TIME_HISTORY (logic_flow.rs:356) */
     ent_t *ents; uint32_t ents_cap;
     cell_t *cells; uint32_t ncells_alloc, cells_cap; u32vec cell_free; uint32_t ncells_live;
     kmap cellmap;
@@ -554,6 +571,7 @@ struct ro_world {
 ro_world *ro_world_new(uint32_t outline, uint32_t atomic) {
     ro_world *w = (ro_world *)calloc(1, sizeof(ro_world));
     w->outline = outline; w->atomic = atomic; w->nthreads = 1;
+    tth_init(&w->tth_render); tth_init(&w->tth_positions);
     km_init(&w->cellmap, 1024); km_init(&w->cachemap, 1024); km_init(&w->sharedmap, 256); km_init(&w->changed_cells_map, 256);
     w->shared_order_dirty = 1;
     return w;
@@ -568,7 +586,17 @@ void ro_world_free(ro_world *w) {
     free(w->shared_order); free(w->caches); free(w->vis_vec); free(w->changed_shared.v); free(w->always_exec.v); free(w->marked.v);
     km_free(&w->cellmap); km_free(&w->cachemap); km_free(&w->sharedmap); km_free(&w->changed_cells_map);
     u64set_free(&w->changed_cells); u64set_free(&w->changed_static_unique); u64set_free(&w->vis_map);
+    free(w->custom_lod);
     free(w);
+}
+/* register_model_with_render_system(.., custom_level_of_view, ..) (flows/render_flow.rs:1069-1076): custom bands of one model; n == 0 removes them */
+void ro_set_model_lod(ro_world *w, uint32_t model_index, uint32_t render_system, uint32_t n, const float *lmin, const float *lmax) {
+    custom_lod_t *c = NULL;
+    for (uint32_t i = 0; i < w->n_custom_lod; i++) if (w->custom_lod[i].model_index == model_index && w->custom_lod[i].render_system == render_system) c = &w->custom_lod[i];
+    if (!n) { if (c) { *c = w->custom_lod[--w->n_custom_lod]; } return; }
+    if (!c) { w->custom_lod = (custom_lod_t *)realloc(w->custom_lod, (size_t)(w->n_custom_lod + 1) * sizeof(custom_lod_t)); c = &w->custom_lod[w->n_custom_lod++]; }
+    c->model_index = model_index; c->render_system = render_system; c->n = n > 8 ? 8 : n;
+    for (uint32_t k = 0; k < c->n; k++) { c->lmin[k] = lmin[k]; c->lmax[k] = lmax[k]; }
 }
 static ent_t *ent_slot(ro_world *w, uint32_t id) {
     if (id >= w->ents_cap) {
@@ -1106,6 +1134,81 @@ static void rebuild_static_cache(ro_world *w, const ro_camera *cam) {
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * TimeTakeHistory::apply_to_function (helper_things/cpu_usage_reducer.rs:59-93): the reference's adaptive "one thread for a time budget, then
+ * every thread" schedule of its per-section loops (render_flow.rs:649, logic_flow.rs:356).  The budget is an exponentially weighted mean of
+ * the single-thread times of the last five calls (alpha = 0.6, :5-21), capped at 10 % of the last total (:24, 104-114) -- and end_frame
+ * stores 1000 us for any call that took measurable time (:117-130), so from the second call on the budget is at most 100 us.  The parallel
+ * part is par_chunks(1): one section per task; results are merged under a lock per section, as the reference's Mutex-guarded appends.
+ * ---------------------------------------------------------------------------------------- */
+static double wall_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec * 1e6 + (double)t.tv_nsec * 1e-3; }
+static void tth_init(tth_t *h) { for (int k = 0; k < 5; k++) h->one_thread[k] = 16000.0f * 0.10f; h->total_us = 16000.0f; }
+static float tth_allowed(const tth_t *h) {
+    static const float coef[5] = { 0.6f, 0.6f * 0.4f, 0.6f * 0.4f * 0.4f, 0.6f * 0.4f * 0.4f * 0.4f, 0.6f * 0.4f * 0.4f * 0.4f * 0.4f };
+    float s = 0.0f; for (int k = 0; k < 5; k++) s += h->one_thread[k] * coef[k];
+    const float cap = h->total_us * 0.10f;
+    return s < cap ? s : cap;
+}
+typedef void (*tth_body)(void *ctx, uint32_t i, int parallel_phase);
+static void tth_apply(tth_t *h, int nthreads, uint32_t n, tth_body f, void *ctx) {
+    const double frame0 = wall_us();                                  /* start_frame */
+    uint32_t done = 0;
+    const double t0 = wall_us(); const float maxt = tth_allowed(h);
+    while ((float)floor(wall_us() - t0) < maxt) {                     /* elapsed().as_micros() as f32 */
+        if (done >= n) return;                                        /* (returns without touching the history, like the reference) */
+        f(ctx, done, 0); done++;
+    }
+    for (int k = 4; k > 0; k--) h->one_thread[k] = h->one_thread[k - 1];   /* rotate_right(1) + overwrite [0] */
+    h->one_thread[0] = (float)floor(wall_us() - t0);
+    const long rest = (long)n - (long)done;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) if (nthreads > 1 && rest > 1)
+#endif
+    for (long i = 0; i < rest; i++) f(ctx, done + (uint32_t)i, nthreads > 1);
+    h->total_us = floor(wall_us() - frame0) == 0.0 ? 0.0f : 1000.0f;    /* end_frame (:117-130) */
+}
+
+/* one active visible section of sort_world_section_active_entities (sort_world_chunk -> sort_unique_world_sections + sort_shared_world_sections,
+ * render_flow.rs:718-866) */
+typedef struct { ro_world *w; const ro_camera *cam; const uint64_t *vec; instvec *iv; uint32_t pass; } render_ctx;
+static void render_active_section(void *vctx, uint32_t i, int parallel_phase) {
+    render_ctx *R = (render_ctx *)vctx; ro_world *w = R->w; const ro_camera *cam = R->cam;
+    int32_t ci = cell_find(w, R->vec[i]);
+    if (ci < 0 || w->cells[ci].is_static_section) return;         /* is_section_active (:397-401) */
+    const cell_t *cell = &w->cells[ci];
+    instvec local = { 0 }, *out = parallel_phase ? &local : R->iv;
+    float d = ro_distance_to_aabb(cell->aabb, cam->pos);
+    if (d < cam->far_draw)                                           /* :754 */
+        for (uint32_t k = 0; k < cell->local.n; k++) {
+            const ent_t *e = &w->ents[cell->local.v[k]];
+            if (!e->alive) continue;
+            iv_push(out, lod_model_index(w->custom_lod, w->n_custom_lod, cam, e->model_index, e->render_system, d), e->render_system, e->sortable, cell->local.v[k], e->mat);
+        }
+    for (uint32_t s = 0; s < cell->shared.n; s++) {
+        shared_t *sh = &w->shared[cell->shared.v[s]];
+        int seen;
+#ifdef _OPENMP
+#pragma omp critical(ro_processed_world_sections)
+#endif
+        { seen = sh->stamp == R->pass; sh->stamp = R->pass; }         /* processed_world_sections (:811), a Mutex<HashSet> in the reference */
+        if (seen) continue;
+        float d2 = ro_distance_to_aabb(sh->aabb, cam->pos);
+        if (d2 < cam->far_draw)                                      /* :822 */
+            for (uint32_t k = 0; k < sh->ents.n; k++) {
+                const ent_t *e = &w->ents[sh->ents.v[k]];
+                if (!e->alive) continue;
+                iv_push(out, lod_model_index(w->custom_lod, w->n_custom_lod, cam, e->model_index, e->render_system, d2), e->render_system, e->sortable, sh->ents.v[k], e->mat);
+            }
+    }
+    if (parallel_phase) {                                            /* append_written_information under sorted_data.lock() (:621-623) */
+#ifdef _OPENMP
+#pragma omp critical(ro_sorted_data)
+#endif
+        for (size_t k = 0; k < local.n; k++) iv_push(R->iv, local.v[k].model_index, local.v[k].render_system, local.v[k].sortable, local.v[k].id, local.v[k].mat);
+        free(local.v);
+    }
+}
+
 uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates, uint32_t cap, uint32_t *ids, float *mats,
                          uint32_t gcap, ro_group *groups, uint32_t *n_groups) {
     instvec iv = { 0 };
@@ -1121,33 +1224,12 @@ uint32_t ro_frame_render(ro_world *w, const ro_camera *cam, int emit_duplicates,
         float d = ci >= 0 ? ro_distance_to_aabb(w->cells[ci].aabb, cam->pos) : 0.0f;
         if (d > cam->far_draw) continue;                             /* :489 */
         for (uint32_t k = 0; k < c->n; k++)
-            iv_push(&iv, ro_lod_adjusted_model_index(c->e[k].model_index, d, cam->n_lod, cam->lod_min, cam->lod_max), c->e[k].render_system, c->e[k].sortable, c->e[k].id, c->e[k].mat);
+            iv_push(&iv, lod_model_index(w->custom_lod, w->n_custom_lod, cam, c->e[k].model_index, c->e[k].render_system, d), c->e[k].render_system, c->e[k].sortable, c->e[k].id, c->e[k].mat);
     }
-    /* sort_world_section_active_entities (:603-653) */
-    uint32_t pass = ++w->pass_id;
-    for (uint32_t i = 0; i < nvec; i++) {
-        int32_t ci = cell_find(w, vec[i]);
-        if (ci < 0 || w->cells[ci].is_static_section) continue;     /* is_section_active (:397-401) */
-        const cell_t *cell = &w->cells[ci];
-        float d = ro_distance_to_aabb(cell->aabb, cam->pos);
-        if (d < cam->far_draw)                                       /* :754 */
-            for (uint32_t k = 0; k < cell->local.n; k++) {
-                const ent_t *e = &w->ents[cell->local.v[k]];
-                if (!e->alive) continue;
-                iv_push(&iv, ro_lod_adjusted_model_index(e->model_index, d, cam->n_lod, cam->lod_min, cam->lod_max), e->render_system, e->sortable, cell->local.v[k], e->mat);
-            }
-        for (uint32_t s = 0; s < cell->shared.n; s++) {
-            shared_t *sh = &w->shared[cell->shared.v[s]];
-            if (sh->stamp == pass) continue;                         /* processed_world_sections (:811) */
-            sh->stamp = pass;
-            float d2 = ro_distance_to_aabb(sh->aabb, cam->pos);
-            if (d2 < cam->far_draw)                                  /* :822 */
-                for (uint32_t k = 0; k < sh->ents.n; k++) {
-                    const ent_t *e = &w->ents[sh->ents.v[k]];
-                    if (!e->alive) continue;
-                    iv_push(&iv, ro_lod_adjusted_model_index(e->model_index, d2, cam->n_lod, cam->lod_min, cam->lod_max), e->render_system, e->sortable, sh->ents.v[k], e->mat);
-                }
-        }
+    /* sort_world_section_active_entities (:603-653): the sections through TimeTakeHistory::apply_to_function (:649) */
+    {
+        render_ctx rc = { w, cam, vec, &iv, ++w->pass_id };
+        tth_apply(&w->tth_render, w->nthreads, nvec, render_active_section, &rc);
     }
     /* append + upload (:661-713, :939-992): groups back to back; group order here = ascending
      * (model, render system, sortable) as a deterministic stand-in for HashMap iteration */
@@ -1251,6 +1333,36 @@ static uint32_t update_aabb_after_kinematic_change(ro_world *w, const u32set *on
     return noob - have;
 }
 
+/* one active visible section of update_positions (updated_kinematics_fn, logic_flow.rs:321-354); the change requests go to one list under a lock
+ * (expected_frame_changes.lock().push, :403, :437) */
+typedef struct { ro_world *w; float dt; changevec *cv; uint32_t pass; } tick_ctx;
+static void tick_active_section(void *vctx, uint32_t i, int parallel_phase) {
+    tick_ctx *T = (tick_ctx *)vctx; ro_world *w = T->w;
+    int32_t ci = cell_find(w, w->vis_map.v[i]);
+    if (ci < 0 || w->cells[ci].is_static_section) return;         /* :216-223 */
+    const cell_t *cell = &w->cells[ci];
+    changevec local = { 0 }, *out = parallel_phase ? &local : T->cv;
+    for (uint32_t k = 0; k < cell->local.n; k++) apply_kinematics_one(w, cell->local.v[k], T->dt, out);
+    for (uint32_t s = 0; s < cell->shared.n; s++) {
+        shared_t *sh = &w->shared[cell->shared.v[s]];
+        int seen;
+#ifdef _OPENMP
+#pragma omp critical(ro_processed_world_sections)
+#endif
+        { seen = sh->stamp == T->pass; sh->stamp = T->pass; }
+        if (seen) continue;
+        if (ro_logic_aabb_in_view(w->lookahead, w->campos, sh->aabb) || ro_frustum_aabb_visible(w->planes, sh->aabb))   /* :338-339 */
+            for (uint32_t k = 0; k < sh->ents.n; k++) apply_kinematics_one(w, sh->ents.v[k], T->dt, out);
+    }
+    if (parallel_phase) {
+#ifdef _OPENMP
+#pragma omp critical(ro_expected_frame_changes)
+#endif
+        for (size_t k = 0; k < local.n; k++) { if (T->cv->n == T->cv->cap) { T->cv->cap = T->cv->cap ? T->cv->cap * 2 : 64; T->cv->v = (change_t *)realloc(T->cv->v, T->cv->cap * sizeof(change_t)); } T->cv->v[T->cv->n++] = local.v[k]; }
+        free(local.v);
+    }
+}
+
 uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob) {
     (void)cam;
     changevec cv = { 0 };
@@ -1260,19 +1372,9 @@ uint32_t ro_frame_tick(ro_world *w, const ro_camera *cam, float dt, uint32_t cap
     w->marked.n = 0;
     /* update_positions over the active visible sections.  Set semantics: a section visited twice
      * (duplicate in visible_sections_vec) yields an identical, idempotent change request. */
-    uint32_t pass = ++w->pass_id;
-    for (uint32_t i = 0; i < w->vis_map.n; i++) {
-        int32_t ci = cell_find(w, w->vis_map.v[i]);
-        if (ci < 0 || w->cells[ci].is_static_section) continue;     /* :216-223 */
-        const cell_t *cell = &w->cells[ci];
-        for (uint32_t k = 0; k < cell->local.n; k++) apply_kinematics_one(w, cell->local.v[k], dt, &cv);
-        for (uint32_t s = 0; s < cell->shared.n; s++) {
-            shared_t *sh = &w->shared[cell->shared.v[s]];
-            if (sh->stamp == pass) continue;
-            sh->stamp = pass;
-            if (ro_logic_aabb_in_view(w->lookahead, w->campos, sh->aabb) || ro_frustum_aabb_visible(w->planes, sh->aabb))   /* :338-339 */
-                for (uint32_t k = 0; k < sh->ents.n; k++) apply_kinematics_one(w, sh->ents.v[k], dt, &cv);
-        }
+    {   /* the sections through TimeTakeHistory::apply_to_function (logic_flow.rs:356) */
+        tick_ctx tc = { w, dt, &cv, ++w->pass_id };
+        tth_apply(&w->tth_positions, w->nthreads, w->vis_map.n, tick_active_section, &tc);
     }
     /* find_always_execute_entities (:803-836) + apply_kinematics(always_execute_entities) (:357) */
     for (uint32_t i = 0; i < w->always_exec.n; i++) {

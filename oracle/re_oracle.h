@@ -124,6 +124,7 @@ void     ro_look_at(const float eye[3], const float target[3], const float up[3]
 /* ---- world (BoundingBoxTree + the ECS columns the hot path reads) ---- */
 ro_world *ro_world_new(uint32_t outline, uint32_t atomic);
 void      ro_world_free(ro_world *w);
+void      ro_set_model_lod(ro_world *w, uint32_t model_index, uint32_t render_system, uint32_t n, const float *lmin, const float *lmax); /* level_views.custom, render_flow.rs:889-893 */
 void      ro_set_threads(ro_world *w, int nthreads);        /* rayon pool size for the par_chunks sites */
 
 /* Pipeline::register_model_instances (pipeline.rs:186-208): create n entities, apply_choices,

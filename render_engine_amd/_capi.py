@@ -89,7 +89,7 @@ class Lights(C.Structure):
 
 
 # every symbol include/re_hip.h declares
-EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_cull_pack", "re_tick",
+EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_set_model_lod", "re_cull_pack", "re_tick",
            "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
@@ -134,6 +134,7 @@ def load():
     L.re_last_error.restype = C.c_char_p; L.re_last_error.argtypes = [vp]
     L.re_abi_version.restype = C.c_uint32; L.re_abi_version.argtypes = []
     L.re_upload_entities.restype = C.c_int; L.re_upload_entities.argtypes = [vp, C.POINTER(Entities), _u32p]
+    L.re_set_model_lod.restype = C.c_int; L.re_set_model_lod.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, _fp, _fp]
     L.re_cull_pack.restype = C.c_int; L.re_cull_pack.argtypes = [vp, C.POINTER(CameraC), C.c_uint32, C.POINTER(Visible)]
     L.re_tick.restype = C.c_int; L.re_tick.argtypes = [vp, C.c_float, C.c_uint32, C.POINTER(TickResult)]
     L.re_wait.restype = C.c_int; L.re_wait.argtypes = [vp, C.POINTER(Visible), C.POINTER(TickResult)]

@@ -127,6 +127,10 @@ struct re_ctx {
     // large visible sets, group tables of <= COUNT_SLOTS_MAX slots: instance counts / running fills per (cursor shard, group slot), two parities alternating by
     // large-pack frame.  k_pack_large of one frame clears the other parity's arrays for the next; `dirty` tracks arrays that hold something nobody will clear.
     DevBuf<uint32_t> d_gcount, d_gfill; bool gc_dirty[2] = { false, false }; uint32_t large_seq = 0;
+    // per-model level-of-view bands (level_views.custom): kept across uploads, like a model registration; device tables rebuilt when they or the group classes change
+    struct CustomLod { uint32_t model, rs, n; float lmin[8], lmax[8]; };
+    std::vector<CustomLod> custom_lod; std::vector<GroupKey> h_gkeys;
+    DevBuf<uint32_t> d_gc_lodtab, d_lod_n; DevBuf<float> d_lod_min, d_lod_max; bool lod_tables_on = false;
     // frame
     uint32_t frame = 0; bool have_cull = false;
     DevBuf<uint32_t> d_rows_gc; std::vector<uint32_t> h_sh_begin;   // group class per row-pool entry; pool offsets of the shared sections' members
@@ -542,6 +546,26 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     return RE_OK;
 }
 
+static int resolve(re_ctx *c);
+// device tables of the per-model level-of-view bands: table 0 = "default bands", table t >= 1 = custom_lod[t - 1]; one table index per group class
+static int upload_lod_tables(re_ctx *c) {
+    c->lod_tables_on = false;
+    if (c->custom_lod.empty() || !c->ngclass) return RE_OK;
+    std::vector<uint32_t> tab(c->ngclass, 0u), ln(c->custom_lod.size() + 1, 0u); std::vector<float> lmin((c->custom_lod.size() + 1) * 8, 0.f), lmax((c->custom_lod.size() + 1) * 8, 0.f);
+    bool any = false;
+    for (size_t t = 0; t < c->custom_lod.size(); t++) {
+        const auto &x = c->custom_lod[t];
+        ln[t + 1] = x.n; for (int k = 0; k < 8; k++) { lmin[(t + 1) * 8 + k] = x.lmin[k]; lmax[(t + 1) * 8 + k] = x.lmax[k]; }
+        for (uint32_t g = 0; g < c->ngclass; g++) if (c->h_gkeys[g].model == x.model && c->h_gkeys[g].rs == x.rs) { tab[g] = (uint32_t)t + 1u; any = true; }
+    }
+    if (!any) return RE_OK;
+    HIPCHK(c, c->d_gc_lodtab.alloc(tab.size(), nullptr)); HIPCHK(c, c->d_lod_n.alloc(ln.size(), nullptr)); HIPCHK(c, c->d_lod_min.alloc(lmin.size(), nullptr)); HIPCHK(c, c->d_lod_max.alloc(lmax.size(), nullptr));
+    HIPCHK(c, hipMemcpy(c->d_gc_lodtab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->d_lod_n.p, ln.data(), ln.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_lod_min.p, lmin.data(), lmin.size() * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->d_lod_max.p, lmax.data(), lmax.size() * 4, hipMemcpyHostToDevice));
+    c->lod_tables_on = true;
+    return RE_OK;
+}
+
 extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_rejected) {
     if (!c) return RE_E_ARG;
     if (!E || (E->n && (!E->entity_id || !E->model_index || !E->flags || !E->original_aabb || !E->position))) return c->fail(RE_E_ARG, "re_upload_entities: missing required array");
@@ -619,7 +643,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->d_row_moved.release(nullptr); c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->col_moved_cap = 0;
     for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
     c->ndyn = (uint32_t)dyn_row.size();
-    c->ngclass = (uint32_t)gkeys.size(); c->nslots = c->ngclass * 8u;
+    c->ngclass = (uint32_t)gkeys.size(); c->nslots = c->ngclass * 8u; c->h_gkeys = gkeys;
     hipStream_t st = c->stream;
     c->ghost_cap = std::max(2048u, n / 8u);   // ghost instances of the frozen static cache (68 bytes each) c->n_ghost = 0; c->h_ghost_gc.clear(); c->ghost_map.clear(); c->dormant_cached.clear();
     HIPCHK(c, c->d_id.alloc((size_t)n + c->ghost_cap, acct)); HIPCHK(c, c->d_gclass.alloc(n, acct)); HIPCHK(c, c->d_flags.alloc(n, acct)); HIPCHK(c, c->d_mat.alloc(((size_t)n + c->ghost_cap) * 16, acct));
@@ -715,7 +739,23 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->frame = 0; c->lane_seq = 0; c->th_clean = true; c->pred_total = 0;
-    return RE_OK;
+    return upload_lod_tables(c);
+}
+
+// level_views.custom (flows/render_flow.rs:495-499, 889-893; registered by register_model_with_render_system :1069-1076): a model with custom_level_of_view
+// uses its own bands instead of the render system's default ones.  n == 0 removes a model's bands.
+extern "C" int re_set_model_lod(re_ctx *c, uint32_t model_index, uint32_t render_system, uint32_t n_lod, const float *lod_min, const float *lod_max) {
+    if (!c || (n_lod && (!lod_min || !lod_max))) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->h_res) { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
+    auto it = std::find_if(c->custom_lod.begin(), c->custom_lod.end(), [&](const re_ctx::CustomLod &x) { return x.model == model_index && x.rs == render_system; });
+    if (!n_lod) { if (it != c->custom_lod.end()) c->custom_lod.erase(it); }
+    else {
+        if (it == c->custom_lod.end()) { c->custom_lod.push_back(re_ctx::CustomLod{}); it = c->custom_lod.end() - 1; }
+        it->model = model_index; it->rs = render_system; it->n = std::min(n_lod, 8u);
+        for (uint32_t k = 0; k < 8; k++) { it->lmin[k] = k < it->n ? lod_min[k] : 0.f; it->lmax[k] = k < it->n ? lod_max[k] : 0.f; }
+    }
+    return c->h_res ? upload_lod_tables(c) : RE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -846,7 +886,9 @@ static FrameHeader *frame_header(re_ctx *c, uint32_t frame) { return c->d_hdr.p 
 static ItemSink item_sink(re_ctx *c, uint32_t frame) {
     const size_t half = (size_t)(frame & 1u) * c->item_cap;
     ItemSink K; K.item_row = c->d_item_row.p + half; K.item_slot = c->d_item_slot.p + half; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
-    K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0; return K;
+    K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0;
+    K.gc_lodtab = c->lod_tables_on ? c->d_gc_lodtab.p : nullptr; K.lod_n = c->d_lod_n.p; K.lod_min = c->d_lod_min.p; K.lod_max = c->d_lod_max.p;
+    return K;
 }
 static SharedArrays shared_arrays(re_ctx *c) {
     SharedArrays S; S.n = c->nsh; S.cells = c->d_sh_cells.p; S.aabb = c->d_sh_aabb.p; S.begin = c->d_sh_begin.p; S.nact = c->d_sh_nact.p; S.nstat = c->d_sh_nstat.p;

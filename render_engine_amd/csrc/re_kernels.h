@@ -119,6 +119,8 @@ struct ItemSink {
     uint32_t *item_row, *item_slot; uint32_t item_cap;
     uint32_t nshards, seg_cap;              // instance list = nshards segments of seg_cap slots, one cursor each
     const uint32_t *rows, *rows_gc;         // the row pool and, entry for entry, the row's group class (0xFFFFFFFF: not drawn -- removed or hidden)
+    const uint32_t *gc_lodtab; const uint32_t *lod_n; const float *lod_min, *lod_max;   // per-model level-of-view bands (level_views.custom, render_flow.rs:889-893): band table of each
+                                            // group class (0: the camera's default bands), tables of 8 bands each; nullptr while no model has custom bands
     uint32_t *group_count; uint32_t count_nslots;   // large visible sets: the expansion also counts the instances per (cursor shard, group slot) -- [nshards][count_nslots],
                                             // through a per-wave LDS histogram flushed once per wave -- so that the pack needs no counting pass (nullptr / 0: off)
 };

@@ -166,15 +166,18 @@ constexpr uint32_t EMIT_MAX = 4u;                              // sections one l
 // row0 / gc0: entry rb of the pool, fetched by the caller ahead of the cursor atomic (k == 0 when first == 0)
 // hist: the wave's LDS histogram of group slots (in-scan counting, see ItemSink), or nullptr: then a counting frame adds straight to
 // K.group_count[shard][slot] (the few instances of shared sections)
+// dist: the section's distance (LOD input); only read for group classes with custom level-of-view bands (K.gc_lodtab)
 __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t first, uint32_t stride, uint32_t n, uint32_t off, uint32_t lod, uint32_t seg_base, const ItemSink &K,
-                                            uint32_t *hist, uint32_t shard, bool have0 = false, uint32_t row0 = 0, uint32_t gc0 = 0) {
+                                            uint32_t *hist, uint32_t shard, float dist, bool have0 = false, uint32_t row0 = 0, uint32_t gc0 = 0) {
     for (uint32_t k = first; k < n; k += stride) {
         uint32_t t = off + k;
         if (t < K.seg_cap) {
             const uint32_t e = rb + (k % cnt);
             const bool pre = have0 && e == rb;
             const uint32_t row = pre ? row0 : K.rows[e], gc = pre ? gc0 : K.rows_gc[e];
-            const uint32_t slot = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod;
+            uint32_t lod_e = lod;
+            if (K.gc_lodtab && gc != 0xFFFFFFFFu) { const uint32_t tb = K.gc_lodtab[gc]; if (tb) lod_e = lod_index(dist, K.lod_n[tb], K.lod_min + tb * 8u, K.lod_max + tb * 8u); }   // level_views.custom
+            const uint32_t slot = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod_e;
             K.item_row[seg_base + t] = row; K.item_slot[seg_base + t] = slot;
             if (K.group_count && slot < K.count_nslots) { if (hist) atomicAdd(&hist[slot], 1u); else atomicAdd(&K.group_count[shard * K.count_nslots + slot], 1u); }
         }
@@ -183,8 +186,11 @@ __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t 
 
 // Every lane brings up to EMIT_MAX visible sections {row range, count, lod | multiplicity << 8}.  ONE 64-bit
 // atomic per call reserves their instances.
+// dist_lds: with custom level-of-view bands, the distance of the section in slot j of lane l at dist_lds[j * 64 + l] (wave-private LDS, float bits), so that no
+// register stays live for it across the reservation; dist0: the same for callers that hold one section per lane in registers (shared sections)
 __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MAX], const uint32_t (&cnt)[EMIT_MAX], const uint32_t (&lodm)[EMIT_MAX],
-                                                    FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint, uint32_t *hist = nullptr) {
+                                                    FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint, uint32_t *hist = nullptr,
+                                                    const uint32_t *dist_lds = nullptr, float dist0 = 0.0f) {
     uint32_t mine = 0, nsec = 0;
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) { uint32_t n = cnt[j] * ((lodm[j] >> 8) & 3u); mine += n; nsec += n ? 1u : 0u; }
@@ -206,19 +212,20 @@ __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MA
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) {
         const uint32_t m = (lodm[j] >> 8) & 3u, lod = lodm[j] & 7u, n = cnt[j] * m;
-        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K, hist, shard, true, row0[j], gc0[j]);
+        const float dj = (!K.gc_lodtab || !n) ? 0.0f : (dist_lds ? __uint_as_float(dist_lds[j * 64u + lane_id()]) : dist0);
+        if (n && n <= WIDE) expand_rows(rb[j], cnt[j], 0u, 1u, n, off, lod, seg_base, K, hist, shard, dj, true, row0[j], gc0[j]);
         uint64_t wide = __ballot(n > WIDE);
         while (wide) {                                          // wave-cooperative expansion of crowded sections
             int src = __ffsll((long long)wide) - 1; wide &= wide - 1;
-            expand_rows(__shfl(rb[j], src, 64), __shfl(cnt[j], src, 64), lane_id(), 64u, __shfl(n, src, 64), __shfl(off, src, 64), __shfl(lod, src, 64), seg_base, K, hist, shard);
+            expand_rows(__shfl(rb[j], src, 64), __shfl(cnt[j], src, 64), lane_id(), 64u, __shfl(n, src, 64), __shfl(off, src, 64), __shfl(lod, src, 64), seg_base, K, hist, shard, __shfl(dj, src, 64));
         }
         off += n;
     }
 }
-__device__ __forceinline__ void emit_sections(uint32_t rb0, uint32_t cnt0, uint32_t lodm0, FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint) {
+__device__ __forceinline__ void emit_sections(uint32_t rb0, uint32_t cnt0, uint32_t lodm0, FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint, float dist) {
     uint32_t rb[EMIT_MAX] = {}, cnt[EMIT_MAX] = {}, lodm[EMIT_MAX] = {};
     rb[0] = rb0; cnt[0] = cnt0; lodm[0] = lodm0;
-    emit_sections_multi(rb, cnt, lodm, hdr, K, shard_hint);
+    emit_sections_multi(rb, cnt, lodm, hdr, K, shard_hint, nullptr, nullptr, dist);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,10 +460,11 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
                                 cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
                                 uint32_t mm = P.emit_duplicates ? mult : 1u;
                                 lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
+                                if (K.gc_lodtab) q_key[j * 64u + lane] = __float_as_uint(d);       // (the keys are no longer needed: stage A is done)
                             }
                         }
                     }
-                    emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, hist);     // one reservation per slice of 256 visible sections
+                    emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, hist, K.gc_lodtab ? q_key : nullptr);     // one reservation per slice of 256 visible sections
                 }
                 if (hist && nv) {                                           // flush: one atomic per non-empty group slot and wave, into the counts of this wave's cursor shard
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -617,10 +625,11 @@ __global__ __launch_bounds__(CULL_THREADS) void k_probe_cull(ProbeArgs Q, ScanCu
                             cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
                             uint32_t mm = P.emit_duplicates ? mult : 1u;
                             lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
+                            if (K.gc_lodtab) q_key[j * 64u + lane] = __float_as_uint(d);
                         }
                     }
                 }
-                emit_sections_multi(rbv, cntv, lodv, hdr, K, wave);
+                emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, nullptr, K.gc_lodtab ? q_key : nullptr);
             }
             for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); cand_acc += __shfl_down(cand_acc, d, 64); }
             if (lane == 0) {
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(CULL_THREADS) void k_probe_cull(ProbeArgs Q, ScanCu
 // Called by whole waves (lanes with s >= S.n contribute nothing).
 __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArrays &S, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
                                                     const Aabb *__restrict__ cell_tight, const ItemSink &K, FrameHeader *hdr, const FrameParams &P) {
-    uint32_t rbA = 0, cntA = 0, lodA = 0, rbS = 0, cntS = 0, lodS = 0;
+    uint32_t rbA = 0, cntA = 0, lodA = 0, rbS = 0, cntS = 0, lodS = 0; float distA = 0.0f, distS = 0.0f;
     if (s < S.n) {
         bool act = false;
         uint32_t na = S.nact[s], ns = S.nstat[s], b = S.begin[s];
@@ -659,20 +668,20 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
             }
         if (act) {
             float d2 = distance_to_aabb(S.aabb[s], P.cam[0], P.cam[1], P.cam[2]);
-            if (d2 < P.far_draw) { rbA = b; cntA = na; lodA = lod_index(d2, P.n_lod, P.lod_min, P.lod_max) | (1u << 8); }
+            if (d2 < P.far_draw) { rbA = b; cntA = na; lodA = lod_index(d2, P.n_lod, P.lod_min, P.lod_max) | (1u << 8); distA = d2; }
         }
         int32_t ow = S.owner[s];
         if (ns && ow >= 0 && S.cached[s]) {
             uint32_t mult = section_multiplicity(cell_key[ow], P, nullptr);
             if (mult) {
                 float d = distance_to_aabb(cell_tight[ow], P.cam[0], P.cam[1], P.cam[2]);      // extract_static_data uses the unique section's distance
-                if (!(d > P.far_draw)) { rbS = b + na; cntS = ns; uint32_t m = P.emit_duplicates ? mult : 1u; lodS = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8); }
+                if (!(d > P.far_draw)) { rbS = b + na; cntS = ns; uint32_t m = P.emit_duplicates ? mult : 1u; lodS = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (m << 8); distS = d; }
             }
         }
     }
     const uint32_t hint = __builtin_amdgcn_readfirstlane(s) >> 6;
-    emit_sections(rbA, cntA, lodA, hdr, K, hint);                 // active members
-    emit_sections(rbS, cntS, lodS, hdr, K, hint + 1u);            // static members
+    emit_sections(rbA, cntA, lodA, hdr, K, hint, distA);          // active members
+    emit_sections(rbS, cntS, lodS, hdr, K, hint + 1u, distS);     // static members
 }
 
 

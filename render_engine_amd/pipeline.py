@@ -178,6 +178,11 @@ class Pipeline:
         self._check(self._L.re_upload_entities(self._h, C.byref(E), C.byref(rej)), "re_upload_entities")
         return rej.value
 
+    def set_model_lod(self, model_index, render_system, lod_min, lod_max):
+        """custom level-of-view bands of one model (register_model_with_render_system(.., custom_level_of_view, ..), render_flow.rs:1069-1076)"""
+        lo = np.ascontiguousarray(lod_min, np.float32); hi = np.ascontiguousarray(lod_max, np.float32)
+        self._check(self._L.re_set_model_lod(self._h, model_index, render_system, len(lo), lo.ctypes.data_as(C.POINTER(C.c_float)), hi.ctypes.data_as(C.POINTER(C.c_float))), "re_set_model_lod")
+
     # -- Pipeline::execute, split at the reference's own seams -----------------------------------
     def cull_and_pack(self, camera, emit_duplicates=False, asynchronous=False, copy=True, force_large_pack=False, defer_pack=False, two_lanes=False):
         """pipeline.rs:216-229 + render_flow.rs:401-410.  Returns dict(total, ids, mats, groups, ...)."""

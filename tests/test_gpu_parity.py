@@ -219,6 +219,30 @@ def test_large_pack_paths_by_group_table_size(R):
         p.close(); w.close()
 
 
+def test_per_model_level_of_view_bands(R):
+    """level_views.custom (render_flow.rs:495-499, 889-893): models registered with custom bands take their LOD from those, the others from the camera's
+    default bands -- active entities, the static cache, shared sections, both pack paths; bands that leave gaps fall back to LOD 7"""
+    ents = R.synthetic.mixed_world(5000, seed=5, spread=600.0)
+    p, w = build_pair(R, ents)
+    bands = {(1, 0): ([0, 150, 300], [150, 300, 450]),                     # gaps beyond 450 -> LOD 7
+             (3, 1): ([0, 40, 90, 200, 420, 650, 800, 900], [40, 90, 200, 420, 650, 800, 900, 5000]),
+             (4, 0): ([100], [250])}                                        # a single band that most distances miss
+    for (m, rs), (lo, hi) in bands.items():
+        p.set_model_lod(m, rs, lo, hi); w.set_model_lod(m, rs, lo, hi)
+    cams = [R.Camera((8192, 8192, 9000), (0, 0, -1), 1500.0), R.Camera((8000, 8300, 8700), (0.3, -0.1, -1), 900.0)]
+    for f, cam in enumerate(cams * 2):
+        g, o = check_frame(R, p, w, cam, bool(f & 1), force_large_pack=f >= 2)
+        n_o, oob = w.tick(oracle_camera(cam), 0.03); t = p.tick(0.03)
+        assert t["n_changed"] == n_o
+    lods = {(int(m) & 0x1FFFFFF, int(rs)): set() for m, rs in zip(g["groups"]["model_index"], g["groups"]["render_system"])}
+    for m, rs in zip(g["groups"]["model_index"], g["groups"]["render_system"]):
+        lods[(int(m) & 0x1FFFFFF, int(rs))].add(int(m) >> 25)
+    assert 7 in lods[(1, 0)] and max(lods[(3, 1)]) >= 5                      # the custom tables were in effect
+    p.set_model_lod(1, 0, [], []); w.set_model_lod(1, 0, [], [])             # removing a model's bands returns it to the default ones
+    check_frame(R, p, w, cams[0], False)
+    p.close(); w.close()
+
+
 def test_async_frames_match_sync(R):
     ents = R.synthetic.lattice_world(cells_per_axis=32, first_cell=112, spinner_every=5)
     p, w = build_pair(R, ents)
