@@ -394,6 +394,37 @@ int re_lighting_run(re_lighting *l, float *kernel_microseconds /* nullable */); 
 int re_lighting_read(re_lighting *l, float *out_rgba);                                 /* width*height*4 floats */
 int re_lighting_read_pixels(re_lighting *l, const uint32_t *pixel_index, uint32_t n, float *out_rgba);
 
+/* ---- history / replay wire format ----
+ * The per-frame FrameChange records of the history thread (threads/public_common_structures.rs:7-16), written with bincode 1.3 as
+ * threads/history_thread.rs:150-205 does: gameplay_history.txt = bincode(ECS) | bincode(BoundingBoxTree) | bincode(FrameChange)*, and
+ * gameplay_byte_lookup.txt = the byte length of every blob, one decimal number per line; read back as GameLoadResult::load does
+ * (helper_things/game_loader.rs:32-71: the LAST line of the lookup file is the empty string after the final newline and is skipped).
+ * Host code only.  The first two blobs are carried as opaque bytes (this library's state is SoA columns, not the reference's hash maps).
+ * TypeIdentifier values are std::any::TypeId bits of one build of the reference (objects/ecs.rs:92-110): the host passes the ids of the
+ * components this path carries. */
+typedef struct re_history re_history;
+typedef struct re_type_ids { uint64_t position, rotation, scale, velocity, acceleration, rotation_velocity, rotation_acceleration, has_moved, has_rotated; } re_type_ids;
+#define RE_FC_CAMERA_VIEW_CHANGE        0u  /* f[0..2] = position, f[3..5] = direction (SerializableCameraInfo, exports/camera_object.rs:47-53) */
+#define RE_FC_CAMERA_STATIONARY         1u
+#define RE_FC_DELTA_TIME                2u  /* f[0] */
+#define RE_FC_DRAW_DISTANCES_CHANGE     3u  /* f[0..2] = near, far, fov */
+#define RE_FC_WINDOW_DIMENSIONS_CHANGE  4u  /* i[0..1] = width, height */
+#define RE_FC_ENTITY_CHANGE             5u  /* changes[0..n_changes): Vec<EntityChangeInformation>, the variants re_apply_changes knows */
+#define RE_FC_END_FRAME_CHANGE          6u
+typedef struct re_frame_change { uint32_t kind; float f[6]; int32_t i[2]; uint32_t n_changes; const re_change *changes; } re_frame_change;
+#define RE_HISTORY_VEC3_AS_ARRAY 1u         /* TVec3 as 12 bytes instead of a serde sequence (u64 count + 12 bytes); see re_history.cpp */
+int         re_history_create(const re_type_ids *ids, uint32_t flags, re_history **out);
+void        re_history_destroy(re_history *h);
+const char *re_history_last_error(const re_history *h /* NULL: the error of a failed re_history_load */);
+int re_history_set_state(re_history *h, const void *ecs_blob, uint64_t ecs_bytes, const void *tree_blob, uint64_t tree_bytes);
+int re_history_get_state(re_history *h, const void **ecs_blob, uint64_t *ecs_bytes, const void **tree_blob, uint64_t *tree_bytes);
+int re_history_record(re_history *h, const re_frame_change *fc);                     /* appends a copy (incl. the change list) */
+int re_history_count(re_history *h, uint32_t *n);
+int re_history_get(re_history *h, uint32_t index, re_frame_change *out);             /* out->changes points into the history object */
+int re_history_encode(re_history *h, uint32_t index, uint8_t *dst /*nullable*/, uint64_t capacity, uint64_t *n_bytes);   /* one record's bincode bytes */
+int re_history_write(re_history *h, const char *history_path, const char *lookup_path);
+int re_history_load(const re_type_ids *ids, uint32_t flags, const char *history_path, const char *lookup_path, re_history **out);
+
 #ifdef __cplusplus
 }
 #endif

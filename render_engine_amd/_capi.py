@@ -57,6 +57,18 @@ ECS_BIT = dict(TYPE_IDENTIFIER=0, CAN_CAUSE_COLLISIONS=2, HAS_MOVED=3, POSITION=
                ACCELERATION_ROTATION=10, SCALE=11, TRANSFORMATION=12, MODEL_ID=13, STATIC_AABB=15, ORIGINAL_AABB=16, ALWAYS_EXECUTE_LOGIC=20)
 
 
+class TypeIds(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("position", "rotation", "scale", "velocity", "acceleration", "rotation_velocity", "rotation_acceleration", "has_moved", "has_rotated")]
+
+
+class FrameChange(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("f", C.c_float * 6), ("i", C.c_int32 * 2), ("n_changes", C.c_uint32), ("changes", C.c_void_p)]
+
+
+FC = dict(CAMERA_VIEW_CHANGE=0, CAMERA_STATIONARY=1, DELTA_TIME=2, DRAW_DISTANCES_CHANGE=3, WINDOW_DIMENSIONS_CHANGE=4, ENTITY_CHANGE=5, END_FRAME_CHANGE=6)
+HISTORY_VEC3_AS_ARRAY = 1
+
+
 class TickResult(C.Structure):
     _fields_ = [("n_changed", C.c_uint32), ("n_rebucket", C.c_uint32), ("n_out_of_bounds", C.c_uint32)]
 
@@ -94,7 +106,9 @@ EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upl
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
-           "re_lighting_run", "re_lighting_read", "re_lighting_read_pixels"]
+           "re_lighting_run", "re_lighting_read", "re_lighting_read_pixels",
+           "re_history_create", "re_history_destroy", "re_history_last_error", "re_history_set_state", "re_history_get_state", "re_history_record",
+           "re_history_count", "re_history_get", "re_history_encode", "re_history_write", "re_history_load"]
 
 _lib = None
 _hip = None
@@ -170,5 +184,16 @@ def load():
     L.re_lighting_run.restype = C.c_int; L.re_lighting_run.argtypes = [vp, _fp]
     L.re_lighting_read.restype = C.c_int; L.re_lighting_read.argtypes = [vp, vp]
     L.re_lighting_read_pixels.restype = C.c_int; L.re_lighting_read_pixels.argtypes = [vp, vp, C.c_uint32, vp]
+    L.re_history_create.restype = C.c_int; L.re_history_create.argtypes = [C.POINTER(TypeIds), C.c_uint32, C.POINTER(vp)]
+    L.re_history_destroy.restype = None; L.re_history_destroy.argtypes = [vp]
+    L.re_history_last_error.restype = C.c_char_p; L.re_history_last_error.argtypes = [vp]
+    L.re_history_set_state.restype = C.c_int; L.re_history_set_state.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+    L.re_history_get_state.restype = C.c_int; L.re_history_get_state.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp), C.POINTER(C.c_uint64)]
+    L.re_history_record.restype = C.c_int; L.re_history_record.argtypes = [vp, C.POINTER(FrameChange)]
+    L.re_history_count.restype = C.c_int; L.re_history_count.argtypes = [vp, _u32p]
+    L.re_history_get.restype = C.c_int; L.re_history_get.argtypes = [vp, C.c_uint32, C.POINTER(FrameChange)]
+    L.re_history_encode.restype = C.c_int; L.re_history_encode.argtypes = [vp, C.c_uint32, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.re_history_write.restype = C.c_int; L.re_history_write.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.re_history_load.restype = C.c_int; L.re_history_load.argtypes = [C.POINTER(TypeIds), C.c_uint32, C.c_char_p, C.c_char_p, C.POINTER(vp)]
     _lib = L
     return L
