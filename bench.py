@@ -109,6 +109,18 @@ def pipelined_frames(p, camc, n, tick_all=False):
     return (time.perf_counter() - t0) / n
 
 
+def launch_us(p, camc, kernel, n, pipelined, tick_all=False):
+    """mean duration of one kernel's own launches (HIP events tied to the dispatch, re_timing_begin) over n synchronous or asynchronous frames"""
+    p.wait()
+    p.timing_begin(n, 1, kernel=kernel)
+    if pipelined:
+        pipelined_frames(p, camc, n, tick_all)
+    else:
+        sync_frames(p, camc, n, tick_all)
+    us = p.timing_collect()
+    return float(np.mean(us)) if len(us) else None
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -326,6 +338,8 @@ def far_leg(R, ents, atomic, centre, n_total, key_bytes):
     us, vis, _ = sync_frames(p, cam, 48)
     kt = kernel_times(p, cam, 12)
     per = pipelined_frames(p, cam, 16); per = pipelined_frames(p, cam, 64)
+    own = {"k_scan_cull": {"sync_frames": launch_us(p, cam, "scan", 48, False), "async_frames": launch_us(p, cam, "scan", 96, True)},
+           "k_pack_large": {"sync_frames": launch_us(p, cam, "pack_large", 48, False), "async_frames": launch_us(p, cam, "pack_large", 96, True)}}
     V, S, slots = vis["total"], vis["n_visible_sections"], stats["n_section_slots"]
     b_scan = key_bytes * slots + 4 * ((slots + 511) // 512) + 41 * S + 16 * V
     b_pack = (8 + 4 + 64 + 68) * V               # list entry + id + matrix read, id + matrix written
@@ -335,6 +349,7 @@ def far_leg(R, ents, atomic, centre, n_total, key_bytes):
             "frame_ms_median_sync": float(np.median(us)) * 1e-3, "entities_per_s_sync": n_total / (float(np.median(us)) * 1e-6),
             "pipelined_ms_per_frame": per * 1e3, "entities_per_s_pipelined": n_total / per,
             "kernel_us": kt,
+            "launch_us": dict(own, note="each kernel's own launches (dispatch-bound HIP events); kernel_us = event pairs around the calls of synchronous frames"),
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                          "scan": {"kernel": "k_scan_cull", "us": kt["cull"], "bytes_compulsory": b_scan, "frac": b_scan / (kt["cull"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["cull"] > 0 else None},
                          "pack": {"kernel": "instance pack (large path)", "us": kt["pack"], "bytes_compulsory": b_pack, "frac": b_pack / (kt["pack"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["pack"] > 0 else None},
@@ -366,14 +381,19 @@ def spinner_leg(R, a, atomic):
         sync_frames(p, camc, 6, tick_all)
         us, vis, tr = sync_frames(p, camc, 40, tick_all)
         kt = kernel_times(p, camc, 10, tick_all)
-        per = pipelined_frames(p, camc, 8, tick_all); per = pipelined_frames(p, camc, 48, tick_all)
+        per = pipelined_frames(p, camc, 8, tick_all); per = pipelined_frames(p, camc, 200, tick_all)
+        t_sync, t_async = launch_us(p, camc, "tick", 40, False, tick_all), launch_us(p, camc, "tick", 200, True, tick_all)
         med = float(np.median(us))
         out[name] = {"camera": "far=%g%s" % (cam.far_draw_distance, ", every dynamic entity ticks (RE_TICK_ALL_DYNAMIC)" if tick_all else ", entities of visible active sections tick (reference semantics)"),
                      "visible_instances": vis["total"], "entities_ticked": tr["n_changed"],
                      "frame_ms_median_sync": med * 1e-3, "entities_per_s_sync": n / (med * 1e-6),
                      "pipelined_ms_per_frame": per * 1e3, "entities_per_s_pipelined": n / per, "kernel_us": kt,
-                     "tick_roofline": {"bound": "hbm", "kernel": "k_tick", "us": kt["tick"], "bytes_per_entity_survey_8d": B_TICK, "bytes": B_TICK * tr["n_changed"],
-                                       "frac": B_TICK * tr["n_changed"] / (kt["tick"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["tick"] > 0 else None}}
+                     "tick_roofline": {"bound": "hbm", "kernel": "k_tick", "bytes_per_entity_survey_8d": B_TICK, "bytes": B_TICK * tr["n_changed"],
+                                       "us_sync_frames": t_sync, "us_async_frames": t_async,
+                                       "frac_sync_frames": B_TICK * tr["n_changed"] / (t_sync * 1e-6) / 1e9 / HBM_PEAK_GBS if t_sync else None,
+                                       "frac_async_frames": B_TICK * tr["n_changed"] / (t_async * 1e-6) / 1e9 / HBM_PEAK_GBS if t_async else None,
+                                       "note": "k_tick's own launches (dispatch-bound HIP events); between synchronous frames the device idles and clocks down, which this "
+                                               "ALU-issue-bound kernel feels and the HBM-bound key scan does not"}}
     p.close()
     return out
 

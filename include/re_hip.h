@@ -353,9 +353,12 @@ int re_debug_get_visible_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys
  * switches the event recording on (it costs ~12 us per synchronous frame, so it is off until asked for) and returns zeros; call again
  * after the next frame.  A call with three NULL pointers switches the recording off again. */
 int re_get_timings(re_ctx *ctx, float *cull_us, float *pack_us, float *tick_us);
-/* per-launch HIP-event timing of the dominant kernel (the section-key scan + cull) over a timed region, sampling every
- * `every`-th launch (0 or 1 = all): re_timing_begin(ctx, max_launches, every); ...frames...;
- * re_timing_collect(ctx, us, cap, &n) (synchronises) */
+/* per-launch HIP-event timing of one kernel over a timed region (the events are tied to the dispatch itself, so the figure holds in synchronous and in
+ * asynchronous frame loops alike), sampling every `every`-th launch (0 or 1 = all): re_timing_begin(ctx, max_launches, every | RE_TIME_x << 16);
+ * ...frames...; re_timing_collect(ctx, us, cap, &n) (synchronises).  RE_TIME_SCAN (0) = the dominant kernel, the section-key scan + cull. */
+#define RE_TIME_SCAN        0u
+#define RE_TIME_TICK        1u
+#define RE_TIME_PACK_LARGE  2u
 int re_timing_begin(re_ctx *ctx, uint32_t max_launches, uint32_t every);
 int re_timing_collect(re_ctx *ctx, float *microseconds, uint32_t capacity, uint32_t *n);
 /* number of world sections inside a candidate box in the last cull (== hash probes the reference would make) */

@@ -20,6 +20,12 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct ReTickResult { pub n_changed: u32, pub n_rebucket: u32, pub n_out_of_bounds: u32 }
 #[repr(C)] pub struct ReChange { pub kind: u32, pub entity_id: u32, pub component: u32, pub reserved: u32, pub value: [f32; 4] }
 #[repr(C)] #[derive(Copy, Clone)] pub struct ReCollision { pub this_entity: u32, pub other_entity: u32 }
+#[repr(C)] pub struct ReGathered { pub n_ranks: u32, pub overflowed: u32, pub counts: *const u32, pub d_entity_ids: *const u32, pub ids_rank_stride: u32,
+                                   pub d_matrices: *const f32, pub matrices_rank_stride: u32 }
+#[repr(C)] pub struct ReHistory { _private: [u8; 0] }
+#[repr(C)] pub struct ReTypeIds { pub position: u64, pub rotation: u64, pub scale: u64, pub velocity: u64, pub acceleration: u64, pub rotation_velocity: u64,
+                                  pub rotation_acceleration: u64, pub has_moved: u64, pub has_rotated: u64 }
+#[repr(C)] pub struct ReFrameChange { pub kind: u32, pub f: [f32; 6], pub i: [i32; 2], pub n_changes: u32, pub changes: *const ReChange }
 
 extern "C" {
     pub fn re_create(cfg: *const ReConfig, out: *mut *mut ReCtx) -> c_int;
@@ -33,9 +39,33 @@ extern "C" {
     pub fn re_wait(ctx: *mut ReCtx, vis: *mut ReVisible, tick: *mut ReTickResult) -> c_int;
     pub fn re_copy_visible(ctx: *mut ReCtx, ids: *mut u32, mats: *mut f32, capacity: u32, n_written: *mut u32) -> c_int;
     pub fn re_set_output_buffers(ctx: *mut ReCtx, d_ids: *mut u32, d_mats: *mut f32, capacity: u32) -> c_int;
-    pub fn re_set_output_count(ctx: *mut ReCtx, d_count: *mut u32) -> c_int;   // device word receiving the instance count (all-gather slab header)
+    pub fn re_set_output_count(ctx: *mut ReCtx, d_count: *mut u32) -> c_int;   // 4 device words {written, total, frame, 0} written by the pack (an all-gather slab header of the host's own; re_comm_* does this itself)
     pub fn re_read_component(ctx: *mut ReCtx, entity_id: u32, component: c_int, dst: *mut c_void) -> c_int;
     pub fn re_get_out_of_bounds(ctx: *mut ReCtx, ids: *mut u32, capacity: u32, n: *mut u32) -> c_int;
+    // round 2
+    pub fn re_abi_version() -> u32;                                                                            // 2
+    pub fn re_set_model_lod(ctx: *mut ReCtx, model_index: u32, render_system: u32, n_lod: u32, lod_min: *const f32, lod_max: *const f32) -> c_int;
+    pub fn re_run_frames(ctx: *mut ReCtx, cam: *const ReCamera, delta_time: f32, cull_flags: u32, tick_flags: u32, n: u32,
+                         wall_us: *mut f32, last_visible: *mut ReVisible, last_tick: *mut ReTickResult) -> c_int;
+    pub fn re_ecs_bitset(ctx: *mut ReCtx, entity_id: u32, bits: *mut u32) -> c_int;
+    pub fn re_ecs_query(ctx: *mut ReCtx, components: *const c_int, n_components: u32, ids: *mut u32, capacity: u32, n: *mut u32) -> c_int;
+    pub fn re_comm_unique_id(id: *mut u8) -> c_int;                                                            // RE_COMM_ID_BYTES = 128
+    pub fn re_comm_init(ctx: *mut ReCtx, id: *const u8, rank: c_int, n_ranks: c_int, slab_instances: u32) -> c_int;
+    pub fn re_comm_adopt(ctx: *mut ReCtx, nccl_comm: *mut c_void, rank: c_int, n_ranks: c_int, slab_instances: u32) -> c_int;
+    pub fn re_comm_destroy(ctx: *mut ReCtx) -> c_int;
+    pub fn re_allgather_visible(ctx: *mut ReCtx, flags: u32, out: *mut ReGathered) -> c_int;
+    pub fn re_gather_wait(ctx: *mut ReCtx, out: *mut ReGathered) -> c_int;
+    pub fn re_history_create(ids: *const ReTypeIds, flags: u32, out: *mut *mut ReHistory) -> c_int;
+    pub fn re_history_destroy(h: *mut ReHistory);
+    pub fn re_history_last_error(h: *const ReHistory) -> *const c_char;
+    pub fn re_history_set_state(h: *mut ReHistory, ecs_blob: *const c_void, ecs_bytes: u64, tree_blob: *const c_void, tree_bytes: u64) -> c_int;
+    pub fn re_history_get_state(h: *mut ReHistory, ecs_blob: *mut *const c_void, ecs_bytes: *mut u64, tree_blob: *mut *const c_void, tree_bytes: *mut u64) -> c_int;
+    pub fn re_history_record(h: *mut ReHistory, fc: *const ReFrameChange) -> c_int;
+    pub fn re_history_count(h: *mut ReHistory, n: *mut u32) -> c_int;
+    pub fn re_history_get(h: *mut ReHistory, index: u32, out: *mut ReFrameChange) -> c_int;
+    pub fn re_history_encode(h: *mut ReHistory, index: u32, dst: *mut u8, capacity: u64, n_bytes: *mut u64) -> c_int;
+    pub fn re_history_write(h: *mut ReHistory, history_path: *const c_char, lookup_path: *const c_char) -> c_int;
+    pub fn re_history_load(ids: *const ReTypeIds, flags: u32, history_path: *const c_char, lookup_path: *const c_char, out: *mut *mut ReHistory) -> c_int;
 }
 
 pub const RE_OK: c_int = 0;
@@ -46,3 +76,7 @@ pub const RE_CULL_EMIT_DUPLICATES: u32 = 0x1; pub const RE_CULL_ASYNC: u32 = 0x2
 pub const RE_CHANGE_MODIFY: u32 = 0; pub const RE_CHANGE_DELETE: u32 = 1; pub const RE_CHANGE_MAKE_STATIC: u32 = 2; pub const RE_CHANGE_WAKE_UP: u32 = 3;
 pub const RE_C_POSITION: u32 = 0; pub const RE_C_ROTATION: u32 = 1; pub const RE_C_SCALE: u32 = 2; pub const RE_C_VELOCITY: u32 = 3; pub const RE_C_ACCELERATION: u32 = 4;
 pub const RE_C_ROTATION_VEL: u32 = 5; pub const RE_C_ROTATION_ACC: u32 = 6;
+pub const RE_CHANGE_REMOVE_COMPONENT: u32 = 4;
+pub const RE_GATHER_ASYNC: u32 = 0x1; pub const RE_COMM_ID_BYTES: usize = 128;
+pub const RE_FC_CAMERA_VIEW_CHANGE: u32 = 0; pub const RE_FC_CAMERA_STATIONARY: u32 = 1; pub const RE_FC_DELTA_TIME: u32 = 2; pub const RE_FC_DRAW_DISTANCES_CHANGE: u32 = 3;
+pub const RE_FC_WINDOW_DIMENSIONS_CHANGE: u32 = 4; pub const RE_FC_ENTITY_CHANGE: u32 = 5; pub const RE_FC_END_FRAME_CHANGE: u32 = 6;

@@ -182,7 +182,7 @@ struct re_ctx {
         std::vector<uint32_t> h_hdr, counts; uint32_t n_second_rounds = 0, n_regathers = 0;
     } comm;
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
-    std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0; bool k1_timing = false;   // per-launch timing of k_scan_cull
+    std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
     int fail(int code, const char *fmt, ...) {
         char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -904,6 +904,11 @@ static int prepare_group_counts(re_ctx *c, uint32_t par) {
     c->gc_dirty[par] = false;
     return RE_OK;
 }
+// re_timing_begin: the begin / end events of every `every`-th launch of the selected kernel (hipExtLaunchKernelGGL ties them to the dispatch itself)
+static void take_timing_events(re_ctx *c, hipEvent_t *a, hipEvent_t *b) {
+    if ((c->k1_seen++ % c->k1_every) == 0 && c->k1_used + 2 <= c->k1_events.size()) { *a = c->k1_events[c->k1_used]; *b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
+}
+
 static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next, bool counted_by_scan = false) {
     const uint32_t nshards = CURSOR_SHARDS, seg_cap = c->item_cap / nshards;
     const ItemSink KS = item_sink(c, c->lane_seq);
@@ -927,7 +932,9 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         // (+25 %; a longer shard makes its workgroups loop, any grid that is a multiple of 8 is correct)
         const uint32_t per_shard = (c->pred_total + c->pred_total / 4u) / nshards + PACK_LARGE_TILE;
         const uint32_t grid = nshards * std::min(2048u, std::max(4u, (per_shard + PACK_LARGE_TILE - 1u) / PACK_LARGE_TILE));
-        hipLaunchKernelGGL(k_pack_large, dim3(grid), dim3(256), 0, st, A);
+        hipEvent_t ta = nullptr, tb = nullptr;
+        if (c->k1_timing && c->k1_kind == RE_TIME_PACK_LARGE) take_timing_events(c, &ta, &tb);
+        hipExtLaunchKernelGGL(k_pack_large, dim3(grid), dim3(256), 0, st, ta, tb, 0, A);
         HIPCHK(c, hipGetLastError());
         c->last_pack.kind = 2; c->last_pack.L = A; c->last_pack.grid = grid; c->last_pack.par = par; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next;
         c->gc_dirty[par] = true; c->gc_dirty[par ^ 1u] = false;                // this frame's arrays stay as they are; the other parity's were cleared by the launch
@@ -1086,7 +1093,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         // the changed-static set is consumed by every render until the frame ends (re_tick clears it)
     }
     hipEvent_t k1a = nullptr, k1b = nullptr;
-    if (c->k1_timing && (c->k1_seen++ % c->k1_every) == 0 && c->k1_used + 2 <= c->k1_events.size()) { k1a = c->k1_events[c->k1_used]; k1b = c->k1_events[c->k1_used + 1]; c->k1_used += 2; }
+    if (c->k1_timing && c->k1_kind == RE_TIME_SCAN) take_timing_events(c, &k1a, &k1b);
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
@@ -1727,7 +1734,9 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     if (c->timed_tick) HIPCHK(c, hipEventRecord(c->ev[3], st));
     if (c->ndyn) {
         if (!c->th_clean) HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));     // normally zeroed by the pack kernel of the frame
-        hipLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
+        hipEvent_t ta = nullptr, tb = nullptr;
+        if (c->k1_timing && c->k1_kind == RE_TIME_TICK) take_timing_events(c, &ta, &tb);
+        hipExtLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, ta, tb, 0, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
                            (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame);
         c->th_clean = false;
@@ -2519,7 +2528,8 @@ extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches, uint32_t every)
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     while (c->k1_events.size() < (size_t)max_launches * 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->k1_events.push_back(e); }
-    c->k1_used = 0; c->k1_timing = max_launches > 0; c->k1_every = std::max(every, 1u); c->k1_seen = 0;
+    c->k1_used = 0; c->k1_timing = max_launches > 0; c->k1_every = std::max(every & 0xFFFFu, 1u); c->k1_kind = every >> 16; c->k1_seen = 0;
+    if (c->k1_kind > RE_TIME_PACK_LARGE) return c->fail(RE_E_ARG, "re_timing_begin: unknown kernel selector");
     return RE_OK;
 }
 extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) {

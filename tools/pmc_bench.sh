@@ -1,10 +1,12 @@
 #!/bin/bash
-# usage (on the GPU box): tools/pmc_bench.sh <tag> ; collects FETCH_SIZE and WRITE_SIZE in two separate passes
-tag=$1
+# usage (on the GPU box): tools/pmc_bench.sh <tag> [bench args...] ; collects FETCH_SIZE and WRITE_SIZE in two separate passes
+# (default bench args: the headline leg alone, so that a kernel name means one workload)
+tag=$1; shift
+args=${@:---config visible --no-extras}
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $root/gpurun_out/pmc_${tag}_$ctr -- python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline > $root/gpurun_out/pmc_${tag}_$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --output-format csv -d $root/gpurun_out/pmc_${tag}_$ctr -- python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline $args > $root/gpurun_out/pmc_${tag}_$ctr.log 2>&1
 done
 cd $root
 python - <<PY
@@ -19,7 +21,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         if r.get("Counter_Name") == ctr:
             acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if "k_scan_cull" in k or "k_pack_small" in k or "k_tick" in k or "k_probe" in k:
+        if any(n in k for n in ("k_scan_cull", "k_pack_small", "k_pack_large", "k_tick", "k_probe", "k_emit", "k_group_scan", "k_deferred_lighting")):
             v = v[len(v) // 3:]                      # steady state
             out.setdefault(k, {})[ctr] = sum(v) / len(v)
 print(json.dumps(out, indent=1))
