@@ -223,7 +223,7 @@ def main():
             dist.barrier()
 
     if a.pipelined_only:
-        pipelined_frames(p, camc, a.warmup); per = pipelined_frames(p, camc, a.steps)
+        pipelined_frames(p, camc, a.warmup, a.tick_all); per = pipelined_frames(p, camc, a.steps, a.tick_all)
         if rank == 0:
             print(json.dumps({"pipelined_ms_per_frame": per * 1e3, "entities_per_s": n_local / per}))
         return
@@ -294,7 +294,7 @@ def main():
         if world == 1:
             kt = kernel_times(p, camc, 16, a.tick_all)
             out["kernel_us"] = kt
-            per = pipelined_frames(p, camc, 64); per = pipelined_frames(p, camc, max(a.steps, 200))
+            per = pipelined_frames(p, camc, 64, a.tick_all); per = pipelined_frames(p, camc, max(a.steps, 200), a.tick_all)
             out["pipelined"] = {"ms_per_frame": per * 1e3, "entities_per_s": n_total / per,
                                 "note": "asynchronous frames, no result read by the host per frame; static worlds defer each pack to the next launch and alternate two frame lanes (round 1's headline figure)"}
         if not a.no_cpu_baseline and world == 1:

@@ -330,7 +330,16 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
             const uint4 *kp = reinterpret_cast<const uint4 *>(keys);
             uint4 kk[NLD];
 #pragma unroll
-            for (uint32_t it = 0; it < NLD; it++) { uint32_t q = (wave_key0 >> 2) + it * 64u + lane; kk[it] = kp[q < nquads ? q : nquads - 1u]; }
+            for (uint32_t it = 0; it < NLD; it++) {
+                uint32_t q = (wave_key0 >> 2) + it * 64u + lane;
+#ifdef RE_EXP_NT_KEYS                                                         // experiment: stream the keys past L2 so that the frame's other kernels keep their lines
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kp) + (q < nquads ? q : nquads - 1u));
+                kk[it] = make_uint4(t.x, t.y, t.z, t.w);
+#else
+                kk[it] = kp[q < nquads ? q : nquads - 1u];
+#endif
+            }
             lv0 = chunk_level[__builtin_amdgcn_readfirstlane(wave)] & (MAX_LEVELS - 1);      // scalar load, in flight together with the keys
             const PBox32 a0 = A.B32.box[lv0];
             const uint32_t hig = a0.hi | KEY32_GUARDS;
