@@ -392,8 +392,26 @@ def spinner_leg(R, a, atomic):
                                        "us_sync_frames": t_sync, "us_async_frames": t_async,
                                        "frac_sync_frames": B_TICK * tr["n_changed"] / (t_sync * 1e-6) / 1e9 / HBM_PEAK_GBS if t_sync else None,
                                        "frac_async_frames": B_TICK * tr["n_changed"] / (t_async * 1e-6) / 1e9 / HBM_PEAK_GBS if t_async else None,
-                                       "note": "k_tick's own launches (dispatch-bound HIP events); between synchronous frames the device idles and clocks down, which this "
-                                               "ALU-issue-bound kernel feels and the HBM-bound key scan does not"}}
+                                       "note": "k_tick's own launches (dispatch-bound HIP events) in synchronous and in asynchronous frame loops; at ~100 K ticking entities the launch holds "
+                                               "1.5 waves per SIMD and is bound by the length of one wave's instruction stream, not by HBM (dense_tick_all fills the machine)"}}
+    p.close()
+    # the same kernel with the machine full: every 10th entity a rotating body (1,007,770 ticking entities, ~15 waves per SIMD instead of 1.5)
+    ents = synthetic.lattice_world(cells_per_axis=a.axis, first_cell=first, atomic=atomic, spinner_every=10)
+    p = R.Pipeline(16384, atomic, max_instances=1 << 16)
+    p.register_model_instances(ents)
+    nd = p.stats()["n_dynamic"]
+    del ents
+    camc = R.Camera((c, c, c), (0, 0, -1), 1000.0).to_c()
+    sync_frames(p, camc, 6, True)
+    us, vis, tr = sync_frames(p, camc, 40, True)
+    per = pipelined_frames(p, camc, 8, True); per = pipelined_frames(p, camc, 100, True)
+    t_sync, t_async = launch_us(p, camc, "tick", 40, False, True), launch_us(p, camc, "tick", 100, True, True)
+    out["dense_tick_all"] = {"workload": "every 10th entity a rotating body: %d dynamic entities, all ticking (RE_TICK_ALL_DYNAMIC), far=1000" % nd, "entities_ticked": tr["n_changed"],
+                             "frame_ms_median_sync": float(np.median(us)) * 1e-3, "pipelined_ms_per_frame": per * 1e3,
+                             "tick_roofline": {"bound": "hbm", "kernel": "k_tick", "bytes_per_entity_survey_8d": B_TICK, "bytes": B_TICK * tr["n_changed"],
+                                               "us_sync_frames": t_sync, "us_async_frames": t_async,
+                                               "frac_sync_frames": B_TICK * tr["n_changed"] / (t_sync * 1e-6) / 1e9 / HBM_PEAK_GBS if t_sync else None,
+                                               "frac_async_frames": B_TICK * tr["n_changed"] / (t_async * 1e-6) / 1e9 / HBM_PEAK_GBS if t_async else None}}
     p.close()
     return out
 

@@ -60,6 +60,10 @@ extern "C" {
 #define RE_F_USER        0x800u  /* the user entity (flows/pipeline.rs:125-151): TransformationMatrix stays identity, StaticAABB = OriginalAABB
                                    * translated by Position; added to the tree as a non-static entity */
 
+#define RE_F_LIGHT_DIRECTIONAL 0x2000u /* EntityTransformationBuilder::new(.., light_type = Some(FindLightType::Directional), ..): the entity joins the light set of its world
+                                       * section (world/bounding_box_tree_v2.rs:157-228, add_entity :601-627, 690-730); see re_visible_lights */
+#define RE_F_LIGHT_POINT  0x4000u
+#define RE_F_LIGHT_SPOT   0x8000u
 #define RE_F_CAN_COLLIDE 0x1000u /* CanCauseCollisions (EntityTransformationBuilder.can_cause_collision, exports/entity_transformer.rs:66-69) */
 
 typedef struct re_ctx re_ctx;
@@ -323,6 +327,13 @@ int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst)
 #define RE_ECS_BIT_ORIGINAL_AABB        16
 #define RE_ECS_BIT_ALWAYS_EXECUTE_LOGIC 20
 int re_ecs_bitset(re_ctx *ctx, uint32_t entity_id, uint32_t *bits);   /* 0 for an entity that was removed (remove_entity clears every bit, ecs.rs:557-600) */
+/* The lights of one type that RenderFlow::render hands to the deferred pass (upload_*_lights, render_system/render_system.rs:676-800) and to the shadow
+ * flow: find_nearby_world_sections_maps (flows/render_flow.rs:249-254, flows/shadow_flow.rs:494-513: the whole-world visibility query with an AABB culler
+ * of radius cam->far_draw around cam->position) followed by find_nearby_lights (shadow_flow.rs:455-487: the light sets of those unique world sections and
+ * of the shared sections linked to them).  light_type: one of RE_F_LIGHT_DIRECTIONAL / RE_F_LIGHT_POINT / RE_F_LIGHT_SPOT.  *n = number found (may exceed
+ * capacity); ids in ascending order.  Independent of re_cull_pack (it runs its own visibility test), after the movers of the last tick are in. */
+int re_visible_lights(re_ctx *ctx, const re_camera *cam, uint32_t light_type, uint32_t *ids, uint32_t capacity, uint32_t *n);
+
 /* ECS::get_indexes_for_components (objects/ecs.rs:238-285): the entities that carry ALL the given components (RE_C_*), in ascending EntityId (the
  * reference returns a BTreeSet).  *n = their number; the first `capacity` ids are written.  Runs on the GPU over the presence column. */
 int re_ecs_query(re_ctx *ctx, const int *components, uint32_t n_components, uint32_t *entity_ids, uint32_t capacity, uint32_t *n);

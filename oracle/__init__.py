@@ -17,6 +17,7 @@ F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
 F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
 F_CAN_COLLIDE = 0x1000
+F_LIGHT_DIRECTIONAL, F_LIGHT_POINT, F_LIGHT_SPOT = 0x2000, 0x4000, 0x8000      # FindLightType of the entity (light sets of its world section)
 
 AABB_DT = np.dtype([("xmin", "f4"), ("xmax", "f4"), ("ymin", "f4"), ("ymax", "f4"), ("zmin", "f4"), ("zmax", "f4")])
 ENTITY_DT = np.dtype([
@@ -319,6 +320,13 @@ class World:
         keys = np.zeros(n, np.uint64)
         self.L.ro_frame_cull(self.h, C.byref(cam), n, keys.ctypes.data)
         return keys  # visible_sections_vec sorted, duplicates included
+
+    def visible_lights(self, cam, type_flag, cap=65536):
+        """ids of the lights of one type RenderFlow::render finds near the camera (flows/shadow_flow.rs:455-513), ascending"""
+        ids = np.zeros(cap, np.uint32)
+        self.L.ro_visible_lights.restype = C.c_uint32; self.L.ro_visible_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        n = self.L.ro_visible_lights(self.h, C.byref(cam), type_flag, cap, ids.ctypes.data)
+        return ids[:min(n, cap)].copy()
 
     def render(self, cam, emit_duplicates=False, cap=None, gcap=4096):
         ng = C.c_uint32()

@@ -565,6 +565,7 @@ struct ro_world {
     /* last CullResult */
     uint64_t *vis_vec; uint32_t vis_n, vis_cap;   /* visible_sections_vec, duplicates kept */
     u64set vis_map;                                /* visible_sections_map */
+    u64set light_vis; ro_aabb light_box;           /* the light query's visible_sections_map and culler (ro_visible_lights) */
     float planes[24]; float lookahead; float campos[3];
 };
 
@@ -585,7 +586,7 @@ void ro_world_free(ro_world *w) {
     free(w->ents); free(w->cells); free(w->cell_free.v); free(w->shared); free(w->shared_free.v); free(w->shared_pending_free.v);
     free(w->shared_order); free(w->caches); free(w->vis_vec); free(w->changed_shared.v); free(w->always_exec.v); free(w->marked.v);
     km_free(&w->cellmap); km_free(&w->cachemap); km_free(&w->sharedmap); km_free(&w->changed_cells_map);
-    u64set_free(&w->changed_cells); u64set_free(&w->changed_static_unique); u64set_free(&w->vis_map);
+    u64set_free(&w->changed_cells); u64set_free(&w->changed_static_unique); u64set_free(&w->vis_map); u64set_free(&w->light_vis);
     free(w->custom_lod);
     free(w);
 }
@@ -1009,7 +1010,8 @@ static void vis_push(ro_world *w, uint64_t key) {
     w->vis_vec[w->vis_n++] = key;
 }
 
-/* which: 0 = LogicFrustumCuller, 1 = RenderFrustumCuller */
+static int aabb_intersect(ro_aabb a, ro_aabb b);
+/* which: 0 = LogicFrustumCuller, 1 = RenderFrustumCuller, 2 = the AABB culler of the light query (results in light_vis) */
 static void find_visible_world_ids(ro_world *w, int which, ro_aabb box) {
     uint32_t maxl = ro_max_level(w->outline, w->atomic);
     float wsl = (float)w->atomic;
@@ -1037,11 +1039,13 @@ static void find_visible_world_ids(ro_world *w, int which, ro_aabb box) {
         size_t b = (size_t)ch * 25, e = b + 25 < ncand ? b + 25 : ncand;
         for (size_t i = b; i < e; i++) {
             if (cell_find(w, cands[i].key) < 0) continue;          /* is_section_in_existence (:389-392) */
-            hit[i] = (uint8_t)(which ? ro_frustum_aabb_visible(w->planes, cands[i].aabb)
-                                     : ro_logic_aabb_in_view(w->lookahead, w->campos, cands[i].aabb));
+            hit[i] = (uint8_t)(which == 2 ? aabb_intersect(w->light_box, cands[i].aabb)      /* shadow_flow.rs:80-86: Culler::aabb_in_view */
+                               : which ? ro_frustum_aabb_visible(w->planes, cands[i].aabb)
+                                       : ro_logic_aabb_in_view(w->lookahead, w->campos, cands[i].aabb));
         }
     }
-    for (size_t i = 0; i < ncand; i++) if (hit[i]) { vis_push(w, cands[i].key); u64set_push_unsorted(&w->vis_map, cands[i].key); }
+    if (which == 2) { for (size_t i = 0; i < ncand; i++) if (hit[i]) u64set_push_unsorted(&w->light_vis, cands[i].key); }
+    else for (size_t i = 0; i < ncand; i++) if (hit[i]) { vis_push(w, cands[i].key); u64set_push_unsorted(&w->vis_map, cands[i].key); }
     free(hit); free(cands);
 }
 
@@ -1069,6 +1073,41 @@ uint32_t ro_frame_cull(ro_world *w, const ro_camera *cam, uint32_t cap, uint64_t
         free(tmp);
     }
     return w->vis_n;
+}
+
+/* The lights RenderFlow::render hands to the deferred pass and the shadow flow: find_nearby_world_sections_maps (flows/shadow_flow.rs:494-513: the
+ * whole-world visibility query with an AABB culler of radius far_draw around the camera) -> find_nearby_lights (:455-487: the light sets of those
+ * unique sections and of the shared sections linked to them; light sets: world/bounding_box_tree_v2.rs:157-228, maintained by add_entity :601-627,
+ * 690-730 and remove_entity :806-831, 886-893).  unique_sections_with_lights only ever holds stale extra members (sections without lights add
+ * nothing), so the query is restated on the section membership itself.  type_flag: RO_F_LIGHT_*.  Ids in ascending order; returns their number. */
+uint32_t ro_visible_lights(ro_world *w, const ro_camera *cam, uint32_t type_flag, uint32_t cap, uint32_t *ids_out) {
+    const float r = cam->far_draw;
+    w->light_box = (ro_aabb){ cam->pos[0] - r, cam->pos[0] + r, cam->pos[1] - r, cam->pos[1] + r, cam->pos[2] - r, cam->pos[2] + r };
+    ro_aabb lb = { rmax(cam->pos[0] - r, 0.0f), cam->pos[0] + r, rmax(cam->pos[1] - r, 0.0f), cam->pos[1] + r, rmax(cam->pos[2] - r, 0.0f), cam->pos[2] + r };   /* generate_original_culling_aabb */
+    u64set_clear(&w->light_vis);
+    find_visible_world_ids(w, 2, lb);
+    u64set_normalize(&w->light_vis);
+    u32vec out = { 0 };
+    uint32_t pass = ++w->pass_id;
+    for (uint32_t i = 0; i < w->light_vis.n; i++) {
+        int32_t ci = cell_find(w, w->light_vis.v[i]);
+        if (ci < 0) continue;
+        const cell_t *c = &w->cells[ci];
+        for (int part = 0; part < 2; part++) { const u32set *set = part ? &c->stat : &c->local;
+            for (uint32_t k = 0; k < set->n; k++) { const ent_t *e = &w->ents[set->v[k]]; if (e->alive && (e->flags & type_flag)) u32vec_push(&out, set->v[k]); } }
+        for (uint32_t k = 0; k < c->shared.n; k++) {
+            shared_t *sh = &w->shared[c->shared.v[k]];
+            if (!sh->used || sh->stamp == pass) continue;                     /* processed_shared_sections (:460, 471) */
+            sh->stamp = pass;
+            for (int part = 0; part < 2; part++) { const u32set *set = part ? &sh->stat : &sh->ents;
+                for (uint32_t q = 0; q < set->n; q++) { const ent_t *e = &w->ents[set->v[q]]; if (e->alive && (e->flags & type_flag)) u32vec_push(&out, set->v[q]); } }
+        }
+    }
+    qsort(out.v, out.n, sizeof(uint32_t), cmp_u32);
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < out.n; i++) { if (i && out.v[i] == out.v[i - 1]) continue; if (ids_out && n < cap) ids_out[n] = out.v[i]; n++; }
+    free(out.v);
+    return n;
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -54,6 +54,9 @@ typedef struct { float xmin, xmax, ymin, ymax, zmin, zmax; } ro_aabb;
 #define RO_F_HAS_MOVED   0x200u  /* HasMoved marker (output) */
 #define RO_F_USER        0x800u  /* the user entity (flows/pipeline.rs:125-144): identity TransformationMatrix, StaticAABB = OriginalAABB translated */
 #define RO_F_HAS_ROTATED 0x400u  /* HasRotated marker (output) */
+#define RO_F_LIGHT_DIRECTIONAL 0x2000u /* EntityTransformationBuilder::new(.., Some(FindLightType::Directional), ..): member of its section's light set */
+#define RO_F_LIGHT_POINT  0x4000u
+#define RO_F_LIGHT_SPOT   0x8000u
 #define RO_F_CAN_COLLIDE 0x1000u /* CanCauseCollisions (EntityTransformationBuilder.can_cause_collision, entity_transformer.rs:66-69) */
 
 /* One entity as EntityTransformationBuilder would be filled (exports/entity_transformer.rs:12-29) */
@@ -157,6 +160,7 @@ int  ro_get_shared(ro_world *w, uint32_t i, uint64_t keys[8], int *nkeys, ro_aab
 /* cull: fills the world's CullResult.  Returns visible_sections_vec.len() (duplicates
  * included, pipeline.rs:228).  keys_out (cap entries) receives the vec in sorted order. */
 uint32_t ro_frame_cull(ro_world *w, const ro_camera *cam, uint32_t cap, uint64_t *keys_out);
+uint32_t ro_visible_lights(ro_world *w, const ro_camera *cam, uint32_t type_flag, uint32_t cap, uint32_t *ids_out);
 /* render gather + pack (render_flow.rs:401-410).  emit_duplicates!=0 reproduces the reference's
  * double emission for cells present twice in visible_sections_vec; 0 emits each instance once
  * (the ID *set*).  ids/mats (cap instances) are written group after group; returns total

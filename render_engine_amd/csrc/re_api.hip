@@ -182,6 +182,7 @@ struct re_ctx {
         std::vector<uint32_t> h_hdr, counts; uint32_t n_second_rounds = 0, n_regathers = 0;
     } comm;
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
+    std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
     int fail(int code, const char *fmt, ...) {
@@ -232,6 +233,7 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) {
 
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
+    c->d_light_rows.release(nullptr); c->d_light_out.release(nullptr); c->light_rows_dirty = true;
     c->d_id.release(a); c->d_gclass.release(a); c->d_flags.release(a); c->d_row_cell.release(a); c->d_mat.release(a); c->d_pos.release(a); c->d_rot.release(a);
     c->d_scale.release(a); c->d_aabb.release(a); c->d_orig.release(a); c->d_dyn_row.release(a); c->d_dyn_cell.release(a); c->d_dyn_vel.release(a); c->d_dyn_acc.release(a);
     c->d_dyn_rotvel.release(a); c->d_dyn_rotacc.release(a); c->d_row_key.release(a); c->d_row_nk.release(a); c->d_shrec.release(a); c->d_counter.release(a);
@@ -639,6 +641,8 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
         }
     }
     c->h_flags = flags; c->h_dyn_row = dyn_row; c->has_rotvel = false;
+    c->h_light_rows.clear(); for (uint32_t r = 0; r < n; r++) if (flags[r] & F_LIGHT_ANY) c->h_light_rows.push_back(r);
+    c->light_rows_dirty = true;
     c->user_row = ROW_CELL_NONE; for (uint32_t r = 0; r < n; r++) if (flags[r] & F_USER) { c->user_row = r; break; }
     c->d_row_moved.release(nullptr); c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->col_moved_cap = 0;
     for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
@@ -2410,6 +2414,39 @@ extern "C" int re_ecs_bitset(re_ctx *c, uint32_t entity_id, uint32_t *bits) {
     *bits = ecs_bits_of_flags(fl);
     return RE_OK;
 }
+// The lights of one type RenderFlow::render finds near the camera (flows/render_flow.rs:249-254 -> flows/shadow_flow.rs:455-513): k_visible_lights over the
+// entities uploaded with RE_F_LIGHT_*.  Stands alone (own visibility test with the AABB culler of radius far_draw); ids in ascending order.
+extern "C" int re_visible_lights(re_ctx *c, const re_camera *cam, uint32_t light_type, uint32_t *ids, uint32_t capacity, uint32_t *n_out) {
+    if (!c) return RE_E_ARG;
+    if (!cam || !n_out || (capacity && !ids)) return c->fail(RE_E_ARG, "re_visible_lights: NULL argument");
+    if (light_type != RE_F_LIGHT_DIRECTIONAL && light_type != RE_F_LIGHT_POINT && light_type != RE_F_LIGHT_SPOT) return c->fail(RE_E_ARG, "re_visible_lights: light_type must be one RE_F_LIGHT_* bit");
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_visible_lights: no world uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }                     // the section table is settled (movers of the last tick are in)
+    *n_out = 0;
+    const uint32_t nl = (uint32_t)c->h_light_rows.size();
+    if (!nl) return RE_OK;
+    if (c->light_rows_dirty) { HIPCHK(c, c->d_light_rows.alloc(nl, nullptr)); HIPCHK(c, hipMemcpy(c->d_light_rows.p, c->h_light_rows.data(), (size_t)nl * 4, hipMemcpyHostToDevice)); c->light_rows_dirty = false; }
+    if (c->d_light_out.n < (size_t)nl + 1) HIPCHK(c, c->d_light_out.alloc((size_t)nl + 1, nullptr));
+    LightQuery Q{}; const float r = cam->far_draw, wsl = (float)c->cfg.atomic_length;
+    Q.culler = Aabb{ cam->position[0] - r, cam->position[0] + r, cam->position[1] - r, cam->position[1] + r, cam->position[2] - r, cam->position[2] + r };
+    fill_level_boxes(Q.box, c->maxlevel, wsl, rmax(cam->position[0] - r, 0.0f), cam->position[0] + r, rmax(cam->position[1] - r, 0.0f), cam->position[1] + r,
+                     rmax(cam->position[2] - r, 0.0f), cam->position[2] + r);   // generate_original_culling_aabb (visible_world_flow.rs:131-145)
+    Q.max_level = c->maxlevel; Q.type_flag = light_type;
+    HIPCHK(c, hipMemsetAsync(c->d_light_out.p + nl, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_visible_lights, dim3((nl + 255) / 256), dim3(256), 0, c->stream, nl, c->d_light_rows.p, c->d_flags.p, c->d_id.p, c->d_row_cell.p, c->d_cell_key.p, c->d_cell_flags.p,
+                       c->d_sh_cells.p, Q, c->d_light_out.p, nl, c->d_light_out.p + nl);
+    HIPCHK(c, hipGetLastError());
+    std::vector<uint32_t> out((size_t)nl + 1);
+    HIPCHK(c, hipMemcpyAsync(out.data(), c->d_light_out.p, ((size_t)nl + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const uint32_t cnt = std::min(out[nl], nl);
+    std::sort(out.begin(), out.begin() + cnt);
+    *n_out = cnt;
+    for (uint32_t i = 0; i < cnt && i < capacity; i++) ids[i] = out[i];
+    return RE_OK;
+}
+
 extern "C" int re_ecs_query(re_ctx *c, const int *components, uint32_t n_components, uint32_t *ids, uint32_t capacity, uint32_t *n_out) {
     if (!c || (n_components && !components) || (capacity && !ids)) return RE_E_ARG;
     if (!c->h_res) return c->fail(RE_E_STATE, "re_ecs_query: no world uploaded");

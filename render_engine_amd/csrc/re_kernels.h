@@ -8,6 +8,7 @@
 namespace re {
 
 // entity flag bits (== RE_F_* of include/re_hip.h) + internal
+constexpr uint32_t F_LIGHT_DIRECTIONAL = 0x2000, F_LIGHT_POINT = 0x4000, F_LIGHT_SPOT = 0x8000, F_LIGHT_ANY = 0xE000;
 constexpr uint32_t F_STATIC = 0x001, F_HAS_VEL = 0x002, F_HAS_ACC = 0x004, F_HAS_ROT = 0x008, F_HAS_ROTVEL = 0x010,
                    F_HAS_ROTACC = 0x020, F_HAS_SCALE = 0x040, F_ALWAYS_EXEC = 0x080, F_OOB_LOGIC = 0x100,
                    F_HAS_MOVED = 0x200, F_HAS_ROTATED = 0x400, F_USER = 0x800, F_CAN_COLLIDE = 0x1000, F_DEAD = 0x80000000u;
@@ -228,6 +229,9 @@ __global__ void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, c
 struct Pair32 { uint32_t idx, val; };
 struct Pair64 { uint32_t idx, pad; uint64_t val; };
 struct FlagOp { uint32_t idx; uint8_t and_mask, or_mask, pad[2]; };
+struct LightQuery { LevelBox box[MAX_LEVELS]; Aabb culler; uint32_t max_level, type_flag; };
+__global__ void k_visible_lights(uint32_t n, const uint32_t *light_rows, const uint32_t *flags, const uint32_t *row_id, const uint32_t *row_cell, const uint64_t *cell_key,
+                                 const uint8_t *cell_flags, const int32_t *sh_cells, LightQuery Q, uint32_t *out_ids, uint32_t cap, uint32_t *count);
 __global__ void k_scatter32(uint32_t m, const Pair32 *pairs, uint32_t *dst);
 __global__ void k_clone_rows(uint32_t m, const Pair32 *src_dst, uint32_t *row_id, float *row_mat);   // ghost instances: (source row, ghost row)
 __global__ void k_scatter64(uint32_t m, const Pair64 *pairs, uint64_t *dst);

@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
     static_assert(PASSES % CHUNK == 0, "matrix passes go in chunks");
     __shared__ uint32_t s_gbase[COUNT_SLOTS_MAX];             // first instance of each group (absolute)
     __shared__ uint32_t s_hist[COUNT_SLOTS_MAX], s_tbase[COUNT_SLOTS_MAX];
-    __shared__ uint32_t s_row[TILE], s_pos[TILE];
+    __shared__ uint32_t s_row[TILE], s_pos[TILE], s_id[TILE], s_tpre[COUNT_SLOTS_MAX];
     __shared__ uint32_t s_wsum[4], s_wcnt[4], s_whash[4], s_carry, s_gcarry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, bid = blockIdx.x, nslots = A.nslots, nsh = A.nshards;
     if (A.spec->stale) {                                    // cancelled frame (SpecState)
@@ -947,8 +947,10 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(A.th)[i] = 0u;
         for (uint32_t i = tid; i < A.zero_words; i += NT) { if (A.zero_a) A.zero_a[i] = 0u; if (A.zero_b) A.zero_b[i] = 0u; }   // the other parity's counts / fills: nobody reads or adds to them during this launch
     }
-    // ---- tiles of PER entries per thread: few, fat tiles -- one reservation per (tile, non-empty group) on the shard's own fill counters, and every
-    // thread keeps CHUNK 16-byte matrix loads in flight while it moves the tile (4 lanes per instance, list order)
+    // ---- tiles of PER entries per thread: few, fat tiles -- one reservation per (tile, non-empty group) on the shard's own fill counters.  The tile is
+    // counting-sorted by group in LDS first, so that neighbouring lanes move neighbouring output rows: the 4-byte ids leave as full lines instead of
+    // one 64-byte write per id (the PMC pass of round 2 showed 1.9x the written bytes for the list-order move), the matrix rows as 1 KB runs.
+    // Every thread keeps CHUNK 16-byte matrix loads in flight while it moves the tile (4 lanes per instance).
     const uint32_t part = tid & 3u, li = tid >> 2;
     for (bool first = true; tile * TILE < n_sh; tile += tstride, first = false) {   // workgroup-uniform
 #pragma unroll
@@ -960,16 +962,32 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         }
         __syncthreads();                                                        // (the previous tile is done with the LDS arrays)
         for (uint32_t i = tid; i < nslots; i += NT) s_hist[i] = 0;
+        for (uint32_t i = tid; i < TILE; i += NT) { s_pos[i] = 0xFFFFFFFFu; s_row[i] = 0u; }   // tile-sorted entries past the tile's live count load row 0 and store nothing
         __syncthreads();
         uint32_t rank[PER], ids[PER];
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) {
             rank[q] = slot[q] != 0xFFFFFFFFu ? atomicAdd(&s_hist[slot[q]], 1u) : 0u;
-            s_row[q * NT + tid] = row[q];
-            ids[q] = slot[q] != 0xFFFFFFFFu ? A.row_id[row[q]] : 0u;              // in flight with the reservations below
+            ids[q] = slot[q] != 0xFFFFFFFFu ? A.row_id[row[q]] : 0u;              // in flight with everything up to the id stores below
         }
         __syncthreads();
-        // requests in flight together from here: the ids (above), the first CHUNK of matrix loads, the reservations on the shard's fill counters
+        // exclusive scan of the tile's group histogram (<= 512 slots: two per thread) -> first tile-sorted position of each group
+        {
+            const uint32_t i0 = tid * 2u, a = i0 < nslots ? s_hist[i0] : 0u, b = i0 + 1u < nslots ? s_hist[i0 + 1u] : 0u;
+            const uint32_t incl = wave_incl_scan(a + b);
+            if (lane == 63) s_wsum[wid] = incl;
+            __syncthreads();
+            uint32_t woff = 0; for (uint32_t w = 0; w < wid; w++) woff += s_wsum[w];
+            const uint32_t ex = woff + incl - (a + b);
+            if (i0 < nslots) s_tpre[i0] = ex;
+            if (i0 + 1u < nslots) s_tpre[i0 + 1u] = ex + a;
+        }
+        __syncthreads();
+        uint32_t tp[PER];
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) { tp[q] = slot[q] != 0xFFFFFFFFu ? s_tpre[slot[q]] + rank[q] : 0xFFFFFFFFu; if (tp[q] != 0xFFFFFFFFu) s_row[tp[q]] = row[q]; }
+        __syncthreads();
+        // requests in flight together from here: the ids (above), the first CHUNK of matrix loads (tile-sorted order), the reservations on the shard's fill counters
         float4 mat[CHUNK];
 #pragma unroll
         for (uint32_t ps = 0; ps < CHUNK; ps++)
@@ -988,14 +1006,12 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         }
         __syncthreads();
 #pragma unroll
-        for (uint32_t q = 0; q < PER; q++) {
-            const uint32_t pos = slot[q] != 0xFFFFFFFFu ? s_tbase[slot[q]] + rank[q] : 0xFFFFFFFFu;
-            s_pos[q * NT + tid] = pos;
-#ifndef RE_EXP_PACK_NOSTORE
-            if (pos < A.out_cap) A.out_ids[pos] = ids[q];
-#endif
-        }
+        for (uint32_t q = 0; q < PER; q++) if (tp[q] != 0xFFFFFFFFu) { s_pos[tp[q]] = s_tbase[slot[q]] + rank[q]; s_id[tp[q]] = ids[q]; }
         __syncthreads();
+#ifndef RE_EXP_PACK_NOSTORE
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) { const uint32_t e = q * NT + tid, pos = s_pos[e]; if (pos < A.out_cap) A.out_ids[pos] = s_id[e]; }   // neighbouring lanes, neighbouring words
+#endif
 #pragma unroll 1
         for (uint32_t c0 = 0; c0 < PASSES; c0 += CHUNK) {
             if (c0) {
@@ -1581,6 +1597,37 @@ __global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t 
     if (lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
     base = __shfl(base, 0, 64);
     if (hit) { const uint32_t slot = base + mbcnt(m); if (slot < cap) out_ids[slot] = row_id[r]; }
+}
+
+// The lights RenderFlow::render finds near the camera (flows/render_flow.rs:249-254 -> shadow_flow.rs:494-513 find_nearby_world_sections_maps: the
+// whole-world visibility query with an AABB culler of radius far_draw; then find_nearby_lights :455-487: the light sets of those unique sections and
+// of the shared sections linked to them, world/bounding_box_tree_v2.rs:157-228).  One thread per light entity: is the section that holds it (or, for
+// an entity of a shared section, any of the linked sections) a candidate of its level's box whose grid AABB intersects the culler?
+__device__ __forceinline__ bool light_section_visible(uint64_t key, const LightQuery &Q) {
+    const uint32_t lv = key_level(key);
+    if (lv >= Q.max_level) return false;
+    const LevelBox b = Q.box[lv];
+    const uint32_t x = key_x(key), y = key_y(key), z = key_z(key);
+    if (!in_box(x, y, z, b)) return false;
+    const float ll = b.level_length;
+    const float fx = (float)(b.bx + ((x - b.bx) & 0xFFFFu)) * ll, fy = (float)(b.by + ((y - b.by) & 0xFFFFu)) * ll, fz = (float)(b.bz + ((z - b.bz) & 0xFFFFu)) * ll;   // visible_world_flow.rs:73-82
+    const Aabb &c = Q.culler;
+    return c.xmin <= fx + ll && c.xmax >= fx && c.ymin <= fy + ll && c.ymax >= fy && c.zmin <= fz + ll && c.zmax >= fz;      // StaticAABB::intersect (aabb.rs:68-73)
+}
+__global__ __launch_bounds__(256) void k_visible_lights(uint32_t n, const uint32_t *__restrict__ light_rows, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ row_id,
+                                                        const uint32_t *__restrict__ row_cell, const uint64_t *__restrict__ cell_key, const uint8_t *__restrict__ cell_flags,
+                                                        const int32_t *__restrict__ sh_cells, LightQuery Q, uint32_t *__restrict__ out_ids, uint32_t cap, uint32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = light_rows[i], fl = flags[r], rc = row_cell[r];
+    if ((fl & F_DEAD) || !(fl & Q.type_flag) || rc == ROW_CELL_NONE) return;
+    bool vis = false;
+    if (!(rc & ROW_CELL_SHARED)) vis = !(cell_flags[rc] & CF_PAD) && light_section_visible(cell_key[rc], Q);
+    else {
+        const uint32_t s = rc & ~ROW_CELL_SHARED;
+        for (int k = 0; k < 8 && !vis; k++) { const int32_t c = sh_cells[s * 8 + k]; if (c >= 0 && !(cell_flags[c] & CF_PAD)) vis = light_section_visible(cell_key[c], Q); }
+    }
+    if (vis) { const uint32_t o = atomicAdd(count, 1u); if (o < cap) out_ids[o] = row_id[r]; }
 }
 
 // gathers the visible sections of the last cull for re_debug_get_visible_sections

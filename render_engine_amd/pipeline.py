@@ -314,6 +314,13 @@ class Pipeline:
         self._check(self._L.re_ecs_bitset(self._h, entity_id, C.byref(b)), "re_ecs_bitset")
         return b.value
 
+    def visible_lights(self, cam, light_type, capacity=65536):
+        """ids (ascending) of the lights of one type (F_LIGHT_*) RenderFlow::render finds near the camera: flows/shadow_flow.rs:455-513"""
+        camc = cam.to_c() if hasattr(cam, "to_c") else cam
+        ids = np.zeros(max(capacity, 1), np.uint32); n = C.c_uint32()
+        self._check(self._L.re_visible_lights(self._h, C.byref(camc), light_type, ids.ctypes.data, capacity, C.byref(n)), "re_visible_lights")
+        return ids[:min(n.value, capacity)].copy()
+
     def get_indexes_for_components(self, components):
         """ECS::get_indexes_for_components (objects/ecs.rs:238-285): ascending entity ids carrying all the components"""
         comps = (C.c_int * max(len(components), 1))(*components)
