@@ -350,7 +350,7 @@ typedef struct {
                                  * seal did not agree when the polled "done" word became visible.  0 while the publication protocol holds. */
     uint32_t n_sync_fallbacks;  /* of those, blocks that only agreed after a stream synchronise */
     uint32_t n_section_slots;   /* slots of the resident section table == keys the visibility scan streams per frame (world sections + padding / spare slots) */
-    uint32_t reserved2;
+    uint32_t n_device_rebuckets; /* re-bucket batches (movers of a tick that changed world section) whose bookkeeping ran on the device; the others took the host path */
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,

@@ -182,6 +182,13 @@ struct re_ctx {
         std::vector<uint32_t> h_hdr, counts; uint32_t n_second_rounds = 0, n_regathers = 0;
     } comm;
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
+    // device-side re-bucket bookkeeping (rebucket_on_device): lookup tables, scratch, and the sections whose host mirrors are behind the device
+    DevBuf<uint32_t> d_cell_cap; DevBuf<uint64_t> d_base_keys; DevBuf<unsigned long long> d_ovl_keys; DevBuf<uint32_t> d_ovl_slots; uint32_t ovl_cap = 0, ovl_count = 0;
+    bool rb_base_dirty = true, rb_ovl_dirty = true;
+    DevBuf<uint64_t> d_rb_key, d_rb_ord, d_rb_key2, d_rb_ksorted; DevBuf<uint32_t> d_rb_row, d_rb_idx, d_rb_perm1, d_rb_perm, d_rb_tmprow, d_rb_refold, d_rb_free, d_rb_freeoff;
+    DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
+    std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
+    uint32_t n_device_rebuckets = 0;
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -234,6 +241,10 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) {
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
     c->d_light_rows.release(nullptr); c->d_light_out.release(nullptr); c->light_rows_dirty = true;
+    c->d_cell_cap.release(a); c->d_base_keys.release(a); c->d_ovl_keys.release(nullptr); c->d_ovl_slots.release(nullptr); c->rb_base_dirty = c->rb_ovl_dirty = true; c->stale_slots.clear();
+    c->d_rb_key.release(nullptr); c->d_rb_ord.release(nullptr); c->d_rb_key2.release(nullptr); c->d_rb_ksorted.release(nullptr); c->d_rb_row.release(nullptr); c->d_rb_idx.release(nullptr);
+    c->d_rb_perm1.release(nullptr); c->d_rb_perm.release(nullptr); c->d_rb_tmprow.release(nullptr); c->d_rb_refold.release(nullptr); c->d_rb_free.release(nullptr); c->d_rb_freeoff.release(nullptr);
+    c->d_rb_tmp.release(nullptr); c->d_rb_segs.release(nullptr); c->d_rb_status.release(nullptr); c->rb_cap = 0;
     c->d_id.release(a); c->d_gclass.release(a); c->d_flags.release(a); c->d_row_cell.release(a); c->d_mat.release(a); c->d_pos.release(a); c->d_rot.release(a);
     c->d_scale.release(a); c->d_aabb.release(a); c->d_orig.release(a); c->d_dyn_row.release(a); c->d_dyn_cell.release(a); c->d_dyn_vel.release(a); c->d_dyn_acc.release(a);
     c->d_dyn_rotvel.release(a); c->d_dyn_rotacc.release(a); c->d_row_key.release(a); c->d_row_nk.release(a); c->d_shrec.release(a); c->d_counter.release(a);
@@ -447,6 +458,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     c->base_keys = keys; c->extra_slots.clear(); c->base_index.clear(); for (size_t i = 0; i < keys.size(); i += 1024) c->base_index.push_back(keys[i]); c->h_cell_nl = nlocal; c->h_cell_ns = nstatic; c->h_cell_begin.assign(begin.begin(), begin.begin() + ncells);
     c->h_cell_cap.resize(ncells); for (uint32_t ci = 0; ci < ncells; ci++) c->h_cell_cap[ci] = nlocal[ci] + nstatic[ci] + nghost[ci];
     c->h_cell_ng = nghost;
+    c->rb_base_dirty = true; c->rb_ovl_dirty = true; c->stale_slots.clear();      // (a full build is made from the host mirrors, which its callers bring up to date first)
     c->h_rows = rows; c->free_slots.assign(MAX_LEVELS, {}); c->h_sh_begin.assign(sh_begin.begin(), sh_begin.begin() + nsh);
     for (uint32_t ci = ncells; ci-- > 0;) if (is_pad(keys[ci])) c->free_slots[key_level(keys[ci]) & (MAX_LEVELS - 1)].push_back(ci);   // popped from the back: lowest slot first
     std::vector<uint64_t> keys_padded(keys); keys_padded.resize((size_t)((ncells + 1) & ~1u) + 2, 0xFFFFFFFFFFFFFFFFull);
@@ -476,6 +488,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, hipMemcpyAsync(c->d_cell_nlocal.p, nlocal.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_cell_nstatic.p, nstatic.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, c->d_cell_nghost.alloc(ncells, acct)); HIPCHK(c, hipMemcpyAsync(c->d_cell_nghost.p, nghost.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, c->d_cell_cap.alloc(ncells, acct)); HIPCHK(c, hipMemcpyAsync(c->d_cell_cap.p, c->h_cell_cap.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_cell_flags.p, cflags.data(), (size_t)ncells, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(c->d_cell_stamp.p, 0, (size_t)ncells * 4, st));
     }
@@ -1287,7 +1300,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     auto ghosts_of = [&](uint64_t K) -> const std::vector<uint32_t> * { auto g = c->ghost_map.find(K); return g == c->ghost_map.end() ? nullptr : &g->second; };
     for (uint64_t k : linked) if (find_slot(c, k) < 0) affected.insert(k);
     for (const SharedIdPub &id : c->h_shids) for (uint32_t k = 0; k < id.nk; k++) if (!linked.count(id.keys[k])) affected.insert(id.keys[k]);
-    std::vector<Pair64> p_key; std::vector<Pair32> p_begin, p_nl, p_ns, p_ng, p_rows, p_rowcell, p_stamp;
+    std::vector<Pair64> p_key; std::vector<Pair32> p_begin, p_nl, p_ns, p_ng, p_rows, p_rowcell, p_stamp, p_cap;
     std::map<uint32_t, FlagOp> fops;                                          // one merged op per slot
     auto fop = [&](uint32_t slot) -> FlagOp & { auto it = fops.find(slot); if (it == fops.end()) { FlagOp f{}; f.idx = slot; f.and_mask = 0xFF; f.or_mask = 0; it = fops.emplace(slot, f).first; } return it->second; };
     std::vector<uint32_t> refold; std::set<uint32_t> created; std::vector<std::pair<uint32_t, uint32_t>> freed;   // (level, slot): reusable from the next patch on
@@ -1337,7 +1350,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             const uint32_t lv = key_level(K) & (MAX_LEVELS - 1);
             if (c->free_slots[lv].empty()) return c->fail(RE_E_STATE, "patch_sections: free-slot accounting");
             slot = (int32_t)c->free_slots[lv].back(); c->free_slots[lv].pop_back();
-            c->h_cell_key[slot] = K; c->extra_slots[K] = (uint32_t)slot; c->h_cell_cap[slot] = 0; c->h_cell_begin[slot] = 0;
+            c->h_cell_key[slot] = K; c->extra_slots[K] = (uint32_t)slot; c->h_cell_cap[slot] = 0; c->h_cell_begin[slot] = 0; p_cap.push_back(Pair32{ (uint32_t)slot, 0u });
             p_key.push_back(Pair64{ (uint32_t)slot, 0, K }); p_stamp.push_back(Pair32{ (uint32_t)slot, 0 });
             FlagOp &f = fop((uint32_t)slot); f.and_mask = 0; f.or_mask = 0;
             if (c->dormant_cached.erase(K)) f.or_mask |= CF_STATIC_CACHED;          // its cache entry (now ghosts only) is reachable again
@@ -1354,7 +1367,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             if ((uint64_t)c->pool_used + cap > c->pool_cap) return c->fail(RE_E_STATE, "patch_sections: row-pool accounting");
             c->h_cell_begin[slot] = c->pool_used; c->h_cell_cap[slot] = cap; c->pool_used += cap;
             if (c->h_rows.size() < c->pool_used) c->h_rows.resize(c->pool_used, 0);
-            p_begin.push_back(Pair32{ (uint32_t)slot, c->h_cell_begin[slot] });
+            p_begin.push_back(Pair32{ (uint32_t)slot, c->h_cell_begin[slot] }); p_cap.push_back(Pair32{ (uint32_t)slot, cap });
         }
         uint32_t nl = 0; for (uint32_t i = 0; i < nmem; i++) if (!(c->h_flags[mem[i]] & F_STATIC)) nl++;
         c->h_cell_nl[slot] = nl; c->h_cell_ns[slot] = nmem - nl;
@@ -1439,11 +1452,10 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     uint64_t *acct = &c->dev_bytes;
     {
         std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
-        std::vector<Pair32> p_dyncell;                                       // (unused since the dynamic rows lead the row arrays: row_cell itself is what the tick reads)
         std::vector<Pair32> p_rowsgc; p_rowsgc.reserve(p_rows.size());         // the group class travels with every pool entry written
         for (const Pair32 &pr : p_rows) p_rowsgc.push_back(Pair32{ pr.idx, effective_gclass(c, pr.val) });
-        std::vector<Pair32> *v32[9] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_dyncell, &p_rowsgc, &p_ng };
-        uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_row_cell.p, c->d_rows_gc.p, c->d_cell_nghost.p };
+        std::vector<Pair32> *v32[9] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_cap, &p_rowsgc, &p_ng };      // (p_cap: the capacities the device-side re-bucket reads)
+        uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_cell_cap.p, c->d_rows_gc.p, c->d_cell_nghost.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
         size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
@@ -1508,8 +1520,171 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + n_real_delta);
     c->nrows_csr = c->pool_used;
     if (!carry.changed_static.empty()) c->dirty_pending = true;
-    c->n_patches++;
+    c->n_patches++; c->rb_ovl_dirty = true;                                   // (extra_slots changed: the device overlay follows before its next use)
     return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same bookkeeping on the device for the common batch -- movers between unique world sections of a world without shared
+// sections, ghosts or hidden rows: two ops per mover sorted by (section key, reference order), one thread per affected section (re_kernels.hip:
+// k_rb_*).  The host reads one status block between the two phases (is the batch eligible, is there slack for the new sections and the
+// relocated segments), hands over the free slots of the levels that need one, and afterwards only notes WHICH sections changed: its mirrors
+// of the section table (h_cell_*, h_rows, h_row_*, extra_slots) are brought up to date from the device when a host path next needs them
+// (sync_mirrors).  Returns RE_OK, 1 when the batch is left to the host path (nothing has been touched then), or an error.
+// ------------------------------------------------------------------------------------------------
+static RbCells rb_cells(re_ctx *c) {
+    RbCells C; C.cell_key = c->d_cell_key.p; C.cell_key32 = c->d_cell_key32.p; C.cell_begin = c->d_cell_begin.p; C.cell_cap = c->d_cell_cap.p; C.cell_nl = c->d_cell_nlocal.p;
+    C.cell_ns = c->d_cell_nstatic.p; C.cell_ng = c->d_cell_nghost.p; C.cell_stamp = c->d_cell_stamp.p; C.cell_flags = c->d_cell_flags.p;
+    C.rows = c->d_rows.p; C.rows_gc = c->d_rows_gc.p; C.row_cell = c->d_row_cell.p; C.pool_cap = c->pool_cap;
+    return C;
+}
+static RbTables rb_tables(re_ctx *c) { RbTables T; T.base_keys = c->d_base_keys.p; T.nbase = (uint32_t)c->base_keys.size(); T.ovl_keys = c->d_ovl_keys.p; T.ovl_slots = c->d_ovl_slots.p; T.ovl_mask = c->ovl_cap - 1u; return T; }
+
+// host mirrors of the sections the device patched, fetched when a host path needs them
+static int sync_mirrors(re_ctx *c) {
+    if (c->stale_slots.empty()) return RE_OK;
+    hipStream_t st = c->stream;
+    std::sort(c->stale_slots.begin(), c->stale_slots.end()); c->stale_slots.erase(std::unique(c->stale_slots.begin(), c->stale_slots.end()), c->stale_slots.end());
+    const uint32_t n = (uint32_t)c->stale_slots.size();
+    DevBuf<uint32_t> d_slots, d_hdr, d_offs, d_rows; DevBuf<uint64_t> d_keys;
+    auto done = [&](int rc) { d_slots.release(nullptr); d_hdr.release(nullptr); d_offs.release(nullptr); d_rows.release(nullptr); d_keys.release(nullptr); return rc; };
+    if (d_slots.alloc(n, nullptr) != hipSuccess || d_hdr.alloc((size_t)n * 4, nullptr) != hipSuccess || d_offs.alloc((size_t)n + 1, nullptr) != hipSuccess || d_keys.alloc(n, nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: out of device memory"));
+    std::vector<uint64_t> keys(n); std::vector<uint32_t> hdr((size_t)n * 4), offs((size_t)n + 1, 0);
+    if (hipMemcpyAsync(d_slots.p, c->stale_slots.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: copy"));
+    hipLaunchKernelGGL(k_rb_gather_cells, dim3((n + 255) / 256), dim3(256), 0, st, n, d_slots.p, rb_cells(c), d_keys.p, d_hdr.p);
+    (void)hipMemcpyAsync(keys.data(), d_keys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(hdr.data(), d_hdr.p, (size_t)n * 16, hipMemcpyDeviceToHost, st);
+    if (hipStreamSynchronize(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: section headers"));
+    for (uint32_t i = 0; i < n; i++) offs[i + 1] = offs[i] + hdr[(size_t)i * 4 + 2] + hdr[(size_t)i * 4 + 3];
+    std::vector<uint32_t> rows(std::max<uint32_t>(offs[n], 1u));
+    if (offs[n]) {
+        if (d_rows.alloc(offs[n], nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: out of device memory"));
+        (void)hipMemcpyAsync(d_offs.p, offs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_rb_gather_rows, dim3((n + 255) / 256), dim3(256), 0, st, n, d_slots.p, d_offs.p, rb_cells(c), d_rows.p);
+        (void)hipMemcpyAsync(rows.data(), d_rows.p, (size_t)offs[n] * 4, hipMemcpyDeviceToHost, st);
+        if (hipStreamSynchronize(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: section rows"));
+    }
+    auto is_pad = [](uint64_t k) { return (k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull; };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t slot = c->stale_slots[i], begin = hdr[(size_t)i * 4], cap = hdr[(size_t)i * 4 + 1], nl = hdr[(size_t)i * 4 + 2], ns = hdr[(size_t)i * 4 + 3];
+        const uint64_t ko = c->h_cell_key[slot], kn = keys[i];
+        if (ko != kn) {                                                        // find_slot: base = last full build, overlay = created since
+            auto e = c->extra_slots.find(ko); if (e != c->extra_slots.end() && e->second == slot) c->extra_slots.erase(e);
+            if (!is_pad(kn) && !(slot < c->base_keys.size() && c->base_keys[slot] == kn)) c->extra_slots[kn] = slot;
+        }
+        c->h_cell_key[slot] = kn; c->h_cell_begin[slot] = begin; c->h_cell_cap[slot] = cap; c->h_cell_nl[slot] = nl; c->h_cell_ns[slot] = ns; c->h_cell_ng[slot] = 0;
+        if (c->h_rows.size() < (size_t)begin + nl + ns) c->h_rows.resize((size_t)begin + nl + ns, 0);
+        for (uint32_t k = 0; k < nl + ns; k++) {
+            const uint32_t r = rows[offs[i] + k];
+            c->h_rows[begin + k] = r;
+            if (r < c->n) { c->h_row_cell[r] = slot; c->h_row_key[r] = kn; c->h_row_nk[r] = 1; }
+        }
+    }
+    c->stale_slots.clear();
+    return done(RE_OK);
+}
+
+static bool device_rebucket_applicable(const re_ctx *c) {
+    static const bool off = getenv("RE_EXP_HOST_REBUCKET") != nullptr;         // A/B switch of tools/rebucket_cost.py
+    return !off && c->ncells && c->nsh == 0 && c->h_row_shared_keys.empty() && c->ghost_map.empty() && c->h_uncached.empty() && c->dormant_cached.empty()
+           && !(c->cfg.flags & (RE_CFG_PROBE | RE_CFG_FULL_REBUILD));
+}
+
+static int rebucket_on_device(re_ctx *c, uint32_t M) {
+    if (!M || !device_rebucket_applicable(c)) return 1;
+    hipStream_t st = c->stream;
+    static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  device rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
+    // ---- lookup tables: the sorted keys of the last full build + the overlay of sections created since (rebuilt from extra_slots after a host-side patch)
+    if (c->rb_base_dirty) {
+        HIPCHK(c, c->d_base_keys.alloc(c->base_keys.size(), &c->dev_bytes));
+        HIPCHK(c, hipMemcpyAsync(c->d_base_keys.p, c->base_keys.data(), c->base_keys.size() * 8, hipMemcpyHostToDevice, st));
+        c->rb_base_dirty = false;
+    }
+    if (!c->ovl_cap) { c->ovl_cap = 1u << 17; HIPCHK(c, c->d_ovl_keys.alloc(c->ovl_cap, nullptr)); HIPCHK(c, c->d_ovl_slots.alloc(c->ovl_cap, nullptr)); c->rb_ovl_dirty = true; }
+    if (c->rb_ovl_dirty) {
+        { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
+        if (c->extra_slots.size() * 4u > c->ovl_cap) return 1;                  // (the host path will rebuild the table from scratch when its own slack is used up)
+        HIPCHK(c, hipMemsetAsync(c->d_ovl_keys.p, 0xFF, (size_t)c->ovl_cap * 8, st));
+        std::vector<Pair64> pr; pr.reserve(c->extra_slots.size());
+        for (auto &kv : c->extra_slots) pr.push_back(Pair64{ kv.second, 0u, kv.first });
+        if (!pr.empty()) {
+            if (c->d_stage.n < pr.size() * sizeof(Pair64)) HIPCHK(c, c->d_stage.alloc(pr.size() * sizeof(Pair64) * 2, nullptr));
+            HIPCHK(c, hipMemcpyAsync(c->d_stage.p, pr.data(), pr.size() * sizeof(Pair64), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_rb_ovl_insert, dim3(((uint32_t)pr.size() + 255) / 256), dim3(256), 0, st, (uint32_t)pr.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p), rb_tables(c));
+            HIPCHK(c, hipStreamSynchronize(st));                                // `pr` goes out of scope
+        }
+        c->ovl_count = (uint32_t)c->extra_slots.size(); c->rb_ovl_dirty = false;
+    }
+    // ---- scratch
+    const uint32_t nops = 2u * M;
+    if (c->rb_cap < nops) {
+        const uint32_t cap = std::max(nops * 2u, 4096u);
+        HIPCHK(c, c->d_rb_key.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_ord.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_key2.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_ksorted.alloc(cap, nullptr));
+        HIPCHK(c, c->d_rb_row.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_idx.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_perm1.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_perm.alloc(cap, nullptr));
+        HIPCHK(c, c->d_rb_tmprow.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_refold.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_segs.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_free.alloc(cap, nullptr));
+        if (!c->d_rb_status.p) { HIPCHK(c, c->d_rb_status.alloc(1, nullptr)); HIPCHK(c, c->d_rb_freeoff.alloc(MAX_LEVELS, nullptr)); }
+        size_t t1 = 0, t2 = 0;
+        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, c->d_rb_ord.p, c->d_rb_key2.p, c->d_rb_idx.p, c->d_rb_perm1.p, cap, 0, 34, st));
+        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t2, c->d_rb_ord.p, c->d_rb_ksorted.p, c->d_rb_perm1.p, c->d_rb_perm.p, cap, 0, 64, st));
+        HIPCHK(c, c->d_rb_tmp.alloc(std::max(t1, t2) + 256, nullptr));
+        c->rb_cap = cap;
+    }
+    size_t tmp_bytes = c->d_rb_tmp.n;
+    RbStatus hs{}; hs.pool_used = c->pool_used;
+    HIPCHK(c, hipMemcpyAsync(c->d_rb_status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    const RbTables T = rb_tables(c); const RbCells C = rb_cells(c);
+    // ---- phase 1: ops, sorted by (section key, reference order), replayed per section on the counts
+    hipLaunchKernelGGL(k_rb_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->cfg.outline_length, c->cfg.atomic_length,
+                       c->d_rb_key.p, c->d_rb_ord.p, c->d_rb_row.p, c->d_rb_idx.p, c->d_rb_status.p);
+    HIPCHK(c, re::sort_pairs_u64_u32(c->d_rb_tmp.p, &tmp_bytes, c->d_rb_ord.p, c->d_rb_key2.p, c->d_rb_idx.p, c->d_rb_perm1.p, nops, 0, 34, st));
+    hipLaunchKernelGGL(k_rb_gather_keys, dim3((nops + 255) / 256), dim3(256), 0, st, nops, c->d_rb_perm1.p, c->d_rb_key.p, c->d_rb_ord.p);     // (d_rb_ord: free again, now the keys in reference order)
+    tmp_bytes = c->d_rb_tmp.n;
+    HIPCHK(c, re::sort_pairs_u64_u32(c->d_rb_tmp.p, &tmp_bytes, c->d_rb_ord.p, c->d_rb_ksorted.p, c->d_rb_perm1.p, c->d_rb_perm.p, nops, 0, 64, st));
+    hipLaunchKernelGGL(k_rb_segments, dim3((nops + 255) / 256), dim3(256), 0, st, nops, c->d_rb_perm.p, c->d_rb_ksorted.p, c->d_rb_row.p, T, C, c->d_rb_segs.p, c->d_rb_status.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&hs, c->d_rb_status.p, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    lap("phase 1");
+    if (hs.fallback) return 1;
+    uint32_t need_total = 0;
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { if (hs.need_slots[l] > c->free_slots[l].size()) return 1; need_total += hs.need_slots[l]; }
+    if ((uint64_t)c->pool_used + hs.need_pool > c->pool_cap) return 1;
+    if (((uint64_t)c->ovl_count + need_total) * 2u > c->ovl_cap) return 1;
+    // ---- phase 2: the free slots the new sections take (the top of each level's list, so that the host only pops), then the patch itself
+    std::vector<uint32_t> fl, off(MAX_LEVELS, 0);
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { off[l] = (uint32_t)fl.size(); for (uint32_t j = 0; j < hs.need_slots[l]; j++) fl.push_back(c->free_slots[l][c->free_slots[l].size() - 1u - j]); }
+    if (!fl.empty()) HIPCHK(c, hipMemcpyAsync(c->d_rb_free.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_rb_freeoff.p, off.data(), MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
+    const uint32_t nseg = hs.nseg;
+    hipLaunchKernelGGL(k_rb_apply, dim3((nseg + 63) / 64), dim3(64), 0, st, c->d_rb_perm.p, c->d_rb_row.p, T, C, row_arrays(c), c->d_rb_segs.p, c->d_rb_status.p, c->d_rb_free.p, c->d_rb_freeoff.p,
+                       c->d_rb_tmprow.p, c->d_rb_refold.p);
+    // end_of_changes: tight AABBs of the changed sections (bounding_box_tree_v2.rs:1055-1130)
+    hipLaunchKernelGGL(k_fold_tight_list, dim3((nseg + 255) / 256), dim3(256), 0, st, nseg, c->d_rb_refold.p, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p,
+                       c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    std::vector<RbSeg> segs(nseg); RbStatus h2{};
+    HIPCHK(c, hipMemcpyAsync(&h2, c->d_rb_status.p, sizeof h2, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(segs.data(), c->d_rb_segs.p, (size_t)nseg * sizeof(RbSeg), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    lap("phase 2");
+    // ---- what the host keeps in step at once: free slots, pool fill, section count; everything else waits for sync_mirrors
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
+        if (h2.popped[l] != hs.need_slots[l]) return c->fail(RE_E_STATE, "device re-bucket: free-slot accounting (level %u: %u taken, %u planned)", l, h2.popped[l], hs.need_slots[l]);
+        c->free_slots[l].resize(c->free_slots[l].size() - hs.need_slots[l]);
+    }
+    int32_t delta = 0;
+    for (const RbSeg &S : segs) {
+        if (S.slot < 0) continue;
+        c->stale_slots.push_back((uint32_t)S.slot);
+        if (S.freed) { c->free_slots[key_level(S.key) & (MAX_LEVELS - 1)].push_back((uint32_t)S.slot); delta--; }      // reusable from the next patch on
+        if (S.created) delta++;
+    }
+    if (h2.pool_used > c->pool_cap) return c->fail(RE_E_STATE, "device re-bucket: row-pool accounting");
+    c->pool_used = h2.pool_used; c->nrows_csr = c->pool_used; c->ovl_count += h2.n_created;
+    c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + delta);
+    c->n_patches++; c->n_device_rebuckets++;
+    lap("bookkeeping");
+    return RE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1530,6 +1705,8 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
     const uint32_t M = std::min(n_movers, c->list_cap);
     if (n_movers > c->list_cap) return c->fail(RE_E_CAPACITY, "mover list overflow");
+    if (!pre && !ghost_touched) { int drc = rebucket_on_device(c, M); if (drc <= 0) return drc; }      // the common batch stays on the device
+    { int src = sync_mirrors(c); if (src != RE_OK) return src; }
     std::vector<uint32_t> movers(M);
     HIPCHK(c, hipMemcpy(movers.data(), c->d_movers.p, (size_t)M * 4, hipMemcpyDeviceToHost));
     std::sort(movers.begin(), movers.end(), [&](uint32_t a, uint32_t b) {
@@ -1683,6 +1860,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
 static int absorb_out_of_bounds(re_ctx *c, uint32_t n_oob) {
     uint32_t cnt = std::min(n_oob, c->list_cap);
     if (!cnt) return RE_OK;
+    { int src = sync_mirrors(c); if (src != RE_OK) return src; }
     std::vector<uint32_t> rows(cnt);
     HIPCHK(c, hipMemcpy(rows.data(), c->d_oob.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     std::vector<Pair32> gc;
@@ -1831,6 +2009,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     hipStream_t st = c->stream;
     if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
     { int rc = resolve(c); if (rc != RE_OK) return rc; }
+    { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
     std::set<uint32_t> kin, trans, deleted;                                   // rows; the mover list is put in the reference's order (ascending EntityId) by rebucket()
     std::map<std::pair<uint32_t, uint32_t>, std::array<float, 4>> writes;     // (row, component) -> last value
     std::map<uint32_t, std::pair<uint32_t, uint32_t>> flag_ops;               // row -> (and-mask, or-mask)
@@ -2042,6 +2221,7 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
     HIPCHK(c, hipSetDevice(c->device));
     { int rc = c->cull_inflight ? finish_cull(c, nullptr) : resolve(c); if (rc != RE_OK) return rc; }
     if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
     hipStream_t st = c->stream;
     if (!c->d_col_hdr.p) {
         HIPCHK(c, c->d_col_hdr.alloc(1, nullptr)); HIPCHK(c, c->d_col_region.alloc(COL_REGION_CAP, nullptr)); HIPCHK(c, c->d_col_high.alloc(COL_REGION_CAP, nullptr));
@@ -2491,7 +2671,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->reserved2 = 0;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->n_device_rebuckets = c->n_device_rebuckets;
     return RE_OK;
 }
 
@@ -2499,6 +2679,7 @@ extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *key
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
+    { int rc_ = sync_mirrors(c); if (rc_ != RE_OK) return rc_; }
     if (n) *n = c->n_real_sections;
     const uint32_t m = c->ncells;
     if (!m || !capacity) return RE_OK;
@@ -2533,6 +2714,7 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
     uint32_t cnt = 0;
     HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
     { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
+    { int rc_ = sync_mirrors(c); if (rc_ != RE_OK) return rc_; }
     std::vector<uint32_t> idx(cnt); std::vector<uint8_t> mult(cnt);
     if (cnt) { HIPCHK(c, hipMemcpy(idx.data(), d_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(mult.data(), d_mult, cnt, hipMemcpyDeviceToHost)); }
     (void)hipFree(d_idx); (void)hipFree(d_mult); (void)hipFree(d_cnt);

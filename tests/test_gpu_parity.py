@@ -761,3 +761,52 @@ def test_soak_random_frames(R, seed, atomic, tight):
     check_entities(R, p, w, ents[::5])
     check_frame(R, p, w, cam, True)
     p.close(); w.close()
+
+
+def hopping_world(R, dims=(14, 14, 14), first=121, atomic=64, every=2):
+    """a lattice (one entity per level-0 world section, no shared sections) in which every `every`-th entity hops exactly one section per unit of
+    time along an axis: after a tick with dt = 1 no AABB straddles a section border, so a batch of movers touches unique world sections only"""
+    ents = R.synthetic.box_world(dims, first_cell=first, atomic=atomic, mover_every=every)
+    mv = (ents["flags"] & R.F_HAS_VEL) != 0
+    idx = np.nonzero(mv)[0]
+    a = np.float32(atomic)
+    cell = np.floor(ents["pos"][idx] / a)
+    ents["pos"][idx] = (cell + np.float32(0.5)) * a + (np.float32(6.0) * ((idx[:, None] * np.array([3, 5, 7])) % 5 - 2)).astype(np.float32)   # well inside the section
+    ents["vel"][idx] = 0
+    axis = idx % 3; sign = np.where((idx // 3) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    ents["vel"][idx, axis] = sign * a * np.where(idx % 5 == 0, 2.0, 1.0).astype(np.float32)
+    return ents
+
+
+def test_rebucket_on_the_device(R):
+    """batches of movers between unique world sections: the bookkeeping runs on the device (k_rb_*), the host only notes which sections changed.
+    Sections are emptied (-> padding slots), created (free slots of the level run), outgrow their segment (relocated); the host mirrors are
+    fetched on demand (a change-request batch, the debug getters) and the device path resumes afterwards"""
+    ents = hopping_world(R)
+    p, w = build_pair(R, ents)
+    assert p.stats()["n_shared_sections"] == 0
+    cams = [R.Camera((8192 + 10 * i, 8192 - 8 * i, 8192 + 2600), (0.02 * i, 0, -1), 6000.0) for i in range(7)]
+    rng = np.random.default_rng(2)
+    moved = 0
+    for f, cam in enumerate(cams):
+        check_frame(R, p, w, cam, f % 2 == 0)
+        n_o, oob_o = w.tick(oracle_camera(cam), 1.0)
+        t = p.tick(1.0)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o) == 0, (f, t, n_o)
+        moved += t["n_rebucket"]
+        if f % 2 == 1:                                           # looks at the table: host mirrors fetched from the device
+            check_sections(p, w)
+        if f == 3:                                               # a host-path batch in between (overlay and capacities change on the host)
+            ch = np.zeros(40, R.CHANGE_DT)
+            ids = rng.choice(ents["id"][(ents["flags"] & R.F_HAS_VEL) != 0], 40, replace=False)          # movers (no ghosts of the static cache), dropped at
+            for k in range(40):                                                                          # section centres (no shared sections)
+                ch[k] = (R._capi.CHANGE_MODIFY, ids[k], R._capi.C_POSITION, 0, (64.0 * (100 + k) + 32.0, 64.0 * 110 + 32.0, 64.0 * (140 - k) + 32.0, 0))
+            g = p.apply_changes(ch); n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT))
+            assert g["n_changed"] == n_a
+            check_sections(p, w)
+    st = p.stats()
+    assert moved > 2000 and st["n_device_rebuckets"] >= 5 and st["n_table_rebuilds"] == 0, (moved, st)
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::7])
+    check_frame(R, p, w, cams[0], False)
+    p.close(); w.close()
