@@ -189,6 +189,7 @@ struct re_ctx {
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
     uint32_t n_device_rebuckets = 0;
+    bool warm_code = getenv("RE_EXP_NO_WARM") == nullptr;   // the frame's kernels touch each other's code (re_kernels.hip: warm_code); the switch is for A/B measurements
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -945,6 +946,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         A.nslots = c->nslots; A.out_cap = out_cap; A.range_cap = c->nslots; A.frame = c->frame; A.item_row = KS.item_row; A.item_slot = KS.item_slot; A.nshards = nshards; A.seg_cap = seg_cap;
         A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats; A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p;
         A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count;
+        A.warm = (c->warm_code && !c->ndyn) ? (c->key32 ? WARM_SCAN32 : WARM_SCAN64) : 0u;
         // workgroup b takes tiles b >> 3, (b >> 3) + grid / 8, ... of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length
         // (+25 %; a longer shard makes its workgroups loop, any grid that is a multiple of 8 is correct)
         const uint32_t per_shard = (c->pred_total + c->pred_total / 4u) / nshards + PACK_LARGE_TILE;
@@ -1116,6 +1118,10 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
     PackArgs A{}; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
     A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count; A.frame = c->frame;
+    // code warm-up (re_kernels.hip: warm_code): the scan touches the code of the pack and of the tick that follow it, the last kernel of the frame that of the next scan
+    const uint32_t scan_code = c->key32 ? WARM_SCAN32 : WARM_SCAN64;
+    const uint32_t k1_warm = c->warm_code ? ((small ? WARM_PACK_SMALL : WARM_PACK_LARGE) | (c->ndyn ? WARM_TICK : 0u)) : 0u;
+    A.warm = (c->warm_code && !c->ndyn) ? scan_code : 0u;
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
@@ -1181,10 +1187,10 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         hipExtLaunchKernelGGL(k_scan_cull_fused<false>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (c->deferred_grid << 8),
                               SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
     else if (c->key32)
-        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n | (k1_warm << 8), SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     else
-        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (k1_warm << 8), SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     if (fuse) { c->deferred_pack = false; c->n_fused_frames++; }
     HIPCHK(c, hipGetLastError());
@@ -1920,7 +1926,7 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
         if (c->k1_timing && c->k1_kind == RE_TIME_TICK) take_timing_events(c, &ta, &tb);
         hipExtLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, ta, tb, 0, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
-                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame);
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame, c->warm_code ? (c->key32 ? WARM_SCAN32 : WARM_SCAN64) : 0u);
         c->th_clean = false;
         c->tick_published = !(flags & RE_TICK_ASYNC);
         if (c->tick_published) hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);

@@ -115,6 +115,22 @@ def box_world(dims, first_cell=20, atomic=64, index_range=None, spinner_every=0,
     return e
 
 
+def hopping_lattice(dims=(14, 14, 14), first_cell=121, atomic=64, every=2):
+    """a lattice (one entity per level-0 world section, no shared sections) in which every `every`-th entity hops exactly one or two sections per
+    unit of time along an axis: after a tick with dt = 1 no AABB straddles a section border, so a batch of movers touches unique world sections
+    only (the batch the device-side re-bucket handles)"""
+    ents = box_world(dims, first_cell=first_cell, atomic=atomic, mover_every=every)
+    mv = (ents["flags"] & _capi.F_HAS_VEL) != 0
+    idx = np.nonzero(mv)[0]
+    a = np.float32(atomic)
+    cell = np.floor(ents["pos"][idx] / a)
+    ents["pos"][idx] = (cell + np.float32(0.5)) * a + (np.float32(6.0) * ((idx[:, None] * np.array([3, 5, 7])) % 5 - 2)).astype(np.float32)   # well inside the section
+    ents["vel"][idx] = 0
+    axis = idx % 3; sign = np.where((idx // 3) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    ents["vel"][idx, axis] = sign * a * np.where(idx % 5 == 0, 2.0, 1.0).astype(np.float32)
+    return ents
+
+
 def mixed_world(n, seed=1234, centre=(8192.0, 8192.0, 8192.0), spread=900.0, atomic=64):
     """Small adversarial world for parity tests: random sizes (unique sections at several levels
     and shared sections), static and active entities, spinners, movers, always-execute entities,

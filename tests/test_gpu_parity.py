@@ -764,18 +764,7 @@ def test_soak_random_frames(R, seed, atomic, tight):
 
 
 def hopping_world(R, dims=(14, 14, 14), first=121, atomic=64, every=2):
-    """a lattice (one entity per level-0 world section, no shared sections) in which every `every`-th entity hops exactly one section per unit of
-    time along an axis: after a tick with dt = 1 no AABB straddles a section border, so a batch of movers touches unique world sections only"""
-    ents = R.synthetic.box_world(dims, first_cell=first, atomic=atomic, mover_every=every)
-    mv = (ents["flags"] & R.F_HAS_VEL) != 0
-    idx = np.nonzero(mv)[0]
-    a = np.float32(atomic)
-    cell = np.floor(ents["pos"][idx] / a)
-    ents["pos"][idx] = (cell + np.float32(0.5)) * a + (np.float32(6.0) * ((idx[:, None] * np.array([3, 5, 7])) % 5 - 2)).astype(np.float32)   # well inside the section
-    ents["vel"][idx] = 0
-    axis = idx % 3; sign = np.where((idx // 3) % 2 == 0, 1.0, -1.0).astype(np.float32)
-    ents["vel"][idx, axis] = sign * a * np.where(idx % 5 == 0, 2.0, 1.0).astype(np.float32)
-    return ents
+    return R.synthetic.hopping_lattice(dims, first, atomic, every)
 
 
 def test_rebucket_on_the_device(R):
