@@ -183,7 +183,8 @@ struct re_ctx {
     } comm;
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
     // device-side re-bucket bookkeeping (rebucket_on_device): lookup tables, scratch, and the sections whose host mirrors are behind the device
-    DevBuf<uint32_t> d_cell_cap; DevBuf<uint64_t> d_base_keys; DevBuf<unsigned long long> d_ovl_keys; DevBuf<uint32_t> d_ovl_slots; uint32_t ovl_cap = 0, ovl_count = 0;
+    DevBuf<uint32_t> d_cell_cap; DevBuf<uint8_t> d_cell_links; std::vector<uint32_t> h_linked_slots;   // (links: shared sections linking each unique section; non-zero keeps a batch on the host)
+    DevBuf<uint64_t> d_base_keys; DevBuf<unsigned long long> d_ovl_keys; DevBuf<uint32_t> d_ovl_slots; uint32_t ovl_cap = 0, ovl_count = 0;
     bool rb_base_dirty = true, rb_ovl_dirty = true;
     DevBuf<uint64_t> d_rb_key, d_rb_ord, d_rb_key2, d_rb_ksorted; DevBuf<uint32_t> d_rb_row, d_rb_idx, d_rb_perm1, d_rb_perm, d_rb_tmprow, d_rb_refold, d_rb_free, d_rb_freeoff;
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
@@ -242,7 +243,7 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) {
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
     c->d_light_rows.release(nullptr); c->d_light_out.release(nullptr); c->light_rows_dirty = true;
-    c->d_cell_cap.release(a); c->d_base_keys.release(a); c->d_ovl_keys.release(nullptr); c->d_ovl_slots.release(nullptr); c->rb_base_dirty = c->rb_ovl_dirty = true; c->stale_slots.clear();
+    c->d_cell_cap.release(a); c->d_cell_links.release(a); c->h_linked_slots.clear(); c->d_base_keys.release(a); c->d_ovl_keys.release(nullptr); c->d_ovl_slots.release(nullptr); c->rb_base_dirty = c->rb_ovl_dirty = true; c->stale_slots.clear();
     c->d_rb_key.release(nullptr); c->d_rb_ord.release(nullptr); c->d_rb_key2.release(nullptr); c->d_rb_ksorted.release(nullptr); c->d_rb_row.release(nullptr); c->d_rb_idx.release(nullptr);
     c->d_rb_perm1.release(nullptr); c->d_rb_perm.release(nullptr); c->d_rb_tmprow.release(nullptr); c->d_rb_refold.release(nullptr); c->d_rb_free.release(nullptr); c->d_rb_freeoff.release(nullptr);
     c->d_rb_tmp.release(nullptr); c->d_rb_segs.release(nullptr); c->d_rb_status.release(nullptr); c->rb_cap = 0;
@@ -490,6 +491,11 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, hipMemcpyAsync(c->d_cell_nstatic.p, nstatic.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, c->d_cell_nghost.alloc(ncells, acct)); HIPCHK(c, hipMemcpyAsync(c->d_cell_nghost.p, nghost.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, c->d_cell_cap.alloc(ncells, acct)); HIPCHK(c, hipMemcpyAsync(c->d_cell_cap.p, c->h_cell_cap.data(), (size_t)ncells * 4, hipMemcpyHostToDevice, st));
+        {   // shared sections linking each unique section (the device-side re-bucket leaves linked sections to the host path)
+            std::vector<uint8_t> links(std::max(ncells, 1u), 0); c->h_linked_slots.clear();
+            for (uint32_t s2 = 0; s2 < nsh; s2++) for (uint32_t k = 0; k < 8; k++) { const int32_t ci = sh_cells[(size_t)s2 * 8 + k]; if (ci >= 0) { if (links[ci] < 255) links[ci]++; c->h_linked_slots.push_back((uint32_t)ci); } }
+            HIPCHK(c, c->d_cell_links.alloc(ncells, acct)); HIPCHK(c, hipMemcpy(c->d_cell_links.p, links.data(), std::max(ncells, 1u), hipMemcpyHostToDevice));
+        }
         HIPCHK(c, hipMemcpyAsync(c->d_cell_flags.p, cflags.data(), (size_t)ncells, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(c->d_cell_stamp.p, 0, (size_t)ncells * 4, st));
     }
@@ -1406,6 +1412,14 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
             if (c->h_row_cell[r] != (ROW_CELL_SHARED | s2)) { c->h_row_cell[r] = ROW_CELL_SHARED | s2; p_rowcell.push_back(Pair32{ r, ROW_CELL_SHARED | s2 }); }
         }
     }
+    std::vector<FlagOp> link_ops;                                             // the link counts the device-side re-bucket reads: formerly linked slots to 0, then the new counts
+    {
+        std::map<uint32_t, uint32_t> cnt;
+        for (uint32_t sl : c->h_linked_slots) cnt[sl] = 0;
+        c->h_linked_slots.clear();
+        for (auto &kv : cell_links) { cnt[kv.first] = (uint32_t)std::min<size_t>(kv.second.size(), 255); for (size_t q = 0; q < kv.second.size(); q++) c->h_linked_slots.push_back(kv.first); }
+        for (auto &kv : cnt) { FlagOp f{}; f.idx = kv.first; f.and_mask = 0; f.or_mask = (uint8_t)kv.second; link_ops.push_back(f); }
+    }
     // rows that left the tree altogether (DeleteRequest)
     // (their row_cell was set by the caller through `arrive` being empty: handled below by the caller-provided list)
     // ---- D. update_static_world_sections for the changed sections (first loop), then for the changed shared sections (second loop)
@@ -1463,7 +1477,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         std::vector<Pair32> *v32[9] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_cap, &p_rowsgc, &p_ng };      // (p_cap: the capacities the device-side re-bucket reads)
         uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_cell_cap.p, c->d_rows_gc.p, c->d_cell_nghost.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
-        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + vf.size() * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
+        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + (vf.size() + link_ops.size()) * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
         if (c->d_stage.n < bytes) HIPCHK(c, c->d_stage.alloc(bytes * 2, nullptr));
         std::vector<uint8_t> host(bytes); size_t off = 0;
@@ -1471,6 +1485,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         const size_t o_key = put(p_key.data(), p_key.size() * sizeof(Pair64)), o_fl = put(vf.data(), vf.size() * sizeof(FlagOp)), o_rf = put(refold.data(), refold.size() * 4);
         size_t o32[9]; for (int k = 0; k < 9; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
         const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
+        const size_t o_lk = put(link_ops.data(), link_ops.size() * sizeof(FlagOp));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
         if ((c->cfg.flags & RE_CFG_PROBE) && !p_key.empty()) {                // the key -> slot table follows: retire the old keys of those slots, then enter the new ones
             for (uint32_t pass = 0; pass < 2; pass++)
@@ -1485,6 +1500,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         if (sh_total) { HIPCHK(c, hipMemcpyAsync(c->d_rows.p + sh_region, c->h_rows.data() + sh_region, (size_t)sh_total * 4, hipMemcpyHostToDevice, st));
                         HIPCHK(c, hipMemcpyAsync(c->d_rows_gc.p + sh_region, sh_gc.data(), (size_t)sh_total * 4, hipMemcpyHostToDevice, st)); }
         if (!vf.empty()) hipLaunchKernelGGL(k_flag_ops, dim3(((uint32_t)vf.size() + 255) / 256), dim3(256), 0, st, (uint32_t)vf.size(), reinterpret_cast<const FlagOp *>(c->d_stage.p + o_fl), c->d_cell_flags.p);
+        if (!link_ops.empty()) hipLaunchKernelGGL(k_flag_ops, dim3(((uint32_t)link_ops.size() + 255) / 256), dim3(256), 0, st, (uint32_t)link_ops.size(), reinterpret_cast<const FlagOp *>(c->d_stage.p + o_lk), c->d_cell_links.p);
         // end_of_changes: tight AABBs of the changed sections (stream order: after the table patches above)
         if (!refold.empty()) hipLaunchKernelGGL(k_fold_tight_list, dim3(((uint32_t)refold.size() + 255) / 256), dim3(256), 0, st, (uint32_t)refold.size(), reinterpret_cast<const uint32_t *>(c->d_stage.p + o_rf), c->d_cell_key.p,
                                                 c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, carry.too_many ? 1 : 0);
@@ -1541,7 +1557,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
 static RbCells rb_cells(re_ctx *c) {
     RbCells C; C.cell_key = c->d_cell_key.p; C.cell_key32 = c->d_cell_key32.p; C.cell_begin = c->d_cell_begin.p; C.cell_cap = c->d_cell_cap.p; C.cell_nl = c->d_cell_nlocal.p;
     C.cell_ns = c->d_cell_nstatic.p; C.cell_ng = c->d_cell_nghost.p; C.cell_stamp = c->d_cell_stamp.p; C.cell_flags = c->d_cell_flags.p;
-    C.rows = c->d_rows.p; C.rows_gc = c->d_rows_gc.p; C.row_cell = c->d_row_cell.p; C.pool_cap = c->pool_cap;
+    C.rows = c->d_rows.p; C.rows_gc = c->d_rows_gc.p; C.row_cell = c->d_row_cell.p; C.pool_cap = c->pool_cap; C.cell_links = c->d_cell_links.p;
     return C;
 }
 static RbTables rb_tables(re_ctx *c) { RbTables T; T.base_keys = c->d_base_keys.p; T.nbase = (uint32_t)c->base_keys.size(); T.ovl_keys = c->d_ovl_keys.p; T.ovl_slots = c->d_ovl_slots.p; T.ovl_mask = c->ovl_cap - 1u; return T; }
@@ -1591,7 +1607,7 @@ static int sync_mirrors(re_ctx *c) {
 
 static bool device_rebucket_applicable(const re_ctx *c) {
     static const bool off = getenv("RE_EXP_HOST_REBUCKET") != nullptr;         // A/B switch of tools/rebucket_cost.py
-    return !off && c->ncells && c->nsh == 0 && c->h_row_shared_keys.empty() && c->ghost_map.empty() && c->h_uncached.empty() && c->dormant_cached.empty()
+    return !off && c->ncells && c->ghost_map.empty() && c->h_uncached.empty() && c->dormant_cached.empty()
            && !(c->cfg.flags & (RE_CFG_PROBE | RE_CFG_FULL_REBUILD));
 }
 

@@ -254,6 +254,7 @@ struct RbTables {                                            // key -> slot of t
 struct RbCells {
     uint64_t *cell_key; uint32_t *cell_key32; uint32_t *cell_begin, *cell_cap, *cell_nl, *cell_ns, *cell_ng, *cell_stamp; uint8_t *cell_flags;
     uint32_t *rows, *rows_gc, *row_cell; uint32_t pool_cap;
+    const uint8_t *cell_links;                               // shared sections linking each unique section (maintained by the host paths)
 };
 hipError_t sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                               uint32_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream);      // re_sort.hip (rocPRIM radix sort)

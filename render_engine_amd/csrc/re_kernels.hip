@@ -1640,7 +1640,8 @@ __global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t 
 // world/bounding_box_tree_v2.rs:563-942, 1055-1213), for the common batch: movers between unique world sections.  The reference's sequential
 // order (translation-only movers, then kinematic movers, ascending EntityId) only matters per world section (the membership counts that decide
 // total_world_aabb_combining), so the batch becomes two ops per mover -- remove from the old section, add to the new one --, sorted by (section key,
-// order), and one thread replays each section's ops in order.  Anything else (shared sections, static rows, ghosts of the frozen static cache)
+// order), and one thread replays each section's ops in order.  Anything else (movers into or out of shared sections, sections that shared sections link,
+// static rows, ghosts of the frozen static cache)
 // raises RbStatus::fallback and the host path (re_api.hip: rebucket) takes the whole batch.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rb_hash(uint64_t k) { k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29; return (uint32_t)k; }
@@ -1694,6 +1695,7 @@ __global__ __launch_bounds__(256) void k_rb_segments(uint32_t n, const uint32_t 
     if (t > 0 && key_sorted[t - 1] == key) return;                           // segment heads only
     uint32_t e = t + 1u; while (e < n && key_sorted[e] == key) e++;
     const int32_t slot = rb_find(T, C.cell_key, key);
+    if (slot >= 0 && C.cell_links[slot]) st->fallback = 1u;                   // a section some shared section links: its existence and static flag depend on that one too (host path)
     const bool exists0 = slot >= 0;
     uint32_t nl = exists0 ? C.cell_nl[slot] : 0u, ns = exists0 ? C.cell_ns[slot] : 0u, total = 0;
     bool exists = exists0, changed = false;

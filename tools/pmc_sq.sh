@@ -5,7 +5,7 @@ args=${@:---spinner-every 100 --tick-all --no-extras}
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 i=0
-for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD"; do
+for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM" "SQ_IFETCH SQ_WAIT_IFETCH SQ_INSTS_SMEM"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $root/gpurun_out/sq_${tag}_$i -- python $root/bench.py --steps 40 --warmup 5 --no-cpu-baseline $args > $root/gpurun_out/sq_${tag}_$i.log 2>&1
 done
