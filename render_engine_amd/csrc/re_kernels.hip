@@ -1018,13 +1018,14 @@ extern "C" __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) 
         for (uint32_t q = 0; q < PER; q++) { tp[q] = slot[q] != 0xFFFFFFFFu ? s_tpre[slot[q]] + rank[q] : 0xFFFFFFFFu; if (tp[q] != 0xFFFFFFFFu) s_row[tp[q]] = row[q]; }
         __syncthreads();
         // requests in flight together from here: the ids (above), the first CHUNK of matrix loads (tile-sorted order), the reservations on the shard's fill counters
-        float4 mat[CHUNK];
+        typedef float f32x4 __attribute__((ext_vector_type(4)));                // (a native vector: an array of HIP's float4 class stays in scratch memory here -- 64 B written and read back per instance)
+        f32x4 mat[CHUNK];
 #pragma unroll
         for (uint32_t ps = 0; ps < CHUNK; ps++)
 #ifdef RE_EXP_PACK_NOLOAD
-            mat[ps] = make_float4((float)s_row[ps * 64u + li], 0.f, 0.f, 0.f);
+            mat[ps] = f32x4{ (float)s_row[ps * 64u + li], 0.f, 0.f, 0.f };
 #else
-            mat[ps] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
+            mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
 #endif
         for (uint32_t i = tid; i < nslots; i += NT) {
             const uint32_t cnt = s_hist[i];
@@ -1042,22 +1043,22 @@ extern "C" __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) 
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) { const uint32_t e = q * NT + tid, pos = s_pos[e]; if (pos < A.out_cap) A.out_ids[pos] = s_id[e]; }   // neighbouring lanes, neighbouring words
 #endif
-#pragma unroll 1
+#pragma unroll                                                                  // (both chunks unrolled: with a rolled loop the compiler keeps mat[] in scratch memory -- 64 B written and read back per instance)
         for (uint32_t c0 = 0; c0 < PASSES; c0 += CHUNK) {
             if (c0) {
 #pragma unroll
                 for (uint32_t ps = 0; ps < CHUNK; ps++)
 #ifdef RE_EXP_PACK_NOLOAD
-                    mat[ps] = make_float4((float)s_row[(c0 + ps) * 64u + li], 0.f, 0.f, 0.f);
+                    mat[ps] = f32x4{ (float)s_row[(c0 + ps) * 64u + li], 0.f, 0.f, 0.f };
 #else
-                    mat[ps] = reinterpret_cast<const float4 *>(A.row_mat + (size_t)s_row[(c0 + ps) * 64u + li] * 16)[part];
+                    mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[(c0 + ps) * 64u + li] * 16)[part];
 #endif
             }
 #pragma unroll
             for (uint32_t ps = 0; ps < CHUNK; ps++) {
                 const uint32_t pp = s_pos[(c0 + ps) * 64u + li];
 #ifndef RE_EXP_PACK_NOSTORE
-                if (pp < A.out_cap) reinterpret_cast<float4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
+                if (pp < A.out_cap) reinterpret_cast<f32x4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
 #else
                 if (pp == 0x12345u && mat[ps].x == 1.5f) A.out_ids[0] = 1u;
 #endif
@@ -1422,6 +1423,9 @@ extern "C" __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *_
         if (in && nfl != fl) R.flags[r] = nfl;
         return;
     }
+#if defined(RE_EXP_TICK_STAGE) && RE_EXP_TICK_STAGE == 1
+    if (in && nfl != fl) R.flags[r] = nfl; return;                          // experiment: round trip 1 only
+#endif
     // ---- round trip 2: every component a ticking lane may need, requested together (all contiguous by row); whether a lane uses
     // them is decided by its flag word afterwards -- no load below depends on another
     float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f }, v[3] = { 0.f, 0.f, 0.f }, a[3] = { 0.f, 0.f, 0.f };
@@ -1436,6 +1440,9 @@ extern "C" __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *_
     }
     PlaceInputs pin;                                                              // what place_core needs from memory, requested in the same round trip
     place_prefetch(pin, run, r, rc, R, cell_key);
+#if defined(RE_EXP_TICK_STAGE) && RE_EXP_TICK_STAGE == 2
+    if (run && (pos[0] + rot[0] + v[0] + a[0] + wq.x + aq.x + pin.orig.xmin + pin.scl[0] + pin.c3w + (float)pin.key) == 12345.678f) R.flags[r] = nfl; return;   // experiment: both round trips, no arithmetic, no stores
+#endif
     // ---- apply_kinematics (logic_flow.rs:366-448)
     bool pos_set = false, rot_set = false;
     if (run) {
@@ -1470,6 +1477,10 @@ extern "C" __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *_
     if (pos_set) nfl |= F_HAS_MOVED;
     if (rot_set) nfl |= F_HAS_ROTATED;
     const bool changed = pos_set || rot_set;
+#if defined(RE_EXP_TICK_STAGE) && RE_EXP_TICK_STAGE == 3
+    if (changed) { if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; } if (rot_set) reinterpret_cast<float4 *>(R.rot)[r] = make_float4(rot[0], rot[1], rot[2], rot[3]); }
+    if (in && nfl != fl) R.flags[r] = nfl; return;   // experiment: kinematics, no matrix / AABB / section decision
+#endif
     uint32_t status = 0;                                                          // 1: the entity changes section (re-bucket list), 2: it leaves the world
     if (changed) {
         if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
