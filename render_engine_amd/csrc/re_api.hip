@@ -190,7 +190,6 @@ struct re_ctx {
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
     uint32_t n_device_rebuckets = 0;
-    bool warm_code = getenv("RE_EXP_NO_WARM") == nullptr;   // the frame's kernels touch each other's code (re_kernels.hip: warm_code); the switch is for A/B measurements
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -952,7 +951,6 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         A.nslots = c->nslots; A.out_cap = out_cap; A.range_cap = c->nslots; A.frame = c->frame; A.item_row = KS.item_row; A.item_slot = KS.item_slot; A.nshards = nshards; A.seg_cap = seg_cap;
         A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats; A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p;
         A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count;
-        A.warm = (c->warm_code && !c->ndyn) ? (c->key32 ? WARM_SCAN32 : WARM_SCAN64) : 0u;
         // workgroup b takes tiles b >> 3, (b >> 3) + grid / 8, ... of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length
         // (+25 %; a longer shard makes its workgroups loop, any grid that is a multiple of 8 is correct)
         const uint32_t per_shard = (c->pred_total + c->pred_total / 4u) / nshards + PACK_LARGE_TILE;
@@ -1124,10 +1122,6 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     bool small = c->nslots <= LDS_HIST_SLOTS && c->nsh <= 65536u && (uint64_t)c->pred_total * 2u <= PACK_SMALL_ITEMS && !(flags & RE_CULL_FORCE_LARGE_PACK);
     PackArgs A{}; A.nslots = c->nslots; A.out_cap = out_cap; A.row_id = c->d_id.p; A.row_mat = c->d_mat.p; A.out_ids = out_ids; A.out_mats = out_mats;
     A.gc_model = c->d_gc_model.p; A.gc_rs = c->d_gc_rs.p; A.gc_sort = c->d_gc_sort.p; A.ranges = c->d_hranges; A.hres = c->d_hres; A.spec = c->d_spec.p; A.out_count = c->ext_out_count; A.frame = c->frame;
-    // code warm-up (re_kernels.hip: warm_code): the scan touches the code of the pack and of the tick that follow it, the last kernel of the frame that of the next scan
-    const uint32_t scan_code = c->key32 ? WARM_SCAN32 : WARM_SCAN64;
-    const uint32_t k1_warm = c->warm_code ? ((small ? WARM_PACK_SMALL : WARM_PACK_LARGE) | (c->ndyn ? WARM_TICK : 0u)) : 0u;
-    A.warm = (c->warm_code && !c->ndyn) ? scan_code : 0u;
     // K1: key scan + candidate cull + instance expansion in one launch (the dominant kernel).  hipExtLaunchKernelGGL ties the two
     // timing events to this dispatch's own begin/end timestamps.
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
@@ -1193,10 +1187,10 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         hipExtLaunchKernelGGL(k_scan_cull_fused<false>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (c->deferred_grid << 8),
                               SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
     else if (c->key32)
-        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n | (k1_warm << 8), SP.start[0], SP.count[0],
+        hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     else
-        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (k1_warm << 8), SP.start[0], SP.count[0],
+        hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     if (fuse) { c->deferred_pack = false; c->n_fused_frames++; }
     HIPCHK(c, hipGetLastError());
@@ -1942,7 +1936,7 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
         if (c->k1_timing && c->k1_kind == RE_TIME_TICK) take_timing_events(c, &ta, &tb);
         hipExtLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, ta, tb, 0, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
-                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame, c->warm_code ? (c->key32 ? WARM_SCAN32 : WARM_SCAN64) : 0u);
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame);
         c->th_clean = false;
         c->tick_published = !(flags & RE_TICK_ASYNC);
         if (c->tick_published) hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
@@ -1975,11 +1969,19 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
 
 // Synchronise and settle speculation: when a tick raised `stale` (entities changed section or left the world), everything enqueued
 // after it has cancelled itself; patch the tree from that tick's lists, then replay the cancelled calls (which may go stale again).
+// the counters of the last tick that ran, copied from the device (stream-ordered); k_tick counts n_changed in shards
+static int fetch_tick_counters(re_ctx *c) {
+    TickHeader t;
+    HIPCHK(c, hipMemcpyAsync(&t, c->d_th.p, sizeof t, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) t.n_changed += t.shard[k * 16u];
+    c->h_th->n_changed = t.n_changed; c->h_th->n_rebucket = t.n_rebucket; c->h_th->n_oob = t.n_oob;
+    return RE_OK;
+}
 static int resolve(re_ctx *c) {
     { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->tick_inflight && c->ndyn && c->h_th) { HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }   // (stream-ordered copy)   // n_changed, n_rebucket, n_oob of the last tick that ran
+    if (c->tick_inflight && c->ndyn && c->h_th) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }   // (stream-ordered copy)   // n_changed, n_rebucket, n_oob of the last tick that ran
     while (c->h_spec && c->h_spec->stale) {
         const uint32_t sf = c->h_spec->stale_frame;
         c->h_spec->stale = 0; HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
@@ -2007,7 +2009,7 @@ static int resolve(re_ctx *c) {
             c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (c->ndyn) { HIPCHK(c, hipMemcpyAsync(c->h_th, c->d_th.p, 12, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+        if (c->ndyn) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }
     }
     c->pending.clear();
     return RE_OK;

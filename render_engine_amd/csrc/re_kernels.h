@@ -65,7 +65,7 @@ struct FrameHeader {
 };
 struct FrameCounts { uint32_t n_candidates, n_vis_map, n_vis_vec; };
 constexpr uint32_t TICK_TICKET_SHARDS = 32;
-struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * 16]; };   // shard: finished-workgroup counters, one per 64-byte line
+struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * 16]; };   // shard: k_tick's share of n_changed, one counter per 64-byte line (a single address serialises the waves' atomics); readers add them up
 // Speculation across frames of a world with dynamic entities: frames are enqueued without waiting for the previous tick; a tick that
 // finds entities that change section (or leave the world) raises `stale`, and every kernel enqueued after it cancels itself until the
 // host has patched the tree and replayed those frames.
@@ -125,9 +125,6 @@ struct ItemSink {
     uint32_t *group_count; uint32_t count_nslots;   // large visible sets: the expansion also counts the instances per (cursor shard, group slot) -- [nshards][count_nslots],
                                             // through a per-wave LDS histogram flushed once per wave -- so that the pack needs no counting pass (nullptr / 0: off)
 };
-// code warm-up (re_kernels.hip: warm_code): which kernels' code to touch, and how many bytes of each (<= the symbol's size, multiple of 128)
-constexpr uint32_t WARM_PACK_SMALL = 1, WARM_PACK_LARGE = 2, WARM_TICK = 4, WARM_SCAN32 = 8, WARM_SCAN64 = 16;
-constexpr uint32_t CODE_BYTES_PACK_SMALL = 12288, CODE_BYTES_PACK_LARGE = 10624, CODE_BYTES_TICK = 20096, CODE_BYTES_SCAN32 = 25600, CODE_BYTES_SCAN64 = 26752;
 constexpr uint32_t COUNT_SLOTS_MAX = 512;   // group slots the in-scan counting (and k_pack_large) handle; larger tables take the count / scan / scatter kernels
 constexpr uint32_t PACK_LARGE_TILE = 1024;  // instances per workgroup iteration of k_pack_large (4 list entries per thread)
 struct PackArgs {                           // what k_pack_small needs besides the item list
@@ -136,7 +133,6 @@ struct PackArgs {                           // what k_pack_small needs besides t
     const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; const SpecState *spec;
     uint32_t frame;                         // this frame's number (HostResult::done_frame)
     uint32_t *out_count;                    // optional device word: instances written to the output buffers (the all-gather slab header)
-    uint32_t warm;                          // WARM_*: kernels whose code this launch touches for the launch behind it (re_kernels.hip: warm_code)
 };
 struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull after its two leading scalars (the kernel addresses it explicitly)
     PBoxTable B; PBox32Table B32;           // read by every wave (one of the two); everything below by candidate waves only
@@ -157,7 +153,7 @@ template <bool K32> __global__ void k_scan_cull(const void *keys, uint32_t ncell
                                                 uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A);   // the leading scalars arrive preloaded in SGPRs
 extern template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 extern template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
-extern "C" __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows);      // (C names: warm_code refers to the symbols)
+__global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows);
 struct FusedPack { FrameHeader *hdr, *hdr_next; TickHeader *th; PackArgs A; ItemSink K; uint32_t nrows, pad; };   // the previous frame's pack, carried by the next frame's launch
 template <bool K32> __global__ void k_scan_cull_fused(const void *keys, uint32_t ncells, uint32_t nsp_npack, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
                                                       uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A, FusedPack F);
@@ -175,18 +171,17 @@ struct PackLargeArgs {
     const uint32_t *item_row, *item_slot; uint32_t nshards, seg_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;
     const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; const SpecState *spec; uint32_t *out_count;
-    uint32_t warm;                                      // WARM_* (see PackArgs)
 };
-extern "C" __global__ void k_pack_large(PackLargeArgs A);
+__global__ void k_pack_large(PackLargeArgs A);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
                              uint32_t *out_count, uint32_t out_cap, uint32_t frame);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap, const SpecState *spec);
-extern "C" __global__ void k_tick(uint32_t ndyn, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
+__global__ void k_tick(uint32_t ndyn, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
-                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame, uint32_t warm);
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame);
 // Probe path of the visibility query (opt-in, RE_CFG_PROBE): instead of streaming every section key, enumerate the cells of the two
 // candidate boxes (their bounding box per level) and look each one up in a device hash table key -> slot, like the reference's
 // own contains_key probes (visible_world_flow.rs:96-104).  Work is O(candidates), not O(sections).

@@ -25,31 +25,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Code warm-up.  Every dispatch starts with cold instruction caches, and the 40 MB key stream of the scan pushes the code of the frame's
-// other kernels out of the L2s: the SQ counters of round 2 show a wave of k_tick active for ~3.7 K of its ~36 K cycles and waiting for
-// memory for ~2.7 K -- the rest is instruction fetch served from beyond L2.  So the kernel in front touches the next kernel's code as data:
-// eight late workgroups (workgroup b runs on XCD b % 8: one per L2) load one word of every 128-byte line of it.  The address comes from a
-// PC-relative relocation against the kernel's symbol (same code object); CODE_BYTES_* must not exceed the symbol's size
-// (tests/test_c_abi.py checks them against the built library).
-// ---------------------------------------------------------------------------------------------
-#define RE_CODE_ADDR(out, SYM) asm volatile("s_getpc_b64 s[60:61]\n\ts_add_u32 s60, s60, " SYM "@rel32@lo+4\n\ts_addc_u32 s61, s61, " SYM "@rel32@hi+12\n\ts_mov_b64 %0, s[60:61]" : "=s"(out) : : "s60", "s61", "scc")
-__device__ __forceinline__ uint32_t touch_lines(uint64_t base, uint32_t bytes, uint32_t tid, uint32_t nthreads) {
-    uint32_t acc = 0;
-    for (uint32_t o = tid * 128u; o < bytes; o += nthreads * 128u) acc ^= *reinterpret_cast<const volatile uint32_t *>(base + o);
-    return acc;
-}
-__device__ __forceinline__ uint32_t warm_code(uint32_t which, uint32_t tid, uint32_t nthreads) {
-    uint32_t acc = 0; uint64_t a;
-    if (which & WARM_PACK_SMALL) { RE_CODE_ADDR(a, "k_pack_small"); acc ^= touch_lines(a, CODE_BYTES_PACK_SMALL, tid, nthreads); }
-    if (which & WARM_PACK_LARGE) { RE_CODE_ADDR(a, "k_pack_large"); acc ^= touch_lines(a, CODE_BYTES_PACK_LARGE, tid, nthreads); }
-    if (which & WARM_TICK) { RE_CODE_ADDR(a, "k_tick"); acc ^= touch_lines(a, CODE_BYTES_TICK, tid, nthreads); }
-    if (which & WARM_SCAN32) { RE_CODE_ADDR(a, "_ZN2re11k_scan_cullILb1EEEvPKvjjjjjjjjjjPKjNS_12ScanCullArgsE"); acc ^= touch_lines(a, CODE_BYTES_SCAN32, tid, nthreads); }
-    if (which & WARM_SCAN64) { RE_CODE_ADDR(a, "_ZN2re11k_scan_cullILb0EEEvPKvjjjjjjjjjjPKjNS_12ScanCullArgsE"); acc ^= touch_lines(a, CODE_BYTES_SCAN64, tid, nthreads); }
-    return acc;
-}
-__device__ __forceinline__ void warm_sink(uint32_t acc) { asm volatile("" :: "v"(acc)); }   // the loads only have to have happened
-
-// ---------------------------------------------------------------------------------------------
 // K_transform: per entity row, TRS -> TransformationMatrix + StaticAABB, then the spatial-hash
 // section decision of BoundingBoxTree::add_entity (world/bounding_box_tree_v2.rs:563-579).
 // mode 0 = registration (EntityTransformationBuilder::write_components: only supplied factors)
@@ -544,11 +519,7 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
 template <bool K32>
 __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
                                                             uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A) {
-    const uint32_t warm = nsp >> 8;                                           // WARM_* of the kernels that follow in this frame
-    uint32_t acc = 0;
-    if (warm && blockIdx.x + 8u >= gridDim.x) acc = warm_code(warm, threadIdx.x, CULL_THREADS);      // the last eight workgroups: late enough to survive the stream
-    scan_cull_body<K32>(blockIdx.x, gridDim.x, keys, ncells, nsp & 0xFFu, s0, c0, s1, c1, s2, c2, s3, c3, chunk_level, A);
-    if (warm) warm_sink(acc);
+    scan_cull_body<K32>(blockIdx.x, gridDim.x, keys, ncells, nsp, s0, c0, s1, c1, s2, c2, s3, c3, chunk_level, A);
 }
 template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
@@ -893,7 +864,7 @@ __global__ __launch_bounds__(256) void k_emit_count_sharded(const FrameHeader *h
 //   * every workgroup moves tiles of PACK_LARGE_TILE instances of ONE shard: rank inside the tile with LDS atomics, ONE global atomic per
 //     (tile, non-empty group) on the shard's own fill counter (contention: tiles of one shard only), then id + 64-byte matrix with 4 lanes per
 //     instance; the matrix loads are issued before the atomics return, so the tile costs two dependent round trips (list entry -> matrix).
-extern "C" __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
+__global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
     constexpr uint32_t NT = 256, TILE = PACK_LARGE_TILE, PER = TILE / NT, CHUNK = 8u, PASSES = TILE / 64u;
     static_assert(PASSES % CHUNK == 0, "matrix passes go in chunks");
     __shared__ uint32_t s_gbase[COUNT_SLOTS_MAX];             // first instance of each group (absolute)
@@ -905,7 +876,6 @@ extern "C" __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) 
         if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
         return;
     }
-    if (A.warm && bid < 8u) warm_sink(warm_code(A.warm, tid, NT));              // (eight of the many workgroups wait ~1 us for the next kernel's code lines)
     // ---- workgroup b works on cursor shard b & 7, tiles (b >> 3), (b >> 3) + gridDim / 8, ... of that shard's segment: the mapping does not depend on
     // the counts, so the first tile's list entries are requested together with the cursors and the group counts (entries beyond the shard's
     // count are stale but harmless: masked below)
@@ -1257,11 +1227,8 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows) {
-    uint32_t acc = 0;
-    if (A.warm && blockIdx.x < 8u) acc = warm_code(A.warm, threadIdx.x, 256u);      // a static world: the next launch is the next frame's scan
+__global__ __launch_bounds__(256) void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows) {
     pack_small_body(blockIdx.x, gridDim.x, hdr, hdr_next, th, A, K, nrows);
-    if (A.warm) warm_sink(acc);
 }
 
 // Software-pipelined frame loop of a static world: the launch of frame f + 1 carries the pack of frame f in its first workgroups
@@ -1370,18 +1337,17 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
 // read -- and TransformationMatrix, StaticAABB, Rotation written -- as contiguous streams (80 B read + 104 B written per
 // ticking entity); the only gathers are the section stamp (the visibility gate) and, for ticking entities, the key of their section.
 // Counters: one atomic per wave (ballot + mbcnt), as in the cull kernel.
-extern "C" __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+__global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                               float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
                                               RowArrays R, const uint32_t *__restrict__ row_cell,
                                               const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                               const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
                                               TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame, uint32_t warm) {
+                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
     // An EARLIER tick left the tree stale: this frame is replayed by the host.  The flag a workgroup of THIS tick raises when it finds a
     // mover must not stop the workgroups of the same tick that start later (they would skip their entities for good): the frame travels
     // with the flag in one 64-bit word.
-    if (warm && blockIdx.x + 8u >= gridDim.x) warm_sink(warm_code(warm, threadIdx.x, 256u));      // the next frame's scan finds its code in the L2s
     {
         const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(spec);
         if ((uint32_t)w != 0u && (uint32_t)(w >> 32) != tick_frame) return;     // tick_frame: the frame this tick was issued for (a cancelled frame never wrote its parameters, so Pp->frame would be the stale one's)
@@ -1495,7 +1461,7 @@ extern "C" __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *_
         const uint32_t lane = lane_id();
         uint32_t base_r = 0, base_o = 0;
         if (lane == 0) {
-            atomicAdd(&th->n_changed, (uint32_t)__popcll(mc));
+            atomicAdd(&th->shard[((blockIdx.x * 4u + (threadIdx.x >> 6)) & (TICK_TICKET_SHARDS - 1u)) * 16u], (uint32_t)__popcll(mc));   // n_changed, sharded: ONE address takes ~88 atomics per us (measured: 1,575 waves = 18 us of a 25 us launch)
             if (mr) base_r = atomicAdd(&th->n_rebucket, (uint32_t)__popcll(mr));
             if (mo) base_o = atomicAdd(&th->n_oob, (uint32_t)__popcll(mo));
             if (mr | mo) {                                                        // {stale = 1, stale_frame = frame} in one store: the host must patch the tree / retire the rows before any later frame runs
@@ -1513,7 +1479,8 @@ extern "C" __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *_
 // stream synchronise considers finished).
 __global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const uint32_t a = th->n_changed, b = th->n_rebucket, c2 = th->n_oob;
+    uint32_t a = th->n_changed; for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) a += th->shard[k * 16u];       // (n_changed itself: the per-lane adds of a change batch, k_apply_rows)
+    const uint32_t b = th->n_rebucket, c2 = th->n_oob;
     h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
     publish_to_host(&h_th->ticket, seq);
 }
