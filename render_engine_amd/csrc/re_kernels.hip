@@ -162,6 +162,7 @@ __device__ __forceinline__ uint32_t shard_item_index(uint32_t t, const ShardMap 
 }
 
 constexpr uint32_t EMIT_MAX = 4u;                              // sections one lane can hold per reservation (rounds of 64 visible sections per slice)
+static_assert(EMIT_MAX * 64u == EMIT_SECTIONS_PER_WAVE, "k_emit_visible's grid is sized with EMIT_SECTIONS_PER_WAVE");
 
 // row0 / gc0: entry rb of the pool, fetched by the caller ahead of the cursor atomic (k == 0 when first == 0)
 // hist: the wave's LDS histogram of group slots (in-scan counting, see ItemSink), or nullptr: then a counting frame adds straight to
@@ -444,6 +445,17 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
 #ifdef RE_EXP_STAMPS
                 tl_pred = wall_clock64();
 #endif
+                if (R.vis_list) {
+                    // split mode: a wave of a wide frustum holds up to 512 visible sections, and ~1 such wave per SIMD would spend ~15 us on their dependent round
+                    // trips one after the other; it only leaves them in segment (wave & 63) of the list (one reservation per wave) and k_emit_visible,
+                    // launched behind the scan, runs stage B with every section in its own lane across the whole device
+                    uint32_t base = 0;
+                    if (lane == 0 && nv) base = atomicAdd(hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u + 3u, nv);
+                    base = __shfl(base, 0, 64);
+                    uint32_t *seg = R.vis_list + (size_t)(wave & (COUNTER_SHARDS - 1u)) * R.vis_seg_cap;
+                    for (uint32_t i = lane; i < nv; i += 64u) if (base + i < R.vis_seg_cap) seg[base + i] = q_idx[i];
+                    nv = 0;                                                     // (nothing left for stage B here)
+                }
                 // stage B -- the visible sections only (usually one round of 64): everything indexed by the section in one memory round trip,
                 // then distance, LOD, active / cached-static row ranges, and the instance expansion
 #pragma unroll 1
@@ -523,6 +535,65 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
 }
 template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
+
+// Stage B of the cull for a split-mode frame (ScanCullArgs::vis_list): the visible sections the scan left in 64 list segments, 256 per wave
+// and round -- the same code as the in-place stage B of scan_cull_body, fed from the list instead of the wave's own candidates.
+__global__ __launch_bounds__(256) void k_emit_visible(EmitArgs A) {
+    if (A.spec->stale) return;
+    __shared__ uint32_t s_dist[4][EMIT_MAX * 64u];
+    extern __shared__ uint32_t s_dyn[];
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = blockIdx.x * 4u + wid, nwaves = gridDim.x * 4u;
+    const FrameParams &P = A.P; const ItemSink &K = A.K; FrameHeader *hdr = A.hdr;
+    // entry g of the concatenated segments: segment = the last one whose first entry is <= g (64 counts, one per lane; wave prefix sum)
+    const uint32_t cnt_l = hdr->counters[lane * 16u + 3u], cnt = cnt_l < A.vis_seg_cap ? cnt_l : A.vis_seg_cap;
+    const uint32_t incl = wave_incl_scan(cnt), excl = incl - cnt, total = __shfl(incl, 63, 64);
+    uint32_t *hist = K.group_count ? s_dyn + wid * K.count_nslots : nullptr;
+    if (hist) for (uint32_t i = lane; i < K.count_nslots; i += 64u) hist[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t vis_map_acc = 0, vis_vec_acc = 0; bool any = false;
+#pragma unroll 1
+    for (uint32_t vbase = wave * (EMIT_MAX * 64u); vbase < total; vbase += nwaves * (EMIT_MAX * 64u)) {
+        any = true;
+        uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
+#pragma unroll
+        for (uint32_t j = 0; j < EMIT_MAX; j++) {
+            const uint32_t g = vbase + j * 64u + lane;
+            rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
+            if (vbase + j * 64u < total) {                                 // wave-uniform
+                const bool on = g < total;
+                uint32_t lo = 0, hi = 63;                                  // binary search over the lanes' exclusive prefix sums
+#pragma unroll
+                for (int step = 0; step < 6; step++) { const uint32_t mid = (lo + hi + 1u) >> 1; const uint32_t ex = __shfl(excl, mid, 64); if (ex <= g) lo = mid; else hi = mid - 1u; }
+                const uint32_t seg_first = __shfl(excl, lo, 64);
+                const uint32_t e = on ? A.vis_list[(size_t)lo * A.vis_seg_cap + (g - seg_first)] : 0u, c = e & 0x3FFFFFFFu, mult = e >> 30;
+                const uint8_t f = A.cell_flags[c];
+                const Aabb t = A.cell_tight[c];
+                const uint32_t nl = A.cell_nlocal[c], ns = A.cell_nstatic[c] + A.cell_nghost[c], cb = A.cell_begin[c];
+                if (on && !(f & CF_PAD)) {
+                    A.cell_stamp[c] = (P.frame << 2) | mult;
+                    vis_map_acc += 1; vis_vec_acc += mult;
+                    float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
+                    bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
+                    bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
+                    rbv[j] = cb + (act ? 0u : nl);
+                    cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
+                    uint32_t mm = P.emit_duplicates ? mult : 1u;
+                    lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
+                    if (K.gc_lodtab) s_dist[wid][j * 64u + lane] = __float_as_uint(d);
+                }
+            }
+        }
+        emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, hist, K.gc_lodtab ? s_dist[wid] : nullptr);
+    }
+    if (!any) return;
+    if (hist) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t *gc = K.group_count + (K.nshards > 1u ? (wave & (CURSOR_SHARDS - 1u)) : 0u) * K.count_nslots;
+        for (uint32_t i = lane; i < K.count_nslots; i += 64u) { const uint32_t v = hist[i]; if (v) atomicAdd(&gc[i], v); }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); }
+    if (lane == 0 && vis_map_acc) { uint32_t *cn = hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u; atomicAdd(cn + 1, vis_map_acc); atomicAdd(cn + 2, vis_vec_acc); }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Probe path (RE_CFG_PROBE): the same stage A / stage B as k_scan_cull, fed by hash probes of the candidate cells
