@@ -1208,7 +1208,8 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         E.cell_flags = SA.cell_flags; E.cell_stamp = SA.cell_stamp; E.K = SA.K; E.hdr = hdr; E.spec = c->d_spec.p; E.vis_list = c->d_vis_list.p; E.vis_seg_cap = c->vis_seg_cap;
         // one wave per 256 listed sections (predicted from the last frame, +12 %); a longer list makes the waves loop
         const uint32_t waves = (c->pred_vis + c->pred_vis / 8u) / (EMIT_SECTIONS_PER_WAVE) + 8u;
-        const uint32_t egrid = std::min(std::max((waves + 3u) / 4u, 64u), 16384u);
+        static const char *eg_env = getenv("RE_EXP_EMIT_GRID");                  // experiments only
+        const uint32_t egrid = eg_env ? (uint32_t)atoi(eg_env) : std::min(std::max((waves + 3u) / 4u, 64u), 16384u);
         hipEvent_t ea = nullptr, eb = nullptr;
         if (c->k1_timing && c->k1_kind == RE_TIME_EMIT) take_timing_events(c, &ea, &eb);
         hipExtLaunchKernelGGL(k_emit_visible, dim3(egrid), dim3(256), scan_lds, st, ea, eb, 0, E);

@@ -56,9 +56,9 @@ struct FrameParams {
 };
 constexpr uint32_t COUNTER_SHARDS = 64;
 constexpr uint32_t PACK_STAGED_GROUPS = 256;   // k_pack_small stages up to this many InstanceRanges in LDS before one wave writes them to the host
-constexpr uint32_t CURSOR_SHARDS = 8;
+constexpr uint32_t CURSOR_SHARDS = 8, CURSOR_STRIDE = 16;
 struct FrameHeader {
-    unsigned long long cursors[CURSOR_SHARDS * 8];   // one per 64-byte line; low 32: emitting sections, high 32: instances.  Sharded by
+    unsigned long long cursors[CURSOR_SHARDS * CURSOR_STRIDE];   // one per 128-byte line (global atomics serialise per LINE, ~87 per us: tools/cpp/atomic_line_probe.hip); low 32: emitting sections, high 32: instances.  Sharded by
                                             // wave index mod 8, because a single word saturates near 88 atomics/us
     uint32_t counters[COUNTER_SHARDS * 16]; // one shard per 64-byte line: [0] sections inside a candidate box (== hash probes of the
                                             // reference), [1] visible sections (map), [2] visible sections (vec, with duplicates)

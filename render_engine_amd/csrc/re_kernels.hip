@@ -149,7 +149,7 @@ __device__ __forceinline__ ShardMap load_shard_map(const FrameHeader *hdr, uint3
     ShardMap m; m.total = 0;
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
-        uint32_t v = k < nshards ? (uint32_t)(hdr->cursors[k * 8] >> 32) : 0u;
+        uint32_t v = k < nshards ? (uint32_t)(hdr->cursors[k * CURSOR_STRIDE] >> 32) : 0u;
         m.n[k] = v < seg_cap ? v : seg_cap; m.total += m.n[k];
     }
     return m;
@@ -191,12 +191,13 @@ __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t 
 // register stays live for it across the reservation; dist0: the same for callers that hold one section per lane in registers (shared sections)
 __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MAX], const uint32_t (&cnt)[EMIT_MAX], const uint32_t (&lodm)[EMIT_MAX],
                                                     FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint, uint32_t *hist = nullptr,
-                                                    const uint32_t *dist_lds = nullptr, float dist0 = 0.0f) {
+                                                    const uint32_t *dist_lds = nullptr, float dist0 = 0.0f, uint32_t *wg = nullptr) {
+    // wg (12 words of LDS; every wave of the workgroup calls with the same shard_hint): ONE reservation for the workgroup's waves instead of one per wave
     uint32_t mine = 0, nsec = 0;
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) { uint32_t n = cnt[j] * ((lodm[j] >> 8) & 3u); mine += n; nsec += n ? 1u : 0u; }
     uint64_t mask = __ballot(mine > 0);
-    if (!mask) return;
+    if (!mask && !wg) return;
     // the first pool entry of every section is requested before the reservation: its round trip overlaps the atomic's
     uint32_t row0[EMIT_MAX], gc0[EMIT_MAX];
 #pragma unroll
@@ -205,8 +206,24 @@ __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MA
     uint32_t tot = __shfl(incl, 63, 64), tots = __shfl(incs, 63, 64);
     const uint32_t shard = K.nshards > 1u ? (shard_hint & (CURSOR_SHARDS - 1u)) : 0u;      // wave-uniform (list / section-block index)
     unsigned long long base = 0;
-    if (lane_id() == 0) base = atomicAdd(&hdr->cursors[shard * 8u], (unsigned long long)tots | ((unsigned long long)tot << 32));
-    base = __shfl(base, 0, 64);
+    if (wg) {
+        const uint32_t wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        if (lane_id() == 0) { wg[wid] = tot; wg[4u + wid] = tots; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t T = 0, Ts = 0; for (uint32_t w = 0; w < nw; w++) { T += wg[w]; Ts += wg[4u + w]; }
+            const unsigned long long b = T ? atomicAdd(&hdr->cursors[shard * CURSOR_STRIDE], (unsigned long long)Ts | ((unsigned long long)T << 32)) : 0ull;
+            wg[8] = (uint32_t)b; wg[9] = (uint32_t)(b >> 32);
+        }
+        __syncthreads();
+        uint32_t pt = 0, ps = 0; for (uint32_t w = 0; w < wid; w++) { pt += wg[w]; ps += wg[4u + w]; }
+        base = ((unsigned long long)wg[8] | ((unsigned long long)wg[9] << 32)) + ((unsigned long long)ps | ((unsigned long long)pt << 32));
+        __syncthreads();                                                   // (wg is written again in the next round)
+        if (!mask) return;
+    } else {
+        if (lane_id() == 0) base = atomicAdd(&hdr->cursors[shard * CURSOR_STRIDE], (unsigned long long)tots | ((unsigned long long)tot << 32));
+        base = __shfl(base, 0, 64);
+    }
     uint32_t off = (uint32_t)(base >> 32) + (incl - mine);
     const uint32_t seg_base = shard * K.seg_cap;
     const uint32_t WIDE = 32u;
@@ -542,18 +559,22 @@ __global__ __launch_bounds__(256) void k_emit_visible(EmitArgs A) {
     if (A.spec->stale) return;
     __shared__ uint32_t s_dist[4][EMIT_MAX * 64u];
     extern __shared__ uint32_t s_dyn[];
-    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6, wave = blockIdx.x * 4u + wid, nwaves = gridDim.x * 4u;
+    __shared__ uint32_t s_wg[12], s_cnt[2];
+    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6;
     const FrameParams &P = A.P; const ItemSink &K = A.K; FrameHeader *hdr = A.hdr;
     // entry g of the concatenated segments: segment = the last one whose first entry is <= g (64 counts, one per lane; wave prefix sum)
     const uint32_t cnt_l = hdr->counters[lane * 16u + 3u], cnt = cnt_l < A.vis_seg_cap ? cnt_l : A.vis_seg_cap;
     const uint32_t incl = wave_incl_scan(cnt), excl = incl - cnt, total = __shfl(incl, 63, 64);
-    uint32_t *hist = K.group_count ? s_dyn + wid * K.count_nslots : nullptr;
-    if (hist) for (uint32_t i = lane; i < K.count_nslots; i += 64u) hist[i] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t vis_map_acc = 0, vis_vec_acc = 0; bool any = false;
+    // one histogram, one reservation per round and one pair of frame counters per WORKGROUP: global atomics serialise per 128-byte line
+    uint32_t *hist = K.group_count ? s_dyn : nullptr;
+    if (hist) for (uint32_t i = threadIdx.x; i < K.count_nslots; i += 256u) hist[i] = 0u;
+    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t vis_map_acc = 0, vis_vec_acc = 0;
+    if (blockIdx.x * (4u * EMIT_MAX * 64u) >= total) return;                // workgroup-uniform
 #pragma unroll 1
-    for (uint32_t vbase = wave * (EMIT_MAX * 64u); vbase < total; vbase += nwaves * (EMIT_MAX * 64u)) {
-        any = true;
+    for (uint32_t wbase = blockIdx.x * (4u * EMIT_MAX * 64u); wbase < total; wbase += gridDim.x * (4u * EMIT_MAX * 64u)) {   // workgroup-uniform trip count (barriers inside)
+        const uint32_t vbase = wbase + wid * (EMIT_MAX * 64u);
         uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
 #pragma unroll
         for (uint32_t j = 0; j < EMIT_MAX; j++) {
@@ -566,6 +587,9 @@ __global__ __launch_bounds__(256) void k_emit_visible(EmitArgs A) {
                 for (int step = 0; step < 6; step++) { const uint32_t mid = (lo + hi + 1u) >> 1; const uint32_t ex = __shfl(excl, mid, 64); if (ex <= g) lo = mid; else hi = mid - 1u; }
                 const uint32_t seg_first = __shfl(excl, lo, 64);
                 const uint32_t e = on ? A.vis_list[(size_t)lo * A.vis_seg_cap + (g - seg_first)] : 0u, c = e & 0x3FFFFFFFu, mult = e >> 30;
+#if defined(RE_EXP_EMIT_STAGE) && RE_EXP_EMIT_STAGE == 1
+                if (e == 0x7FFFFFFFu) A.cell_stamp[0] = e; continue;          // experiment: list lookup only
+#endif
                 const uint8_t f = A.cell_flags[c];
                 const Aabb t = A.cell_tight[c];
                 const uint32_t nl = A.cell_nlocal[c], ns = A.cell_nstatic[c] + A.cell_nghost[c], cb = A.cell_begin[c];
@@ -583,16 +607,22 @@ __global__ __launch_bounds__(256) void k_emit_visible(EmitArgs A) {
                 }
             }
         }
-        emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, hist, K.gc_lodtab ? s_dist[wid] : nullptr);
+#if defined(RE_EXP_EMIT_STAGE) && RE_EXP_EMIT_STAGE == 2
+        if (rbv[0] + cntv[1] + lodv[2] + rbv[3] == 0x7FFFFFFFu) A.cell_stamp[0] = 1u; continue;   // experiment: section gathers, no expansion
+#endif
+        emit_sections_multi(rbv, cntv, lodv, hdr, K, blockIdx.x, hist, K.gc_lodtab ? s_dist[wid] : nullptr, 0.0f, s_wg);
     }
-    if (!any) return;
-    if (hist) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t *gc = K.group_count + (K.nshards > 1u ? (wave & (CURSOR_SHARDS - 1u)) : 0u) * K.count_nslots;
-        for (uint32_t i = lane; i < K.count_nslots; i += 64u) { const uint32_t v = hist[i]; if (v) atomicAdd(&gc[i], v); }
-    }
+#if defined(RE_EXP_EMIT_STAGE) && RE_EXP_EMIT_STAGE == 3
+    return;                                                                 // experiment: no histogram flush, no frame counters
+#endif
     for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); }
-    if (lane == 0 && vis_map_acc) { uint32_t *cn = hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u; atomicAdd(cn + 1, vis_map_acc); atomicAdd(cn + 2, vis_vec_acc); }
+    if (lane == 0 && vis_map_acc) { atomicAdd(&s_cnt[0], vis_map_acc); atomicAdd(&s_cnt[1], vis_vec_acc); }
+    __syncthreads();
+    if (hist) {
+        uint32_t *gc = K.group_count + (K.nshards > 1u ? (blockIdx.x & (CURSOR_SHARDS - 1u)) : 0u) * K.count_nslots;
+        for (uint32_t i = threadIdx.x; i < K.count_nslots; i += 256u) { const uint32_t v = hist[i]; if (v) atomicAdd(&gc[i], v); }
+    }
+    if (threadIdx.x == 0 && s_cnt[0]) { uint32_t *cn = hdr->counters + (blockIdx.x & (COUNTER_SHARDS - 1u)) * 16u; atomicAdd(cn + 1, s_cnt[0]); atomicAdd(cn + 2, s_cnt[1]); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -848,7 +878,7 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
     if (wid == 0) fc = load_frame_counts(hdr);
     if (threadIdx.x == 0) {
         uint32_t nsec = 0, nitems = 0, table_hash = 0;
-        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * 8]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * CURSOR_STRIDE]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
         for (uint32_t w = 0; w < 16u; w++) table_hash ^= s_whash[w];
         HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry < range_cap ? s_gcarry : range_cap; r.total = s_carry; r.n_candidates = fc.n_candidates;
         r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
@@ -916,7 +946,7 @@ __global__ __launch_bounds__(256) void k_emit_count_sharded(const FrameHeader *h
     extern __shared__ uint32_t s_hist[];
     if (spec->stale) return;
     const uint32_t shard = blockIdx.x % nshards, part = blockIdx.x / nshards, parts = gridDim.x / nshards;
-    uint32_t n = (uint32_t)(hdr->cursors[shard * 8u] >> 32); if (n > seg_cap) n = seg_cap;
+    uint32_t n = (uint32_t)(hdr->cursors[shard * CURSOR_STRIDE] >> 32); if (n > seg_cap) n = seg_cap;
     for (uint32_t i = threadIdx.x; i < nslots; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
     for (uint32_t t = part * blockDim.x + threadIdx.x; t < n; t += parts * blockDim.x) {
@@ -961,7 +991,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
     uint32_t n_sh = 0, raw_items = 0, raw_sec = 0;
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
-        const unsigned long long cur = k < nsh ? A.hdr->cursors[k * 8] : 0ull;
+        const unsigned long long cur = k < nsh ? A.hdr->cursors[k * CURSOR_STRIDE] : 0ull;
         const uint32_t v = (uint32_t)(cur >> 32);
         raw_sec += (uint32_t)cur; raw_items += v;
         if (k == shard) n_sh = v < A.seg_cap ? v : A.seg_cap;
@@ -1147,7 +1177,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     // ---- round trip 1: everything that needs no other load
     unsigned long long cur[CURSOR_SHARDS];
 #pragma unroll
-    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) cur[k] = hdr->cursors[k * 8];
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) cur[k] = hdr->cursors[k * CURSOR_STRIDE];
     uint32_t sl[CURSOR_SHARDS];
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) sl[k] = tid < K.seg_cap ? K.item_slot[k * K.seg_cap + tid] : 0xFFFFFFFFu;
