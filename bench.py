@@ -339,7 +339,6 @@ def far_leg(R, ents, atomic, centre, n_total, key_bytes):
     kt = kernel_times(p, cam, 12)
     per = pipelined_frames(p, cam, 16); per = pipelined_frames(p, cam, 64)
     own = {"k_scan_cull": {"sync_frames": launch_us(p, cam, "scan", 48, False), "async_frames": launch_us(p, cam, "scan", 96, True)},
-           "k_emit_visible": {"sync_frames": launch_us(p, cam, "emit", 48, False), "async_frames": launch_us(p, cam, "emit", 96, True)},
            "k_pack_large": {"sync_frames": launch_us(p, cam, "pack_large", 48, False), "async_frames": launch_us(p, cam, "pack_large", 96, True)}}
     V, S, slots = vis["total"], vis["n_visible_sections"], stats["n_section_slots"]
     b_scan = key_bytes * slots + 4 * ((slots + 511) // 512) + 41 * S + 16 * V

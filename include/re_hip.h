@@ -370,7 +370,6 @@ int re_get_timings(re_ctx *ctx, float *cull_us, float *pack_us, float *tick_us);
 #define RE_TIME_SCAN        0u
 #define RE_TIME_TICK        1u
 #define RE_TIME_PACK_LARGE  2u
-#define RE_TIME_EMIT        3u   /* k_emit_visible: stage B of the cull when a large visible set is expected (split mode) */
 int re_timing_begin(re_ctx *ctx, uint32_t max_launches, uint32_t every);
 int re_timing_collect(re_ctx *ctx, float *microseconds, uint32_t capacity, uint32_t *n);
 /* number of world sections inside a candidate box in the last cull (== hash probes the reference would make) */

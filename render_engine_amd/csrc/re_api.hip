@@ -190,7 +190,6 @@ struct re_ctx {
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
     uint32_t n_device_rebuckets = 0;
-    DevBuf<uint32_t> d_vis_list; uint32_t vis_seg_cap = 0, pred_vis = 0, n_split_frames = 0;   // split-mode cull (k_emit_visible): the scan's list of visible sections, 64 segments
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -762,7 +761,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->frame = 0; c->lane_seq = 0; c->th_clean = true; c->pred_total = 0; c->pred_vis = 0;
+    c->frame = 0; c->lane_seq = 0; c->th_clean = true; c->pred_total = 0;
     return upload_lod_tables(c);
 }
 
@@ -1003,7 +1002,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     c->timings_pending = c->timed_frame;                                      // the events are read in re_get_timings (they may still be in flight here)
-    c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates; c->pred_vis = c->h_res->n_vis_map;
+    c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
     {   // The group table carries a seal: a hash over every table word, tied to the frame number and the counts (result_seal).  With the
         // publication protocol of publish_to_host the block is complete when "frame done" is visible, so the check below passes at first
         // sight; n_seal_waits / n_sync_fallbacks (re_stats) count the times it did not, and the GPU tests assert that both stay 0.
@@ -1103,7 +1102,7 @@ static int flush_deferred_pack(re_ctx *c) {
 
 static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     hipStream_t st = c->stream;
-    if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); c->pred_vis = std::max(c->pred_vis, c->h_res->n_vis_map); }   // hint from an earlier async frame, if it has landed
+    if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
     const FrameParams &P = c->P;
@@ -1128,7 +1127,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     uint32_t scan_grid = std::max(1u, (c->nlists + (CULL_THREADS / 64) - 1) / (CULL_THREADS / 64));
     ScanCullArgs SA; SA.B = c->PB; SA.B32 = c->PB32; SA.cell_key64 = c->d_cell_key.p; SA.P = P; SA.P_dev = c->d_params.p;
     SA.cell_tight = c->d_cell_tight.p; SA.cell_begin = c->d_cell_begin.p; SA.cell_nlocal = c->d_cell_nlocal.p; SA.cell_nstatic = c->d_cell_nstatic.p; SA.cell_nghost = c->d_cell_nghost.p;
-    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c, c->lane_seq); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p; SA.vis_list = nullptr; SA.vis_seg_cap = 0;
+    SA.cell_flags = c->d_cell_flags.p; SA.cell_stamp = c->d_cell_stamp.p; SA.K = item_sink(c, c->lane_seq); SA.hdr = hdr; SA.S = shared_arrays(c); SA.spec = c->d_spec.p;
     // a large visible set is expected: the scan counts the instances per (cursor shard, group slot) while it expands them, so the pack is one launch
     const bool count_in_scan = !small && c->nslots <= COUNT_SLOTS_MAX && c->d_gcount.p != nullptr;
     size_t scan_lds = 0;
@@ -1180,15 +1179,6 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     const bool fuse = c->deferred_pack && !probed && c->deferred_grid < (1u << 20);
     if (c->deferred_pack && !fuse) { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     const size_t fused_lds = (size_t)std::max(c->nslots, 1u) * 8;
-    // split mode: with a large visible set expected, the candidate waves only list their visible sections and k_emit_visible expands them
-    // (the in-place chain of a wave holding 512 visible sections is the critical path of a wide frustum)
-    static const bool split_off = getenv("RE_EXP_NO_SPLIT") != nullptr;     // A/B switch
-    const bool split = count_in_scan && !probed && !fuse && !split_off;
-    if (split) {
-        const uint32_t seg_cap = c->ncells / COUNTER_SHARDS + 2048u;
-        if (c->vis_seg_cap != seg_cap || !c->d_vis_list.p) { HIPCHK(c, c->d_vis_list.alloc((size_t)seg_cap * COUNTER_SHARDS, &c->dev_bytes)); c->vis_seg_cap = seg_cap; }
-        SA.vis_list = c->d_vis_list.p; SA.vis_seg_cap = seg_cap;
-    }
     if (probed) {}
     else if (fuse && c->key32)
         hipExtLaunchKernelGGL(k_scan_cull_fused<true>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n | (c->deferred_grid << 8),
@@ -1203,18 +1193,6 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         hipExtLaunchKernelGGL(k_scan_cull<false>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     if (fuse) { c->deferred_pack = false; c->n_fused_frames++; }
-    if (split) {
-        EmitArgs E{}; E.P = P; E.cell_tight = SA.cell_tight; E.cell_begin = SA.cell_begin; E.cell_nlocal = SA.cell_nlocal; E.cell_nstatic = SA.cell_nstatic; E.cell_nghost = SA.cell_nghost;
-        E.cell_flags = SA.cell_flags; E.cell_stamp = SA.cell_stamp; E.K = SA.K; E.hdr = hdr; E.spec = c->d_spec.p; E.vis_list = c->d_vis_list.p; E.vis_seg_cap = c->vis_seg_cap;
-        // one wave per 256 listed sections (predicted from the last frame, +12 %); a longer list makes the waves loop
-        const uint32_t waves = (c->pred_vis + c->pred_vis / 8u) / (EMIT_SECTIONS_PER_WAVE) + 8u;
-        static const char *eg_env = getenv("RE_EXP_EMIT_GRID");                  // experiments only
-        const uint32_t egrid = eg_env ? (uint32_t)atoi(eg_env) : std::min(std::max((waves + 3u) / 4u, 64u), 16384u);
-        hipEvent_t ea = nullptr, eb = nullptr;
-        if (c->k1_timing && c->k1_kind == RE_TIME_EMIT) take_timing_events(c, &ea, &eb);
-        hipExtLaunchKernelGGL(k_emit_visible, dim3(egrid), dim3(256), scan_lds, st, ea, eb, 0, E);
-        c->n_split_frames++;
-    }
     HIPCHK(c, hipGetLastError());
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
@@ -2794,7 +2772,7 @@ extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches, uint32_t every)
     HIPCHK(c, hipSetDevice(c->device));
     while (c->k1_events.size() < (size_t)max_launches * 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->k1_events.push_back(e); }
     c->k1_used = 0; c->k1_timing = max_launches > 0; c->k1_every = std::max(every & 0xFFFFu, 1u); c->k1_kind = every >> 16; c->k1_seen = 0;
-    if (c->k1_kind > RE_TIME_EMIT) return c->fail(RE_E_ARG, "re_timing_begin: unknown kernel selector");
+    if (c->k1_kind > RE_TIME_PACK_LARGE) return c->fail(RE_E_ARG, "re_timing_begin: unknown kernel selector");
     return RE_OK;
 }
 extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) {

@@ -140,8 +140,6 @@ struct ScanCullArgs {                       // the kernel-argument segment of k_
     FrameParams P; FrameParams *P_dev;
     const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic, *cell_nghost; const uint8_t *cell_flags; uint32_t *cell_stamp;
     ItemSink K; FrameHeader *hdr; SharedArrays S; const SpecState *spec;
-    uint32_t *vis_list; uint32_t vis_seg_cap;   // split mode (a large visible set is expected): candidate waves only append their visible sections (index | multiplicity << 30) to
-                                            // segment (wave & 63) of this list, counted in hdr->counters[shard * 16 + 3]; k_emit_visible does the rest with the whole device
 #ifdef RE_EXP_STAMPS
     unsigned long long *timeline;           // development builds: [wave] = {start, keys arrived, end} 100 MHz stamps
 #endif
@@ -155,14 +153,6 @@ template <bool K32> __global__ void k_scan_cull(const void *keys, uint32_t ncell
                                                 uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A);   // the leading scalars arrive preloaded in SGPRs
 extern template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 extern template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
-constexpr uint32_t EMIT_SECTIONS_PER_WAVE = 256;   // EMIT_MAX x 64 (re_kernels.hip)
-struct EmitArgs {                            // k_emit_visible: stage B of the cull over the list a split-mode scan left behind
-    FrameParams P;
-    const Aabb *cell_tight; const uint32_t *cell_begin, *cell_nlocal, *cell_nstatic, *cell_nghost; const uint8_t *cell_flags; uint32_t *cell_stamp;
-    ItemSink K; FrameHeader *hdr; const SpecState *spec;
-    const uint32_t *vis_list; uint32_t vis_seg_cap;
-};
-__global__ void k_emit_visible(EmitArgs A);
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows);
 struct FusedPack { FrameHeader *hdr, *hdr_next; TickHeader *th; PackArgs A; ItemSink K; uint32_t nrows, pad; };   // the previous frame's pack, carried by the next frame's launch
 template <bool K32> __global__ void k_scan_cull_fused(const void *keys, uint32_t ncells, uint32_t nsp_npack, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,

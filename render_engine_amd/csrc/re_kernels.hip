@@ -162,7 +162,6 @@ __device__ __forceinline__ uint32_t shard_item_index(uint32_t t, const ShardMap 
 }
 
 constexpr uint32_t EMIT_MAX = 4u;                              // sections one lane can hold per reservation (rounds of 64 visible sections per slice)
-static_assert(EMIT_MAX * 64u == EMIT_SECTIONS_PER_WAVE, "k_emit_visible's grid is sized with EMIT_SECTIONS_PER_WAVE");
 
 // row0 / gc0: entry rb of the pool, fetched by the caller ahead of the cursor atomic (k == 0 when first == 0)
 // hist: the wave's LDS histogram of group slots (in-scan counting, see ItemSink), or nullptr: then a counting frame adds straight to
@@ -191,13 +190,12 @@ __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t 
 // register stays live for it across the reservation; dist0: the same for callers that hold one section per lane in registers (shared sections)
 __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MAX], const uint32_t (&cnt)[EMIT_MAX], const uint32_t (&lodm)[EMIT_MAX],
                                                     FrameHeader *hdr, const ItemSink &K, uint32_t shard_hint, uint32_t *hist = nullptr,
-                                                    const uint32_t *dist_lds = nullptr, float dist0 = 0.0f, uint32_t *wg = nullptr) {
-    // wg (12 words of LDS; every wave of the workgroup calls with the same shard_hint): ONE reservation for the workgroup's waves instead of one per wave
+                                                    const uint32_t *dist_lds = nullptr, float dist0 = 0.0f) {
     uint32_t mine = 0, nsec = 0;
 #pragma unroll
     for (uint32_t j = 0; j < EMIT_MAX; j++) { uint32_t n = cnt[j] * ((lodm[j] >> 8) & 3u); mine += n; nsec += n ? 1u : 0u; }
     uint64_t mask = __ballot(mine > 0);
-    if (!mask && !wg) return;
+    if (!mask) return;
     // the first pool entry of every section is requested before the reservation: its round trip overlaps the atomic's
     uint32_t row0[EMIT_MAX], gc0[EMIT_MAX];
 #pragma unroll
@@ -206,24 +204,8 @@ __device__ __forceinline__ void emit_sections_multi(const uint32_t (&rb)[EMIT_MA
     uint32_t tot = __shfl(incl, 63, 64), tots = __shfl(incs, 63, 64);
     const uint32_t shard = K.nshards > 1u ? (shard_hint & (CURSOR_SHARDS - 1u)) : 0u;      // wave-uniform (list / section-block index)
     unsigned long long base = 0;
-    if (wg) {
-        const uint32_t wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        if (lane_id() == 0) { wg[wid] = tot; wg[4u + wid] = tots; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t T = 0, Ts = 0; for (uint32_t w = 0; w < nw; w++) { T += wg[w]; Ts += wg[4u + w]; }
-            const unsigned long long b = T ? atomicAdd(&hdr->cursors[shard * CURSOR_STRIDE], (unsigned long long)Ts | ((unsigned long long)T << 32)) : 0ull;
-            wg[8] = (uint32_t)b; wg[9] = (uint32_t)(b >> 32);
-        }
-        __syncthreads();
-        uint32_t pt = 0, ps = 0; for (uint32_t w = 0; w < wid; w++) { pt += wg[w]; ps += wg[4u + w]; }
-        base = ((unsigned long long)wg[8] | ((unsigned long long)wg[9] << 32)) + ((unsigned long long)ps | ((unsigned long long)pt << 32));
-        __syncthreads();                                                   // (wg is written again in the next round)
-        if (!mask) return;
-    } else {
-        if (lane_id() == 0) base = atomicAdd(&hdr->cursors[shard * CURSOR_STRIDE], (unsigned long long)tots | ((unsigned long long)tot << 32));
-        base = __shfl(base, 0, 64);
-    }
+    if (lane_id() == 0) base = atomicAdd(&hdr->cursors[shard * CURSOR_STRIDE], (unsigned long long)tots | ((unsigned long long)tot << 32));
+    base = __shfl(base, 0, 64);
     uint32_t off = (uint32_t)(base >> 32) + (incl - mine);
     const uint32_t seg_base = shard * K.seg_cap;
     const uint32_t WIDE = 32u;
@@ -462,17 +444,6 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
 #ifdef RE_EXP_STAMPS
                 tl_pred = wall_clock64();
 #endif
-                if (R.vis_list) {
-                    // split mode: a wave of a wide frustum holds up to 512 visible sections, and ~1 such wave per SIMD would spend ~15 us on their dependent round
-                    // trips one after the other; it only leaves them in segment (wave & 63) of the list (one reservation per wave) and k_emit_visible,
-                    // launched behind the scan, runs stage B with every section in its own lane across the whole device
-                    uint32_t base = 0;
-                    if (lane == 0 && nv) base = atomicAdd(hdr->counters + (wave & (COUNTER_SHARDS - 1u)) * 16u + 3u, nv);
-                    base = __shfl(base, 0, 64);
-                    uint32_t *seg = R.vis_list + (size_t)(wave & (COUNTER_SHARDS - 1u)) * R.vis_seg_cap;
-                    for (uint32_t i = lane; i < nv; i += 64u) if (base + i < R.vis_seg_cap) seg[base + i] = q_idx[i];
-                    nv = 0;                                                     // (nothing left for stage B here)
-                }
                 // stage B -- the visible sections only (usually one round of 64): everything indexed by the section in one memory round trip,
                 // then distance, LOD, active / cached-static row ranges, and the instance expansion
 #pragma unroll 1
@@ -552,78 +523,6 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
 }
 template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
-
-// Stage B of the cull for a split-mode frame (ScanCullArgs::vis_list): the visible sections the scan left in 64 list segments, 256 per wave
-// and round -- the same code as the in-place stage B of scan_cull_body, fed from the list instead of the wave's own candidates.
-__global__ __launch_bounds__(256) void k_emit_visible(EmitArgs A) {
-    if (A.spec->stale) return;
-    __shared__ uint32_t s_dist[4][EMIT_MAX * 64u];
-    extern __shared__ uint32_t s_dyn[];
-    __shared__ uint32_t s_wg[12], s_cnt[2];
-    const uint32_t lane = lane_id(), wid = threadIdx.x >> 6;
-    const FrameParams &P = A.P; const ItemSink &K = A.K; FrameHeader *hdr = A.hdr;
-    // entry g of the concatenated segments: segment = the last one whose first entry is <= g (64 counts, one per lane; wave prefix sum)
-    const uint32_t cnt_l = hdr->counters[lane * 16u + 3u], cnt = cnt_l < A.vis_seg_cap ? cnt_l : A.vis_seg_cap;
-    const uint32_t incl = wave_incl_scan(cnt), excl = incl - cnt, total = __shfl(incl, 63, 64);
-    // one histogram, one reservation per round and one pair of frame counters per WORKGROUP: global atomics serialise per 128-byte line
-    uint32_t *hist = K.group_count ? s_dyn : nullptr;
-    if (hist) for (uint32_t i = threadIdx.x; i < K.count_nslots; i += 256u) hist[i] = 0u;
-    if (threadIdx.x < 2u) s_cnt[threadIdx.x] = 0u;
-    __syncthreads();
-    uint32_t vis_map_acc = 0, vis_vec_acc = 0;
-    if (blockIdx.x * (4u * EMIT_MAX * 64u) >= total) return;                // workgroup-uniform
-#pragma unroll 1
-    for (uint32_t wbase = blockIdx.x * (4u * EMIT_MAX * 64u); wbase < total; wbase += gridDim.x * (4u * EMIT_MAX * 64u)) {   // workgroup-uniform trip count (barriers inside)
-        const uint32_t vbase = wbase + wid * (EMIT_MAX * 64u);
-        uint32_t rbv[EMIT_MAX], cntv[EMIT_MAX], lodv[EMIT_MAX];
-#pragma unroll
-        for (uint32_t j = 0; j < EMIT_MAX; j++) {
-            const uint32_t g = vbase + j * 64u + lane;
-            rbv[j] = 0; cntv[j] = 0; lodv[j] = 0;
-            if (vbase + j * 64u < total) {                                 // wave-uniform
-                const bool on = g < total;
-                uint32_t lo = 0, hi = 63;                                  // binary search over the lanes' exclusive prefix sums
-#pragma unroll
-                for (int step = 0; step < 6; step++) { const uint32_t mid = (lo + hi + 1u) >> 1; const uint32_t ex = __shfl(excl, mid, 64); if (ex <= g) lo = mid; else hi = mid - 1u; }
-                const uint32_t seg_first = __shfl(excl, lo, 64);
-                const uint32_t e = on ? A.vis_list[(size_t)lo * A.vis_seg_cap + (g - seg_first)] : 0u, c = e & 0x3FFFFFFFu, mult = e >> 30;
-#if defined(RE_EXP_EMIT_STAGE) && RE_EXP_EMIT_STAGE == 1
-                if (e == 0x7FFFFFFFu) A.cell_stamp[0] = e; continue;          // experiment: list lookup only
-#endif
-                const uint8_t f = A.cell_flags[c];
-                const Aabb t = A.cell_tight[c];
-                const uint32_t nl = A.cell_nlocal[c], ns = A.cell_nstatic[c] + A.cell_nghost[c], cb = A.cell_begin[c];
-                if (on && !(f & CF_PAD)) {
-                    A.cell_stamp[c] = (P.frame << 2) | mult;
-                    vis_map_acc += 1; vis_vec_acc += mult;
-                    float d = distance_to_aabb(t, P.cam[0], P.cam[1], P.cam[2]);
-                    bool act = !(f & CF_STATIC_SECTION) && (d < P.far_draw);     // is_section_active && render_flow.rs:754
-                    bool sta = (f & CF_STATIC_CACHED) && !(d > P.far_draw);      // cached && render_flow.rs:489
-                    rbv[j] = cb + (act ? 0u : nl);
-                    cntv[j] = (act ? nl : 0u) + (sta ? ns : 0u);
-                    uint32_t mm = P.emit_duplicates ? mult : 1u;
-                    lodv[j] = lod_index(d, P.n_lod, P.lod_min, P.lod_max) | (mm << 8);
-                    if (K.gc_lodtab) s_dist[wid][j * 64u + lane] = __float_as_uint(d);
-                }
-            }
-        }
-#if defined(RE_EXP_EMIT_STAGE) && RE_EXP_EMIT_STAGE == 2
-        if (rbv[0] + cntv[1] + lodv[2] + rbv[3] == 0x7FFFFFFFu) A.cell_stamp[0] = 1u; continue;   // experiment: section gathers, no expansion
-#endif
-        emit_sections_multi(rbv, cntv, lodv, hdr, K, blockIdx.x, hist, K.gc_lodtab ? s_dist[wid] : nullptr, 0.0f, s_wg);
-    }
-#if defined(RE_EXP_EMIT_STAGE) && RE_EXP_EMIT_STAGE == 3
-    return;                                                                 // experiment: no histogram flush, no frame counters
-#endif
-    for (int d = 32; d >= 1; d >>= 1) { vis_map_acc += __shfl_down(vis_map_acc, d, 64); vis_vec_acc += __shfl_down(vis_vec_acc, d, 64); }
-    if (lane == 0 && vis_map_acc) { atomicAdd(&s_cnt[0], vis_map_acc); atomicAdd(&s_cnt[1], vis_vec_acc); }
-    __syncthreads();
-    if (hist) {
-        uint32_t *gc = K.group_count + (K.nshards > 1u ? (blockIdx.x & (CURSOR_SHARDS - 1u)) : 0u) * K.count_nslots;
-        for (uint32_t i = threadIdx.x; i < K.count_nslots; i += 256u) { const uint32_t v = hist[i]; if (v) atomicAdd(&gc[i], v); }
-    }
-    if (threadIdx.x == 0 && s_cnt[0]) { uint32_t *cn = hdr->counters + (blockIdx.x & (COUNTER_SHARDS - 1u)) * 16u; atomicAdd(cn + 1, s_cnt[0]); atomicAdd(cn + 2, s_cnt[1]); }
-}
 
 // ---------------------------------------------------------------------------------------------
 // Probe path (RE_CFG_PROBE): the same stage A / stage B as k_scan_cull, fed by hash probes of the candidate cells

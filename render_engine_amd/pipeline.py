@@ -363,7 +363,7 @@ class Pipeline:
 
     def timing_begin(self, max_launches, every=1, kernel="scan"):
         """per-launch HIP-event timing of one kernel: "scan" (k_scan_cull), "tick" (k_tick) or "pack_large" (k_pack_large)"""
-        kind = {"scan": 0, "tick": 1, "pack_large": 2, "emit": 3}[kernel]
+        kind = {"scan": 0, "tick": 1, "pack_large": 2}[kernel]
         self._check(self._L.re_timing_begin(self._h, max_launches, (every & 0xFFFF) | (kind << 16)), "re_timing_begin")
 
     def timing_collect(self, cap=65536):
