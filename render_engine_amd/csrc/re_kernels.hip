@@ -1348,15 +1348,16 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     // An EARLIER tick left the tree stale: this frame is replayed by the host.  The flag a workgroup of THIS tick raises when it finds a
     // mover must not stop the workgroups of the same tick that start later (they would skip their entities for good): the frame travels
     // with the flag in one 64-bit word.
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = j;
+    const bool in = j < ndyn;
+    const FrameParams &P = *Pp;
+    // ---- round trip 1: flag word and section slot of the row (coalesced), the frame number, and -- in the same round trip, not in front of it -- the speculation word
+    const uint32_t fl = in ? R.flags[r] : F_DEAD, rc = in ? row_cell[r] : ROW_CELL_NONE;
+    const uint32_t cull_frame = P.frame;
     {
         const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(spec);
         if ((uint32_t)w != 0u && (uint32_t)(w >> 32) != tick_frame) return;     // tick_frame: the frame this tick was issued for (a cancelled frame never wrote its parameters, so Pp->frame would be the stale one's)
     }
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = j;
-    const bool in = j < ndyn;
-    const FrameParams &P = *Pp;
-    // ---- round trip 1: flag word and section slot of the row (coalesced)
-    const uint32_t fl = in ? R.flags[r] : F_DEAD, rc = in ? row_cell[r] : ROW_CELL_NONE;
     // ---- the visibility gate (logic_flow.rs:216-223, 308-358): one gathered word per entity, none with RE_TICK_ALL_DYNAMIC
     const bool unique_cell = rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED);
     const uint32_t stamp = (unique_cell && !tick_all) ? cell_stamp[rc] : 0u;
@@ -1367,7 +1368,7 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     else if (tick_all) run = rc != ROW_CELL_NONE;
     else if (rc == ROW_CELL_NONE) run = false;
     else if (!(rc & ROW_CELL_SHARED)) {
-        const bool vis = (stamp >> 2) == P.frame;
+        const bool vis = (stamp >> 2) == cull_frame;
         // visible loop: local (non-static) entities of active visible sections; always-execute entities
         // only when their section is NOT in visible_sections_map (find_always_execute_entities :803-836)
         run = (!(fl & F_STATIC) && vis) || ((fl & F_ALWAYS_EXEC) && !vis);
@@ -1376,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
         bool anyvis = false, act = false;
         for (int k = 0; k < 8; k++) {
             const int32_t c = sh_cells[s * 8 + k];
-            if (c >= 0 && (cell_stamp[c] >> 2) == P.frame) { anyvis = true; if (!(cell_flags[c] & CF_STATIC_SECTION)) act = true; }
+            if (c >= 0 && (cell_stamp[c] >> 2) == cull_frame) { anyvis = true; if (!(cell_flags[c] & CF_STATIC_SECTION)) act = true; }
         }
         bool inview = false;
         if (act && !(fl & F_STATIC)) {

@@ -23,6 +23,7 @@
 namespace {
 
 constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 512;
+constexpr uint32_t CULL_CHUNK = 8;      // rounds of 256 lights whose positions are in flight together
 
 struct LightParams {
     uint32_t width, height, n_spot, n_point;
@@ -37,14 +38,23 @@ __device__ __forceinline__ float pow64(float x) { x *= x; x *= x; x *= x; x *= x
 
 // one light's contribution to one pixel; A = (pos, radius|unused), B = (diffuse, linear), C = (specular, quadratic), D = ambient rgba
 __device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3 camdir, float4 A, float4 B, float4 C, float4 D, bool radius_cut, float intensity, float3 &acc) {
+    // The shader's divisions and square roots are GPU-precision operations in the reference too (GLSL gives no IEEE guarantee); here they are the
+    // hardware's reciprocal / reciprocal square root (1 ulp) instead of the ~10-instruction IEEE sequences: the kernel is bound by the VALU work of
+    // this function, and the result stays within 1e-6 of the f32 GLSL restatement (tolerance of the path: 1e-4).
     float3 d = sub3(f3(A.x, A.y, A.z), frag);
-    float dist = sqrtf(dot3(d, d));
-    if (radius_cut && dist > A.w) return;                                      // :97-100
-    float3 nd = f3(d.x / dist, d.y / dist, d.z / dist);
-    float att = 1.0f / (1.0f + B.w * dist + C.w * dist * dist);                // calculateAttenuation :132-136
+    const float d2 = dot3(d, d);
+    if (radius_cut) {                                                          // :97-100: dist > radius, decided exactly (the cut is a discontinuity) -- the square root only near the boundary
+        const float r2 = A.w * A.w;
+        if (d2 > r2 * 1.000001f) return;
+        if (d2 > r2 * 0.999999f && sqrtf(d2) > A.w) return;
+    }
+    const float inv = __builtin_amdgcn_rsqf(d2), dist = d2 * inv;
+    float3 nd = f3(d.x * inv, d.y * inv, d.z * inv);
+    float att = __builtin_amdgcn_rcpf(1.0f + B.w * dist + C.w * dist * dist);  // calculateAttenuation :132-136
     float dc = fmaxf(dot3(nrm, nd), 0.0f);                                     // calculateDiffuse :118-122
-    float3 h = norm3v(f3(nd.x + camdir.x, nd.y + camdir.y, nd.z + camdir.z));  // calculateSpecular :124-130
-    float sf = pow64(fmaxf(dot3(nrm, h), 0.0f));
+    float3 hv = f3(nd.x + camdir.x, nd.y + camdir.y, nd.z + camdir.z);         // calculateSpecular :124-130
+    const float invh = __builtin_amdgcn_rsqf(dot3(hv, hv));
+    float sf = pow64(fmaxf(dot3(nrm, hv) * invh, 0.0f));
     acc.x += (od.x * D.x * D.w) * att; acc.x += (B.x * od.x * dc) * att * intensity; acc.x += (C.x * sf) * att;
     acc.y += (od.y * D.y * D.w) * att; acc.y += (B.y * od.y * dc) * att * intensity; acc.y += (C.y * sf) * att;
     acc.z += (od.z * D.z * D.w) * att; acc.z += (B.z * od.z * dc) * att * intensity; acc.z += (C.z * sf) * att;
@@ -56,8 +66,8 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
                                                                    float4 *__restrict__ out) {
     __shared__ float s_red[4][6];
     __shared__ uint32_t s_list[LIST_CAP];
+    __shared__ float4 s_rec[LIST_CAP * 4];                                    // the listed lights' records (A, B, C, D)
     __shared__ uint32_t s_wcnt[4];
-    __shared__ uint32_t s_n;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t tx = blockIdx.x * TILE + (tid & 31u), ty0 = blockIdx.y * TILE + (tid >> 5);
     float3 frag[4], nrm[4], od[4], camdir[4], acc[4]; bool live[4];
@@ -83,41 +93,53 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         for (int a = 0; a < 3; a++)
             for (int d = 32; d >= 1; d >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64)); }
         if (lane == 0) for (int a = 0; a < 3; a++) { s_red[wid][a] = lo[a]; s_red[wid][3 + a] = hi[a]; }
-        if (tid == 0) s_n = 0;
         __syncthreads();
         for (int a = 0; a < 3; a++) { lo[a] = fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a])); hi[a] = fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a])); }
         // ---- radius lights: cull 256 per round into the ordered LDS list, shade whenever the list could overflow ----
+        // Two things keep a tile from waiting on one memory round trip after the other: the positions of CULL_CHUNK rounds of lights are requested
+        // together before their tests, and the 64-byte records of the listed lights are fetched into LDS by the whole workgroup in one go, so the
+        // per-pixel loop reads them as LDS broadcasts (round 1 loaded each light's record with scalar loads inside that loop: one exposed L2
+        // latency per listed light and tile).
         float3 spot_acc[4]; for (int k = 0; k < 4; k++) spot_acc[k] = f3(0.f, 0.f, 0.f);
-        for (uint32_t i0 = 0; i0 < P.n_spot; i0 += LT_THREADS) {
-            uint32_t li = i0 + tid; bool hit = false;
-            if (li < P.n_spot) {
-                float4 A = spot[(size_t)li * 4];
-                float dx = fmaxf(fmaxf(lo[0] - A.x, A.x - hi[0]), 0.0f), dy = fmaxf(fmaxf(lo[1] - A.y, A.y - hi[1]), 0.0f), dz = fmaxf(fmaxf(lo[2] - A.z, A.z - hi[2]), 0.0f);
-                float r = A.w * 1.00001f + 1e-3f;                                  // conservative: the exact per-pixel radius test follows
-                hit = ((dx * dx + dy * dy) + dz * dz) <= r * r;
-            }
-            uint64_t m = __ballot(hit);
-            if (lane == 0) s_wcnt[wid] = (uint32_t)__popcll(m);
+        uint32_t n = 0;                                                        // listed lights (uniform)
+        auto shade_list = [&]() {
+            for (uint32_t idx = tid; idx < n * 4u; idx += LT_THREADS) s_rec[idx] = spot[(size_t)s_list[idx >> 2] * 4 + (idx & 3u)];
             __syncthreads();
-            uint32_t base = s_n, tot = 0;
-            for (uint32_t w = 0; w < 4; w++) { if (w < wid) base += s_wcnt[w]; tot += s_wcnt[w]; }
-            if (hit) s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = li;
-            __syncthreads();
-            uint32_t n = s_n + tot;
-            const bool last = i0 + LT_THREADS >= P.n_spot;
-            if (n + LT_THREADS > LIST_CAP || last) {                            // uniform decision
-                for (uint32_t j = 0; j < n; j++) {
-                    uint32_t l = __builtin_amdgcn_readfirstlane(s_list[j]);
-                    float4 A = spot[(size_t)l * 4], B = spot[(size_t)l * 4 + 1], C = spot[(size_t)l * 4 + 2], D = spot[(size_t)l * 4 + 3];
+            for (uint32_t j = 0; j < n; j++) {
+                const float4 A = s_rec[j * 4u], B = s_rec[j * 4u + 1u], C = s_rec[j * 4u + 2u], D = s_rec[j * 4u + 3u];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (live[k]) shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, true, 1.0f, spot_acc[k]);
-                }
-                n = 0;
+                for (int k = 0; k < 4; k++) if (live[k]) shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, true, 1.0f, spot_acc[k]);
             }
-            __syncthreads();
-            if (tid == 0) s_n = n;
-            __syncthreads();
+            __syncthreads();                                                   // (s_rec / s_list are refilled afterwards)
+            n = 0;
+        };
+        for (uint32_t c0 = 0; c0 < P.n_spot; c0 += LT_THREADS * CULL_CHUNK) {
+            float4 Ac[CULL_CHUNK];
+#pragma unroll
+            for (uint32_t r = 0; r < CULL_CHUNK; r++) { const uint32_t li = c0 + r * LT_THREADS + tid; Ac[r] = li < P.n_spot ? spot[(size_t)li * 4] : make_float4(0.f, 0.f, 0.f, -1.f); }
+#pragma unroll
+            for (uint32_t r = 0; r < CULL_CHUNK; r++) {
+                const uint32_t i0 = c0 + r * LT_THREADS;
+                if (i0 >= P.n_spot) break;                                      // uniform
+                const uint32_t li = i0 + tid; bool hit = false;
+                if (li < P.n_spot) {
+                    const float4 A = Ac[r];
+                    float dx = fmaxf(fmaxf(lo[0] - A.x, A.x - hi[0]), 0.0f), dy = fmaxf(fmaxf(lo[1] - A.y, A.y - hi[1]), 0.0f), dz = fmaxf(fmaxf(lo[2] - A.z, A.z - hi[2]), 0.0f);
+                    float rr = A.w * 1.00001f + 1e-3f;                              // conservative: the exact per-pixel radius test follows
+                    hit = ((dx * dx + dy * dy) + dz * dz) <= rr * rr;
+                }
+                const uint64_t m = __ballot(hit);
+                if (lane == 0) s_wcnt[wid] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t base = n, tot = 0;
+                for (uint32_t w = 0; w < 4; w++) { if (w < wid) base += s_wcnt[w]; tot += s_wcnt[w]; }
+                if (hit) s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = li;
+                __syncthreads();
+                n += tot;
+                if (n + LT_THREADS > LIST_CAP) shade_list();                    // uniform decision: the next round could overflow the list
+            }
         }
+        if (n) shade_list();
         // ---- cone lights (calculatePointLights :72-91): no radius, every pixel evaluates every light ----
         float3 point_acc[4]; for (int k = 0; k < 4; k++) point_acc[k] = f3(0.f, 0.f, 0.f);
         for (uint32_t l = 0; l < P.n_point; l++) {
