@@ -1605,7 +1605,8 @@ static bool device_rebucket_applicable(const re_ctx *c) {
            && !(c->cfg.flags & (RE_CFG_PROBE | RE_CFG_FULL_REBUILD));
 }
 
-static int rebucket_on_device(re_ctx *c, uint32_t M) {
+static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host_list) {
+    host_list->clear();
     if (!M || !device_rebucket_applicable(c)) return 1;
     hipStream_t st = c->stream;
     static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
@@ -1650,8 +1651,8 @@ static int rebucket_on_device(re_ctx *c, uint32_t M) {
     HIPCHK(c, hipMemcpyAsync(c->d_rb_status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     const RbTables T = rb_tables(c); const RbCells C = rb_cells(c);
     // ---- phase 1: ops, sorted by (section key, reference order), replayed per section on the counts
-    hipLaunchKernelGGL(k_rb_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->cfg.outline_length, c->cfg.atomic_length,
-                       c->d_rb_key.p, c->d_rb_ord.p, c->d_rb_row.p, c->d_rb_idx.p, c->d_rb_status.p);
+    hipLaunchKernelGGL(k_rb_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), T, C, c->cfg.outline_length, c->cfg.atomic_length,
+                       c->d_rb_key.p, c->d_rb_ord.p, c->d_rb_row.p, c->d_rb_idx.p, c->d_rb_tmprow.p /* the host path's movers (free until phase 2 sorts arrivals there) */, c->d_rb_status.p);
     HIPCHK(c, re::sort_pairs_u64_u32(c->d_rb_tmp.p, &tmp_bytes, c->d_rb_ord.p, c->d_rb_key2.p, c->d_rb_idx.p, c->d_rb_perm1.p, nops, 0, 34, st));
     hipLaunchKernelGGL(k_rb_gather_keys, dim3((nops + 255) / 256), dim3(256), 0, st, nops, c->d_rb_perm1.p, c->d_rb_key.p, c->d_rb_ord.p);     // (d_rb_ord: free again, now the keys in reference order)
     tmp_bytes = c->d_rb_tmp.n;
@@ -1662,6 +1663,12 @@ static int rebucket_on_device(re_ctx *c, uint32_t M) {
     HIPCHK(c, hipStreamSynchronize(st));
     lap("phase 1");
     if (hs.fallback) return 1;
+    // Movers the host path keeps (hs.n_host): it takes them as a second batch behind this one.  The two batches count total_world_aabb_combining
+    // separately, so the split is only made where the threshold cannot depend on it: this part alone is already above 500 (crowded changed
+    // sections fall back to their grid AABB in both parts).  A small batch with such movers goes to the host path whole (it is cheap there).
+    if (hs.n_host >= M || (hs.n_host && hs.total <= 500u)) return 1;
+    std::vector<uint32_t> keep(hs.n_host);
+    if (hs.n_host) HIPCHK(c, hipMemcpy(keep.data(), c->d_rb_tmprow.p, (size_t)hs.n_host * 4, hipMemcpyDeviceToHost));      // (before phase 2 reuses the array)
     uint32_t need_total = 0;
     for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { if (hs.need_slots[l] > c->free_slots[l].size()) return 1; need_total += hs.need_slots[l]; }
     if ((uint64_t)c->pool_used + hs.need_pool > c->pool_cap) return 1;
@@ -1699,6 +1706,7 @@ static int rebucket_on_device(re_ctx *c, uint32_t M) {
     c->pool_used = h2.pool_used; c->nrows_csr = c->pool_used; c->ovl_count += h2.n_created;
     c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + delta);
     c->n_patches++; c->n_device_rebuckets++;
+    host_list->swap(keep);
     lap("bookkeeping");
     return RE_OK;
 }
@@ -1719,12 +1727,16 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     hipStream_t st = c->stream;
     static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
     auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
-    const uint32_t M = std::min(n_movers, c->list_cap);
     if (n_movers > c->list_cap) return c->fail(RE_E_CAPACITY, "mover list overflow");
-    if (!pre && !ghost_touched) { int drc = rebucket_on_device(c, M); if (drc <= 0) return drc; }      // the common batch stays on the device
+    std::vector<uint32_t> movers; bool second_batch = false;              // second_batch: the device took the movers between unique sections, these are the rest
+    if (!pre && !ghost_touched) {
+        int drc = rebucket_on_device(c, n_movers, &movers);
+        if (drc < 0) return drc;
+        if (drc == 0) { if (movers.empty()) return RE_OK; second_batch = true; }
+    }
     { int src = sync_mirrors(c); if (src != RE_OK) return src; }
-    std::vector<uint32_t> movers(M);
-    HIPCHK(c, hipMemcpy(movers.data(), c->d_movers.p, (size_t)M * 4, hipMemcpyDeviceToHost));
+    const uint32_t M = second_batch ? (uint32_t)movers.size() : std::min(n_movers, c->list_cap);
+    if (!second_batch) { movers.resize(M); HIPCHK(c, hipMemcpy(movers.data(), c->d_movers.p, (size_t)M * 4, hipMemcpyDeviceToHost)); }
     std::sort(movers.begin(), movers.end(), [&](uint32_t a, uint32_t b) {
         bool ta = (a >> 31) != 0, tb = (b >> 31) != 0;                 // translation-only first
         if (ta != tb) return ta;
@@ -1828,7 +1840,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     for (auto it = c->h_uncached.begin(); it != c->h_uncached.end();) { if (!(c->h_flags[*it] & F_STATIC)) { reveal.push_back(*it); it = c->h_uncached.erase(it); } else ++it; }
     for (uint32_t r : reveal) if (!(c->h_flags[r] & F_DEAD)) HIPCHK(c, hipMemcpyAsync(c->d_gclass.p + r, &c->h_gclass[r], 4, hipMemcpyHostToDevice, st));
     // (their pool entries are rewritten by the patch / rebuild below with the row's now visible group class: they moved)
-    carry.too_many = total > 500;
+    carry.too_many = total > 500 || second_batch;                             // (second batch: the device part alone was above the threshold)
     // ---- write the result into the resident table; rebuild everything only when its slack is exhausted
     lap("replay");
     {

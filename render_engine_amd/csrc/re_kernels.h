@@ -239,7 +239,8 @@ struct RbStatus {                                            // one block the ho
     uint32_t need_slots[MAX_LEVELS];                         // sections to create, per level
     uint32_t popped[MAX_LEVELS];                             // phase 2: free slots handed out, per level
     uint32_t pool_used;                                      // in: the pool's fill; out: after the relocations
-    uint32_t n_created, n_freed, pad;
+    uint32_t n_created, n_freed;
+    uint32_t n_host;                                         // movers left to the host path (shared sections, linked sections, static rows): rows in host_list
 };
 struct RbSeg { uint64_t key; int32_t slot; uint32_t op_begin, op_count, nl1, ns; uint8_t exists0, exists1, created, freed; };
 struct RbTables {                                            // key -> slot of the resident table: the immutable sorted keys of the last full build + an overlay of sections created since
@@ -253,8 +254,8 @@ struct RbCells {
 };
 hipError_t sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                               uint32_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream);      // re_sort.hip (rocPRIM radix sort)
-__global__ void k_rb_ops(uint32_t m, const uint32_t *movers, RowArrays R, const uint32_t *row_cell, const uint64_t *cell_key, uint32_t outline, uint32_t atomic,
-                         uint64_t *op_key, uint64_t *op_ord, uint32_t *op_row, uint32_t *op_idx, RbStatus *st);
+__global__ void k_rb_ops(uint32_t m, const uint32_t *movers, RowArrays R, RbTables T, RbCells C, uint32_t outline, uint32_t atomic,
+                         uint64_t *op_key, uint64_t *op_ord, uint32_t *op_row, uint32_t *op_idx, uint32_t *host_list, RbStatus *st);
 __global__ void k_rb_gather_keys(uint32_t n, const uint32_t *perm, const uint64_t *op_key, uint64_t *key_sorted);
 __global__ void k_rb_segments(uint32_t n, const uint32_t *perm, const uint64_t *op_key, const uint32_t *op_row, RbTables T, RbCells C, RbSeg *segs, RbStatus *st);
 __global__ void k_rb_apply(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, RbSeg *segs, RbStatus *st,

@@ -1619,9 +1619,9 @@ __global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t 
 // world/bounding_box_tree_v2.rs:563-942, 1055-1213), for the common batch: movers between unique world sections.  The reference's sequential
 // order (translation-only movers, then kinematic movers, ascending EntityId) only matters per world section (the membership counts that decide
 // total_world_aabb_combining), so the batch becomes two ops per mover -- remove from the old section, add to the new one --, sorted by (section key,
-// order), and one thread replays each section's ops in order.  Anything else (movers into or out of shared sections, sections that shared sections link,
-// static rows, ghosts of the frozen static cache)
-// raises RbStatus::fallback and the host path (re_api.hip: rebucket) takes the whole batch.
+// order), and one thread replays each section's ops in order.  Movers into or out of shared sections, of sections that shared sections link, and static
+// rows are listed for the host path (re_api.hip: rebucket), which takes them as a second batch behind this one; worlds with ghosts of the frozen
+// static cache or hidden rows stay on the host path altogether.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t rb_hash(uint64_t k) { k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29; return (uint32_t)k; }
 __device__ __forceinline__ int32_t rb_find(const RbTables &T, const uint64_t *cell_key, uint64_t key) {
@@ -1644,21 +1644,28 @@ __global__ __launch_bounds__(256) void k_rb_ovl_insert(uint32_t n, const Pair64 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rb_ovl_put(T, pairs[i].val, pairs[i].idx);
 }
-__global__ __launch_bounds__(256) void k_rb_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, const uint32_t *__restrict__ row_cell, const uint64_t *__restrict__ cell_key,
+__global__ __launch_bounds__(256) void k_rb_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbTables T, RbCells C,
                                                 uint32_t outline, uint32_t atomic, uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
-                                                uint32_t *__restrict__ op_idx, RbStatus *st) {
+                                                uint32_t *__restrict__ op_idx, uint32_t *__restrict__ host_list, RbStatus *st) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    const uint32_t w = movers[i], r = w & 0x7FFFFFFFu, fl = R.flags[r], rc = row_cell[r];
+    const uint32_t w = movers[i], r = w & 0x7FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
     Aabb bv = R.aabb[r];
     normalize_aabb(&bv, (float)outline);
     uint64_t keys[8];
     const int nk = assign_sections(bv, atomic, keys);                      // add_entity with add_if_out_bounds = true: the box is clamped
-    const bool bad = nk != 1 || rc == ROW_CELL_NONE || (rc & ROW_CELL_SHARED) || (fl & (F_STATIC | F_DEAD));
-    if (bad) st->fallback = 1u;
+    if (rc == ROW_CELL_NONE || (fl & F_DEAD) || nk < 1) st->fallback = 1u;  // (not a mover the tick can have listed)
+    // movers the host path keeps: into or out of a shared section, static rows, and unique sections that a shared section links (their existence and
+    // static flag depend on that one too).  Their two ops get the key ~0 (sorted behind every section, skipped by k_rb_segments).
+    bool host = nk != 1 || (rc & ROW_CELL_SHARED) || (fl & F_STATIC) || rc == ROW_CELL_NONE;
+    if (!host) {
+        if (C.cell_links[rc]) host = true;
+        else { const int32_t ns = rb_find(T, C.cell_key, keys[0]); if (ns >= 0 && C.cell_links[ns]) host = true; }
+    }
+    if (host) host_list[atomicAdd(&st->n_host, 1u)] = w;
     const uint64_t ord = ((uint64_t)((w >> 31) ? 0u : 1u) << 33) | ((uint64_t)R.id[r] << 1);   // translation-only movers first, then ascending EntityId; remove before add
-    op_key[2 * i] = bad ? 0ull : cell_key[rc]; op_ord[2 * i] = ord;       op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
-    op_key[2 * i + 1] = nk >= 1 ? keys[0] : 0ull; op_ord[2 * i + 1] = ord | 1ull; op_row[2 * i + 1] = r;  op_idx[2 * i + 1] = 2 * i + 1;
+    op_key[2 * i] = host ? ~0ull : C.cell_key[rc]; op_ord[2 * i] = ord;       op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
+    op_key[2 * i + 1] = host ? ~0ull : keys[0];    op_ord[2 * i + 1] = ord | 1ull; op_row[2 * i + 1] = r;  op_idx[2 * i + 1] = 2 * i + 1;
 }
 __global__ __launch_bounds__(256) void k_rb_gather_keys(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ op_key, uint64_t *__restrict__ key_sorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1672,6 +1679,7 @@ __global__ __launch_bounds__(256) void k_rb_segments(uint32_t n, const uint32_t 
     if (t >= n) return;
     const uint64_t key = key_sorted[t];
     if (t > 0 && key_sorted[t - 1] == key) return;                           // segment heads only
+    if (key == ~0ull) return;                                               // the ops of the movers left to the host path
     uint32_t e = t + 1u; while (e < n && key_sorted[e] == key) e++;
     const int32_t slot = rb_find(T, C.cell_key, key);
     if (slot >= 0 && C.cell_links[slot]) st->fallback = 1u;                   // a section some shared section links: its existence and static flag depend on that one too (host path)
