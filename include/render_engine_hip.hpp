@@ -301,6 +301,30 @@ class Pipeline {
     StaticAABB get_copy_static_aabb(EntityId e) { float v[6]; read(e, RE_C_STATIC_AABB, v); return StaticAABB{ { v[0], v[1] }, { v[2], v[3] }, { v[4], v[5] } }; }
     std::vector<EntityId> out_of_bounds_entities() { uint32_t n = 0; std::vector<EntityId> ids(4096); check(re_get_out_of_bounds(ctx_, ids.data(), (uint32_t)ids.size(), &n), "re_get_out_of_bounds"); ids.resize(std::min<uint32_t>(n, 4096)); return ids; }
     uint32_t rejected_at_registration() const { return n_rejected_; }
+    // shadow_flow::find_nearby_lights (flows/shadow_flow.rs:455-513) for the camera of the frame: the light entities of one type near it, ascending ids
+    std::vector<EntityId> find_nearby_lights(const Camera &camera, FindLightType light_type) {
+        upload_if_needed();
+        re_camera cam{}; const TVec3 cp = camera.get_position();
+        cam.position[0] = cp.x; cam.position[1] = cp.y; cam.position[2] = cp.z; cam.far_draw = camera.get_far_draw_distance();      // (the light query reads the position and the far distance only)
+        const uint32_t flag = light_type == FindLightType::Directional ? RE_F_LIGHT_DIRECTIONAL : light_type == FindLightType::Point ? RE_F_LIGHT_POINT : RE_F_LIGHT_SPOT;
+        uint32_t n = 0; check(re_visible_lights(ctx_, &cam, flag, nullptr, 0u, &n), "re_visible_lights");
+        std::vector<EntityId> ids(n);
+        if (n) check(re_visible_lights(ctx_, &cam, flag, ids.data(), n, &n), "re_visible_lights");
+        return ids;
+    }
+    // RenderFlow::register_model_with_render_system with custom_level_of_view (flows/render_flow.rs:1069-1076)
+    void register_custom_level_of_view(ModelId model_id, const std::vector<float> &min_distance, const std::vector<float> &max_distance) {
+        check(re_set_model_lod(ctx_, model_id.model_index, model_id.render_system_index, (uint32_t)std::min(min_distance.size(), max_distance.size()), min_distance.data(), max_distance.data()), "re_set_model_lod");
+    }
+    // ECS::get_indexes_for_components over the movement components (objects/ecs.rs:238-285); components: RE_C_*
+    std::vector<EntityId> get_indexes_for_components(const std::vector<int> &components) {
+        upload_if_needed();
+        uint32_t n = 0; check(re_ecs_query(ctx_, components.data(), (uint32_t)components.size(), nullptr, 0u, &n), "re_ecs_query");
+        std::vector<EntityId> ids(n);
+        if (n) check(re_ecs_query(ctx_, components.data(), (uint32_t)components.size(), ids.data(), n, &n), "re_ecs_query");
+        return ids;
+    }
+    bool has_component(EntityId e, uint32_t ecs_bit) { upload_if_needed(); uint32_t bits = 0; check(re_ecs_bitset(ctx_, e, &bits), "re_ecs_bitset"); return (bits >> ecs_bit) & 1u; }   // ecs_bit: RE_ECS_BIT_*
     re_ctx *context() { upload_if_needed(); return ctx_; }
 
   private:
@@ -352,7 +376,7 @@ inline void EntityTransformationBuilder::apply_choices(StaticAABB original_aabb,
     if (rotation_velocity_) { r.rotvel = *rotation_velocity_; r.flags |= RE_F_HAS_ROTVEL; }
     if (rotation_acceleration_) { r.rotacc = *rotation_acceleration_; r.flags |= RE_F_HAS_ROTACC; }
     if (scale_) { r.scale = scale_->v; r.flags |= RE_F_HAS_SCALE; }
-    (void)light_;                                               // lights are outside this path
+    if (light_) r.flags |= *light_ == FindLightType::Directional ? RE_F_LIGHT_DIRECTIONAL : *light_ == FindLightType::Point ? RE_F_LIGHT_POINT : RE_F_LIGHT_SPOT;   // the entity joins its section's light set (add_entity, bounding_box_tree_v2.rs:601-627)
     pipeline.uploaded_ = false;
 }
 
