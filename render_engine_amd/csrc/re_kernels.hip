@@ -330,16 +330,7 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
             const uint4 *kp = reinterpret_cast<const uint4 *>(keys);
             uint4 kk[NLD];
 #pragma unroll
-            for (uint32_t it = 0; it < NLD; it++) {
-                uint32_t q = (wave_key0 >> 2) + it * 64u + lane;
-#ifdef RE_EXP_NT_KEYS                                                         // experiment: stream the keys past L2 so that the frame's other kernels keep their lines
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kp) + (q < nquads ? q : nquads - 1u));
-                kk[it] = make_uint4(t.x, t.y, t.z, t.w);
-#else
-                kk[it] = kp[q < nquads ? q : nquads - 1u];
-#endif
-            }
+            for (uint32_t it = 0; it < NLD; it++) { uint32_t q = (wave_key0 >> 2) + it * 64u + lane; kk[it] = kp[q < nquads ? q : nquads - 1u]; }
             lv0 = chunk_level[__builtin_amdgcn_readfirstlane(wave)] & (MAX_LEVELS - 1);      // scalar load, in flight together with the keys
             const PBox32 a0 = A.B32.box[lv0];
             const uint32_t hig = a0.hi | KEY32_GUARDS;
@@ -992,46 +983,28 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         f32x4 mat[CHUNK];
 #pragma unroll
         for (uint32_t ps = 0; ps < CHUNK; ps++)
-#ifdef RE_EXP_PACK_NOLOAD
-            mat[ps] = f32x4{ (float)s_row[ps * 64u + li], 0.f, 0.f, 0.f };
-#else
             mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
-#endif
         for (uint32_t i = tid; i < nslots; i += NT) {
             const uint32_t cnt = s_hist[i];
-#ifdef RE_EXP_PACK_NOATOMIC
-            s_tbase[i] = s_gbase[i];
-#else
             s_tbase[i] = s_gbase[i] + (cnt ? atomicAdd(&A.gfill[shard * nslots + i], cnt) : 0u);
-#endif
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) if (tp[q] != 0xFFFFFFFFu) { s_pos[tp[q]] = s_tbase[slot[q]] + rank[q]; s_id[tp[q]] = ids[q]; }
         __syncthreads();
-#ifndef RE_EXP_PACK_NOSTORE
 #pragma unroll
         for (uint32_t q = 0; q < PER; q++) { const uint32_t e = q * NT + tid, pos = s_pos[e]; if (pos < A.out_cap) A.out_ids[pos] = s_id[e]; }   // neighbouring lanes, neighbouring words
-#endif
 #pragma unroll                                                                  // (both chunks unrolled: with a rolled loop the compiler keeps mat[] in scratch memory -- 64 B written and read back per instance)
         for (uint32_t c0 = 0; c0 < PASSES; c0 += CHUNK) {
             if (c0) {
 #pragma unroll
                 for (uint32_t ps = 0; ps < CHUNK; ps++)
-#ifdef RE_EXP_PACK_NOLOAD
-                    mat[ps] = f32x4{ (float)s_row[(c0 + ps) * 64u + li], 0.f, 0.f, 0.f };
-#else
                     mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[(c0 + ps) * 64u + li] * 16)[part];
-#endif
             }
 #pragma unroll
             for (uint32_t ps = 0; ps < CHUNK; ps++) {
                 const uint32_t pp = s_pos[(c0 + ps) * 64u + li];
-#ifndef RE_EXP_PACK_NOSTORE
                 if (pp < A.out_cap) reinterpret_cast<f32x4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
-#else
-                if (pp == 0x12345u && mat[ps].x == 1.5f) A.out_ids[0] = 1u;
-#endif
             }
         }
     }
@@ -1390,9 +1363,6 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
         if (in && nfl != fl) R.flags[r] = nfl;
         return;
     }
-#if defined(RE_EXP_TICK_STAGE) && RE_EXP_TICK_STAGE == 1
-    if (in && nfl != fl) R.flags[r] = nfl; return;                          // experiment: round trip 1 only
-#endif
     // ---- round trip 2: every component a ticking lane may need, requested together (all contiguous by row); whether a lane uses
     // them is decided by its flag word afterwards -- no load below depends on another
     float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f }, v[3] = { 0.f, 0.f, 0.f }, a[3] = { 0.f, 0.f, 0.f };
@@ -1407,9 +1377,6 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     }
     PlaceInputs pin;                                                              // what place_core needs from memory, requested in the same round trip
     place_prefetch(pin, run, r, rc, R, cell_key);
-#if defined(RE_EXP_TICK_STAGE) && RE_EXP_TICK_STAGE == 2
-    if (run && (pos[0] + rot[0] + v[0] + a[0] + wq.x + aq.x + pin.orig.xmin + pin.scl[0] + pin.c3w + (float)pin.key) == 12345.678f) R.flags[r] = nfl; return;   // experiment: both round trips, no arithmetic, no stores
-#endif
     // ---- apply_kinematics (logic_flow.rs:366-448)
     bool pos_set = false, rot_set = false;
     if (run) {
@@ -1444,10 +1411,6 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     if (pos_set) nfl |= F_HAS_MOVED;
     if (rot_set) nfl |= F_HAS_ROTATED;
     const bool changed = pos_set || rot_set;
-#if defined(RE_EXP_TICK_STAGE) && RE_EXP_TICK_STAGE == 3
-    if (changed) { if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; } if (rot_set) reinterpret_cast<float4 *>(R.rot)[r] = make_float4(rot[0], rot[1], rot[2], rot[3]); }
-    if (in && nfl != fl) R.flags[r] = nfl; return;   // experiment: kinematics, no matrix / AABB / section decision
-#endif
     uint32_t status = 0;                                                          // 1: the entity changes section (re-bucket list), 2: it leaves the world
     if (changed) {
         if (pos_set) { R.pos[r * 3 + 0] = pos[0]; R.pos[r * 3 + 1] = pos[1]; R.pos[r * 3 + 2] = pos[2]; }
