@@ -1761,8 +1761,8 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     // ---- replay of remove_entity / add_entity on the affected sections (counts only)
     struct CS { uint32_t nl, ns, links; bool exists; };
     struct SS { uint32_t na, nst; bool exists; };
-    std::map<uint64_t, CS> cs; std::map<SharedIdPub, SS> ss;
-    std::map<uint64_t, uint32_t> link_count;                             // shared sections linking each section, from the previous structure
+    std::unordered_map<uint64_t, CS> cs; cs.reserve((size_t)M * 4u + 64u); std::map<SharedIdPub, SS> ss;
+    std::unordered_map<uint64_t, uint32_t> link_count; link_count.reserve((size_t)os * 4u + 16u);   // shared sections linking each section, from the previous structure
     std::map<SharedIdPub, uint32_t> shid_index;                           // shared section id -> its index in the previous table (a linear search per lookup cost 6 ms per tick with ~1,000 shared sections)
     for (uint32_t s = 0; s < os; s++) shid_index.emplace(c->h_shids[s], s);
     for (uint32_t s = 0; s < os; s++) for (uint32_t k = 0; k < c->h_shids[s].nk; k++) link_count[c->h_shids[s].keys[k]]++;
