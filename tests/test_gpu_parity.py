@@ -807,3 +807,37 @@ def test_rebucket_on_the_device(R, straddlers):
     check_entities(R, p, w, ents[::7])
     check_frame(R, p, w, cams[0], False)
     p.close(); w.close()
+
+
+@pytest.mark.parametrize("straddlers", [False, True])
+def test_async_frames_with_the_device_rebucket(R, straddlers):
+    """frames enqueued without waiting while every tick moves entities between world sections: each such tick cancels the frames behind it, the
+    library patches the tree (on the device: the movers between unique sections) and replays them -- the end state equals the frame-by-frame reference"""
+    ents = hopping_world(R, dims=(12, 12, 12), first=122)
+    if straddlers:
+        mv = np.nonzero((ents["flags"] & R.F_HAS_VEL) != 0)[0][::19]
+        for k, i in enumerate(mv):
+            h = np.float32(22.0 + 5.0 * (k % 3))
+            ents["original"][i] = (-h, h, -h, h, -h, h)
+    p, w = build_pair(R, ents)
+    cams = [R.Camera((8192 + 12 * i, 8192 - 6 * i, 8192 + 2400), (0.01 * i, 0, -1), 6000.0) for i in range(6)]
+    for cam in cams[:-1]:
+        oc = oracle_camera(cam); w.cull(oc); w.render(oc); w.tick(oc, 1.0)
+    for cam in cams[:-1]:
+        p.cull_and_pack(cam, asynchronous=True, copy=False)
+        p.tick(1.0, asynchronous=True)
+    p.wait()
+    st = p.stats()
+    assert st["n_device_rebuckets"] >= 3, st
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::5])
+    check_frame(R, p, w, cams[-1], True)
+    for i, cam in enumerate(cams):                                   # mixed styles
+        oc = oracle_camera(cam); w.cull(oc); w.render(oc); w.tick(oc, 1.0)
+        p.cull_and_pack(cam, asynchronous=(i % 3 != 0), copy=False)
+        p.tick(1.0, asynchronous=(i % 2 == 0))
+    p.wait()
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::5])
+    check_frame(R, p, w, cams[0], False)
+    p.close(); w.close()
