@@ -64,6 +64,8 @@ extern "C" {
                                        * section (world/bounding_box_tree_v2.rs:157-228, add_entity :601-627, 690-730); see re_visible_lights */
 #define RE_F_LIGHT_POINT  0x4000u
 #define RE_F_LIGHT_SPOT   0x8000u
+#define RE_F_PHANTOM     0x10000u /* halo replica of an entity another GPU's shard owns (re_section_keys): it takes part in the tree -- section membership,
+                                   * shared-section links, static-section flags, tight AABBs, the "other" side of collision pairs -- and is never drawn, ticked or listed as a light here */
 #define RE_F_CAN_COLLIDE 0x1000u /* CanCauseCollisions (EntityTransformationBuilder.can_cause_collision, exports/entity_transformer.rs:66-69) */
 
 typedef struct re_ctx re_ctx;
@@ -327,6 +329,13 @@ int re_read_component(re_ctx *ctx, uint32_t entity_id, int component, void *dst)
 #define RE_ECS_BIT_ORIGINAL_AABB        16
 #define RE_ECS_BIT_ALWAYS_EXECUTE_LOGIC 20
 int re_ecs_bitset(re_ctx *ctx, uint32_t entity_id, uint32_t *bits);   /* 0 for an entity that was removed (remove_entity clears every bit, ecs.rs:557-600) */
+/* Sharding helper: the world sections entity i is registered in -- n_keys[i] = 1 (its unique section) or 2..8 (the sections its shared
+ * section links), 0 = rejected as out of bounds; keys[i * 8 ..].  A world is spread over several GPUs by contiguous ranges of an entity's SMALLEST key:
+ * every unique section's entities, and every shared section together with the section that caches its static entities, then live on one shard.  What a
+ * shard's static-section flags still depend on -- the entities of the sections its shared sections link, and the other shared sections linking those --
+ * it uploads as halo replicas (RE_F_PHANTOM).  Host arithmetic (no device, no context); the functions re_upload_entities runs on the GPU. */
+int re_section_keys(const re_config *cfg, const re_entities *entities, uint64_t *keys /* [n * 8] */, uint8_t *n_keys /* [n] */);
+
 /* The lights of one type that RenderFlow::render hands to the deferred pass (upload_*_lights, render_system/render_system.rs:676-800) and to the shadow
  * flow: find_nearby_world_sections_maps (flows/render_flow.rs:249-254, flows/shadow_flow.rs:494-513: the whole-world visibility query with an AABB culler
  * of radius cam->far_draw around cam->position) followed by find_nearby_lights (shadow_flow.rs:455-487: the light sets of those unique world sections and

@@ -50,6 +50,7 @@ extern "C" {
     pub fn re_ecs_bitset(ctx: *mut ReCtx, entity_id: u32, bits: *mut u32) -> c_int;
     pub fn re_ecs_query(ctx: *mut ReCtx, components: *const c_int, n_components: u32, ids: *mut u32, capacity: u32, n: *mut u32) -> c_int;
     pub fn re_visible_lights(ctx: *mut ReCtx, cam: *const ReCamera, light_type: u32, ids: *mut u32, capacity: u32, n: *mut u32) -> c_int;
+    pub fn re_section_keys(cfg: *const ReConfig, ents: *const ReEntities, keys: *mut u64 /* [n * 8] */, n_keys: *mut u8 /* [n] */) -> c_int;   // host arithmetic: the sharding key of a multi-GPU loader
     pub fn re_comm_unique_id(id: *mut u8) -> c_int;                                                            // RE_COMM_ID_BYTES = 128
     pub fn re_comm_init(ctx: *mut ReCtx, id: *const u8, rank: c_int, n_ranks: c_int, slab_instances: u32) -> c_int;
     pub fn re_comm_adopt(ctx: *mut ReCtx, nccl_comm: *mut c_void, rank: c_int, n_ranks: c_int, slab_instances: u32) -> c_int;
@@ -82,3 +83,4 @@ pub const RE_GATHER_ASYNC: u32 = 0x1; pub const RE_COMM_ID_BYTES: usize = 128;
 pub const RE_FC_CAMERA_VIEW_CHANGE: u32 = 0; pub const RE_FC_CAMERA_STATIONARY: u32 = 1; pub const RE_FC_DELTA_TIME: u32 = 2; pub const RE_FC_DRAW_DISTANCES_CHANGE: u32 = 3;
 pub const RE_FC_WINDOW_DIMENSIONS_CHANGE: u32 = 4; pub const RE_FC_ENTITY_CHANGE: u32 = 5; pub const RE_FC_END_FRAME_CHANGE: u32 = 6;
 pub const RE_F_LIGHT_DIRECTIONAL: u32 = 0x2000; pub const RE_F_LIGHT_POINT: u32 = 0x4000; pub const RE_F_LIGHT_SPOT: u32 = 0x8000;
+pub const RE_F_PHANTOM: u32 = 0x10000;

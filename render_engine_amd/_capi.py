@@ -10,6 +10,7 @@ F_STATIC, F_HAS_VEL, F_HAS_ACC, F_HAS_ROT = 0x001, 0x002, 0x004, 0x008
 F_HAS_ROTVEL, F_HAS_ROTACC, F_HAS_SCALE, F_ALWAYS_EXEC = 0x010, 0x020, 0x040, 0x080
 F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
 F_CAN_COLLIDE = 0x1000
+F_PHANTOM = 0x10000            # halo replica of an entity another shard owns: in the tree, never drawn or ticked
 F_LIGHT_DIRECTIONAL, F_LIGHT_POINT, F_LIGHT_SPOT = 0x2000, 0x4000, 0x8000      # FindLightType of the entity (light sets of its world section)
 CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK, CULL_FORCE_STREAM, CULL_DEFER_PACK, CULL_TWO_LANES = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
 TICK_ALL_DYNAMIC, TICK_ASYNC = 0x1, 0x2
@@ -103,7 +104,7 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_set_model_lod", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_section_keys", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
@@ -166,6 +167,7 @@ def load():
     L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]
     L.re_read_component.restype = C.c_int; L.re_read_component.argtypes = [vp, C.c_uint32, C.c_int, vp]
     L.re_ecs_bitset.restype = C.c_int; L.re_ecs_bitset.argtypes = [vp, C.c_uint32, _u32p]
+    L.re_section_keys.restype = C.c_int; L.re_section_keys.argtypes = [C.POINTER(Config), C.POINTER(Entities), vp, vp]
     L.re_visible_lights.restype = C.c_int; L.re_visible_lights.argtypes = [vp, C.POINTER(CameraC), C.c_uint32, vp, C.c_uint32, _u32p]
     L.re_ecs_query.restype = C.c_int; L.re_ecs_query.argtypes = [vp, C.POINTER(C.c_int), C.c_uint32, vp, C.c_uint32, _u32p]
     L.re_get_out_of_bounds.restype = C.c_int; L.re_get_out_of_bounds.argtypes = [vp, vp, C.c_uint32, _u32p]

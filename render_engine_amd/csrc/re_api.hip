@@ -189,7 +189,7 @@ struct re_ctx {
     DevBuf<uint64_t> d_rb_key, d_rb_ord, d_rb_key2, d_rb_ksorted; DevBuf<uint32_t> d_rb_row, d_rb_idx, d_rb_perm1, d_rb_perm, d_rb_tmprow, d_rb_refold, d_rb_free, d_rb_freeoff;
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
-    uint32_t n_device_rebuckets = 0;
+    uint32_t n_device_rebuckets = 0, n_phantom = 0;
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -284,7 +284,7 @@ static RowArrays row_arrays(re_ctx *c) {
 // group class a row-pool entry carries for row r: hidden while the row is not to be drawn (removed, or made static after the cache froze)
 static inline uint32_t effective_gclass(const re_ctx *c, uint32_t r) {
     if (r >= c->n) return c->h_ghost_gc[r - c->n];                            // a ghost instance keeps the group class it was cloned with
-    return ((c->h_flags[r] & F_DEAD) || c->h_uncached.count(r)) ? 0xFFFFFFFFu : c->h_gclass[r];
+    return ((c->h_flags[r] & (F_DEAD | F_PHANTOM)) || c->h_uncached.count(r)) ? 0xFFFFFFFFu : c->h_gclass[r];      // (a halo replica is never drawn here)
 }
 // pool positions of row r (one: its section's segment or its shared section's) get the row's current effective group class
 static void collect_row_gc(const re_ctx *c, uint32_t r, std::vector<Pair32> &out) {
@@ -606,11 +606,12 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     // dynamic entity j, and the tick reads and writes contiguous streams (k_tick) instead of gathering 12..64-byte pieces per entity.
     std::vector<uint32_t> perm; bool permuted = false;
     {
+        auto dynamic = [&](uint32_t i) { return (E->flags[i] & (F_HAS_VEL | F_HAS_ROTVEL)) && !(E->flags[i] & F_PHANTOM); };   // (a halo replica never ticks here)
         uint32_t nd = 0; bool prefix = true;
-        for (uint32_t i = 0; i < n; i++) if (E->flags[i] & (F_HAS_VEL | F_HAS_ROTVEL)) { if (i != nd) prefix = false; nd++; }
+        for (uint32_t i = 0; i < n; i++) if (dynamic(i)) { if (i != nd) prefix = false; nd++; }
         if (nd && !prefix) {
             perm.resize(n); uint32_t a = 0, b = nd;
-            for (uint32_t i = 0; i < n; i++) { if (E->flags[i] & (F_HAS_VEL | F_HAS_ROTVEL)) perm[a++] = i; else perm[b++] = i; }
+            for (uint32_t i = 0; i < n; i++) { if (dynamic(i)) perm[a++] = i; else perm[b++] = i; }
             permuted = true;
         }
     }
@@ -621,6 +622,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     for (uint32_t r = 0; r < n; r++) {
         const size_t i = src(r);
         uint32_t fl = E->flags[i] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
+        if (fl & F_PHANTOM) fl &= ~(F_HAS_VEL | F_HAS_ACC | F_HAS_ROTVEL | F_HAS_ROTACC | F_ALWAYS_EXEC | F_USER | F_LIGHT_ANY);   // RE_F_PHANTOM: in the tree, otherwise inert (its owner shard ticks, draws and lists it)
         flags[r] = fl;
         if ((fl & F_HAS_ROT) && !E->rotation) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_ROT but rotation == NULL", r);
         if ((fl & F_HAS_SCALE) && !E->scale) return c->fail(RE_E_ARG, "entity %u has RE_F_HAS_SCALE but scale == NULL", r);
@@ -662,6 +664,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->h_flags = flags; c->h_dyn_row = dyn_row; c->has_rotvel = false;
     c->h_light_rows.clear(); for (uint32_t r = 0; r < n; r++) if (flags[r] & F_LIGHT_ANY) c->h_light_rows.push_back(r);
     c->light_rows_dirty = true;
+    c->n_phantom = 0; for (uint32_t r = 0; r < n; r++) if (flags[r] & F_PHANTOM) c->n_phantom++;      // halo replicas: listed by the scan, hidden from the pack (twice each in duplicates mode)
     c->user_row = ROW_CELL_NONE; for (uint32_t r = 0; r < n; r++) if (flags[r] & F_USER) { c->user_row = r; break; }
     c->d_row_moved.release(nullptr); c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->col_moved_cap = 0;
     for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
@@ -1025,7 +1028,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
             if (!ok) { c->n_sync_fallbacks++; HIPCHK(c, hipStreamSynchronize(c->stream)); std::atomic_thread_fence(std::memory_order_acquire); ok = table_ok(); }
             if (!ok) return c->fail(RE_E_STATE, "group table inconsistent with its seal (frame %u, %u groups, %u instances)", c->frame, c->h_res->n_groups, c->h_res->total);
         }
-        if (c->h_res->n_items > c->h_res->total + c->n_dead + (uint32_t)c->h_uncached.size()) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
+        if (c->h_res->n_items > c->h_res->total + c->n_dead + (uint32_t)c->h_uncached.size() + 2u * c->n_phantom) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
     }
     if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
     fill_visible(c, out);
@@ -2632,6 +2635,35 @@ extern "C" int re_ecs_bitset(re_ctx *c, uint32_t entity_id, uint32_t *bits) {
     *bits = ecs_bits_of_flags(fl);
     return RE_OK;
 }
+// The world sections an entity is registered in -- one key (its unique section) or the 2..8 keys its shared section links --, for a loader that spreads
+// a world over several GPUs.  The owner of an entity is the shard whose key range holds the SMALLEST of its keys: all
+// entities of a unique section, and a shared section together with the unique section that caches its static entities, then live on one shard (a
+// section's tight AABB -- distance test, LOD -- folds all of its entities).  The other keys tell which entities a shard needs as halo replicas
+// (RE_F_PHANTOM).  Host arithmetic with the functions the upload kernel runs (re_math.h); no device needed.
+extern "C" int re_section_keys(const re_config *cfg, const re_entities *E, uint64_t *keys, uint8_t *n_keys) {
+    if (!cfg || !E || (E->n && (!keys || !n_keys || !E->flags || !E->original_aabb || !E->position))) return RE_E_ARG;
+    if (!cfg->outline_length || !cfg->atomic_length) return RE_E_ARG;
+    for (uint32_t i = 0; i < E->n; i++) {
+        const uint32_t fl = E->flags[i];
+        const float *p = E->position + (size_t)i * 3;
+        float axis[3] = { 1.f, 0.f, 0.f }, angle = 0.f, scl[3] = { 1.f, 1.f, 1.f }, m[16];
+        if ((fl & F_HAS_ROT) && E->rotation) { const float *a = E->rotation + (size_t)i * 4; const float nn = norm3(a[0], a[1], a[2]); axis[0] = a[0] / nn; axis[1] = a[1] / nn; axis[2] = a[2] / nn; angle = a[3]; }   // Rotation::new normalises the axis (as re_upload_entities does)
+        if ((fl & F_HAS_SCALE) && E->scale) { const float *q = E->scale + (size_t)i * 3; scl[0] = q[0]; scl[1] = q[1]; scl[2] = q[2]; }
+        Aabb orig; memcpy(&orig, E->original_aabb + (size_t)i * 6, sizeof orig);
+        Aabb a;
+        if (fl & F_USER) { a = orig; a.xmin += p[0]; a.xmax += p[0]; a.ymin += p[1]; a.ymax += p[1]; a.zmin += p[2]; a.zmax += p[2]; }
+        else { trs_matrix(p, (fl & F_HAS_ROT) != 0, axis, angle, (fl & F_HAS_SCALE) != 0, scl, m); a = apply_transformation(orig, m); }
+        Aabb bv = a;
+        const bool oob = normalize_aabb(&bv, (float)cfg->outline_length);
+        uint64_t k8[8];
+        int nk = oob ? 0 : assign_sections(bv, cfg->atomic_length, k8);
+        if (nk < 0) nk = 0;
+        n_keys[i] = (uint8_t)nk;
+        for (int k = 0; k < 8; k++) keys[(size_t)i * 8 + k] = k < nk ? k8[k] : 0ull;
+    }
+    return RE_OK;
+}
+
 // The lights of one type RenderFlow::render finds near the camera (flows/render_flow.rs:249-254 -> flows/shadow_flow.rs:455-513): k_visible_lights over the
 // entities uploaded with RE_F_LIGHT_*.  Stands alone (own visibility test with the AABB culler of radius far_draw); ids in ascending order.
 extern "C" int re_visible_lights(re_ctx *c, const re_camera *cam, uint32_t light_type, uint32_t *ids, uint32_t capacity, uint32_t *n_out) {

@@ -8,6 +8,7 @@
 namespace re {
 
 // entity flag bits (== RE_F_* of include/re_hip.h) + internal
+constexpr uint32_t F_PHANTOM = 0x10000;
 constexpr uint32_t F_LIGHT_DIRECTIONAL = 0x2000, F_LIGHT_POINT = 0x4000, F_LIGHT_SPOT = 0x8000, F_LIGHT_ANY = 0xE000;
 constexpr uint32_t F_STATIC = 0x001, F_HAS_VEL = 0x002, F_HAS_ACC = 0x004, F_HAS_ROT = 0x008, F_HAS_ROTVEL = 0x010,
                    F_HAS_ROTACC = 0x020, F_HAS_SCALE = 0x040, F_ALWAYS_EXEC = 0x080, F_OOB_LOGIC = 0x100,

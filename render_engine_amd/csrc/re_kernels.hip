@@ -1567,7 +1567,7 @@ __global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t 
                                                      uint32_t *__restrict__ out_ids, uint32_t cap, uint32_t *count) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t fl = r < n ? flags[r] : F_DEAD;
-    const bool hit = !(fl & F_DEAD) && (fl & need_mask) == need_mask;
+    const bool hit = !(fl & (F_DEAD | F_PHANTOM)) && (fl & need_mask) == need_mask;      // (halo replicas belong to another shard's ECS)
     const uint64_t m = __ballot(hit);
     if (!m) return;
     uint32_t base = 0;

@@ -110,6 +110,74 @@ class Camera:
         return c
 
 
+def section_keys(ents, tree_outline_length=16384, tree_atomic_length=64):
+    """re_section_keys: (keys [n, 8] uint64, n_keys [n] uint8) -- the world sections every entity (ENTITY_DT array) is registered in: one key (its
+    unique section) or the 2..8 sections its shared section links; n_keys 0 = rejected as out of bounds.  Host arithmetic; no GPU needed."""
+    L = _capi.load()
+    e = np.ascontiguousarray(ents, ENTITY_DT); n = len(e)
+    keep = [np.ascontiguousarray(e["flags"]), np.ascontiguousarray(e["original"], np.float32), np.ascontiguousarray(e["pos"], np.float32),
+            np.ascontiguousarray(np.concatenate([e["rot_axis"], e["rot_angle"][:, None]], axis=1), np.float32) if n else np.zeros((0, 4), np.float32),
+            np.ascontiguousarray(e["scale"], np.float32)]
+    E = _capi.Entities(); E.n = n
+    E.flags = keep[0].ctypes.data_as(C.POINTER(C.c_uint32)); E.original_aabb = keep[1].ctypes.data_as(C.POINTER(C.c_float)); E.position = keep[2].ctypes.data_as(C.POINTER(C.c_float))
+    E.rotation = keep[3].ctypes.data_as(C.POINTER(C.c_float)); E.scale = keep[4].ctypes.data_as(C.POINTER(C.c_float))
+    cfg = _capi.Config(0, tree_outline_length, tree_atomic_length, 0, 0)
+    keys = np.zeros((max(n, 1), 8), np.uint64); nk = np.zeros(max(n, 1), np.uint8)
+    rc = L.re_section_keys(C.byref(cfg), C.byref(E), keys.ctypes.data, nk.ctypes.data)
+    if rc != _capi.RE_OK:
+        raise RenderEngineError(f"re_section_keys failed ({rc})")
+    return keys[:n], nk[:n]
+
+
+def first_section_keys(ents, tree_outline_length=16384, tree_atomic_length=64):
+    """the smallest section key of every entity (0 = rejected): the key that decides the owning shard"""
+    keys, nk = section_keys(ents, tree_outline_length, tree_atomic_length)
+    k = np.where(np.arange(8)[None, :] < nk[:, None], keys, np.uint64(0xFFFFFFFFFFFFFFFF)).min(axis=1) if len(keys) else np.zeros(0, np.uint64)
+    return np.where(nk > 0, k, np.uint64(0)).astype(np.uint64)
+
+
+def shard_by_first_section(ents, n_shards, tree_outline_length=16384, tree_atomic_length=64, halo=False):
+    """Shards of a world for `n_shards` GPUs: contiguous ranges of the entities' smallest section key with near-equal entity counts; entities that
+    share a first section stay together (a section's tight AABB folds all of its entities: SURVEY 8e).  Returns one index array per shard -- or,
+    with halo=True, (own, halo) pairs: `halo` are the entities another shard owns that this shard uploads as replicas with F_PHANTOM, because the
+    static-section flag of a unique section depends on all of its entities and on every shared section linking it: for each shared section the
+    shard owns, the members of the unique sections it links and the members of the other shared sections linking those."""
+    keys, nk = section_keys(ents, tree_outline_length, tree_atomic_length)
+    first = np.where(np.arange(8)[None, :] < nk[:, None], keys, np.uint64(0xFFFFFFFFFFFFFFFF)).min(axis=1)
+    first = np.where(nk > 0, first, np.uint64(0))
+    order = np.argsort(first, kind="stable")
+    ks = first[order]; n = len(ks)
+    cuts = [0]
+    for r in range(1, n_shards):
+        c = max((n * r) // n_shards, cuts[-1])
+        while 0 < c < n and ks[c] == ks[c - 1]:
+            c += 1                                              # never split the entities of one section
+        cuts.append(min(c, n))
+    cuts.append(n)
+    own = [np.sort(order[cuts[r]:cuts[r + 1]]) for r in range(n_shards)]
+    if not halo:
+        return own
+    owner = np.zeros(n, np.int64)
+    for r, idx in enumerate(own):
+        owner[idx] = r
+    unique_members, linking = {}, {}                            # section key -> entities registered in it alone / shared-section members linking it
+    for i in range(n):
+        if nk[i] == 1:
+            unique_members.setdefault(int(keys[i, 0]), []).append(i)
+        elif nk[i] > 1:
+            for k in keys[i, :nk[i]]:
+                linking.setdefault(int(k), []).append(i)
+    out = []
+    for r, idx in enumerate(own):
+        linked = {int(k) for i in idx if nk[i] > 1 for k in keys[i, :nk[i]]}          # unique sections the shard's shared sections link
+        h = set()
+        for k in linked:
+            h.update(i for i in unique_members.get(k, ()) if owner[i] != r)
+            h.update(i for i in linking.get(k, ()) if owner[i] != r)
+        out.append((idx, np.array(sorted(h), np.int64)))
+    return out
+
+
 class Pipeline:
     """One GPU's share of the world: BoundingBoxTree + ECS columns resident in HBM."""
 
