@@ -8,6 +8,7 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import render_engine_amd as R
 from render_engine_amd import parallel, synthetic
 
@@ -33,9 +34,15 @@ def main():
         p.tick(0.016, asynchronous=True)
     p.wait(); g.finish()
     ids, mats, counts = g.gathered(b)
+    import oracle as ro
+    from helpers import to_oracle, oracle_camera, assert_render_equal
+    w = ro.World(16384, atomic); w.register(to_oracle(synthetic.box_world(dims, first_cell=first, atomic=atomic, spinner_every=9)))
     for cam in cams:
         ref = full.cull_and_pack(cam)
-        full.tick(0.016)
+        oc = oracle_camera(cam); w.cull(oc); o = w.render(oc)
+        assert_render_equal(ref, o)                     # the single pipeline the gathered set is compared with equals the CPU oracle, frame by frame
+        full.tick(0.016); w.tick(oc, 0.016)
+    w.close()
     assert sum(counts) == ref["total"], (counts, ref["total"])
     got = np.sort(ids.cpu().numpy().astype(np.uint32)); want = np.sort(ref["ids"])
     np.testing.assert_array_equal(got, want)
