@@ -745,6 +745,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     // frame buffers
     c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
     c->item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
+    if (n <= 65536u) c->item_cap = CURSOR_SHARDS * (2u * (n + std::max(2048u, n / 8u)) + 64u);   // a small world's sections sit in a few waves, i.e. in a few cursor shards: every segment holds the whole world incl. its ghost instances (twice: duplicates mode)
     c->list_cap = std::max(std::max(c->ndyn, std::min(n, 65536u)), 1u);   // movers of one tick (dynamic rows) or of one change batch (any row)
     // two instance lists, alternating by frame: a deferred pack (RE_CULL_DEFER_PACK) reads the list of frame f while the scan of frame f + 1 fills the other
     HIPCHK(c, c->d_item_row.alloc((size_t)c->item_cap * 2, acct)); HIPCHK(c, c->d_item_slot.alloc((size_t)c->item_cap * 2, acct));

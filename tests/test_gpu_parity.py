@@ -841,3 +841,21 @@ def test_async_frames_with_the_device_rebucket(R, straddlers):
     check_entities(R, p, w, ents[::5])
     check_frame(R, p, w, cams[0], False)
     p.close(); w.close()
+
+
+@pytest.mark.parametrize("dims,first,atomic,every", [((9, 17, 6), 200, 32, 3), ((20, 5, 11), 118, 64, 2), ((8, 8, 8), 60, 128, 2)])
+def test_device_rebucket_soak(R, dims, first, atomic, every):
+    """more shapes for the device-side re-bucket: other section lengths, flat and slab-shaped worlds; the table is compared with the oracle after every tick"""
+    ents = R.synthetic.hopping_lattice(dims, first, atomic, every)
+    p, w = build_pair(R, ents, atomic=atomic)
+    c = (first + max(dims) / 2.0) * atomic
+    for f in range(6):
+        cam = R.Camera((c + 5.0 * f, c, c + 30.0 * atomic), (0.0, 0.0, -1.0), 90.0 * atomic)
+        check_frame(R, p, w, cam, f % 2 == 0)
+        n_o, oob_o = w.tick(oracle_camera(cam), 1.0)
+        t = p.tick(1.0)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o), (f, t, n_o, len(oob_o))
+        check_sections(p, w)
+    assert p.stats()["n_device_rebuckets"] >= 1, p.stats()
+    check_entities(R, p, w, ents[::3])
+    p.close(); w.close()
