@@ -843,10 +843,11 @@ def test_async_frames_with_the_device_rebucket(R, straddlers):
     p.close(); w.close()
 
 
-@pytest.mark.parametrize("dims,first,atomic,every", [((9, 17, 6), 200, 32, 3), ((20, 5, 11), 118, 64, 2), ((8, 8, 8), 60, 128, 2)])
+@pytest.mark.parametrize("dims,first,atomic,every", [((9, 17, 6), 200, 32, 3), ((20, 5, 11), 118, 64, 2), ((8, 8, 8), 60, 128, 2), ((6, 6, 6), 249, 64, 2)])
 def test_device_rebucket_soak(R, dims, first, atomic, every):
     """more shapes for the device-side re-bucket: other section lengths, flat and slab-shaped worlds; the table is compared with the oracle after every tick"""
-    ents = R.synthetic.hopping_lattice(dims, first, atomic, every)
+    ents = R.synthetic.hopping_lattice(dims, first, atomic, every)         # (the last shape sits at the edge of the world: movers hop out of bounds)
+    ents["flags"][::5] |= np.uint32(R.F_LIGHT_POINT)
     p, w = build_pair(R, ents, atomic=atomic)
     c = (first + max(dims) / 2.0) * atomic
     for f in range(6):
@@ -855,7 +856,26 @@ def test_device_rebucket_soak(R, dims, first, atomic, every):
         n_o, oob_o = w.tick(oracle_camera(cam), 1.0)
         t = p.tick(1.0)
         assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o), (f, t, n_o, len(oob_o))
+        assert sorted(p.out_of_bounds()) == sorted(int(i) for i in oob_o)
         check_sections(p, w)
+        np.testing.assert_array_equal(p.visible_lights(cam, R.F_LIGHT_POINT), w.visible_lights(oracle_camera(cam), ro.F_LIGHT_POINT))     # lights follow the sections the device moved them to
     assert p.stats()["n_device_rebuckets"] >= 1, p.stats()
     check_entities(R, p, w, ents[::3])
+    p.close(); w.close()
+
+
+@pytest.mark.parametrize("n,atomic", [(1, 64), (2, 64), (3, 32), (7, 128), (63, 64), (64, 64), (65, 32), (100, 256), (512, 64), (513, 128), (1000, 16)])
+def test_tiny_and_odd_worlds(R, n, atomic):
+    """worlds of a handful of entities, section lengths from 16 to 256: every frame path (small pack, large pack forced, duplicates), ticks, the table"""
+    ents = R.synthetic.mixed_world(n, seed=100 + n, spread=min(600.0, 40.0 + 6.0 * n), atomic=atomic)
+    p, w = build_pair(R, ents, atomic=atomic)
+    check_sections(p, w)
+    cams = [R.Camera((8192 + 30 * i, 8192 - 20 * i, 8192 + 500 - 60 * i), (0.1 * i - 0.1, 0.05 * i, -1), 700.0 + 200.0 * i) for i in range(4)]
+    for f, cam in enumerate(cams):
+        check_frame(R, p, w, cam, f % 2 == 1, force_large_pack=(f == 2))
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.05)
+        t = p.tick(0.05)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o), (f, t, n_o)
+        check_sections(p, w)
+    check_entities(R, p, w, ents)
     p.close(); w.close()
