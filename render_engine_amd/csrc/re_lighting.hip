@@ -38,6 +38,7 @@ __device__ __forceinline__ float pow64(float x) { x *= x; x *= x; x *= x; x *= x
 
 // one light's contribution to one pixel; A = (pos, radius|unused), B = (diffuse, linear), C = (specular, quadratic), D = ambient rgba
 __device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3 camdir, float4 A, float4 B, float4 C, float4 D, bool radius_cut, float intensity, float3 &acc) {
+#pragma clang fp contract(fast)          // this file's arithmetic is tolerance-bound (1e-4), not bit-exact like the cull path: multiply-adds may fuse here (the library is built with -ffp-contract=off)
     // The shader's divisions and square roots are GPU-precision operations in the reference too (GLSL gives no IEEE guarantee); here they are the
     // hardware's reciprocal / reciprocal square root (1 ulp) instead of the ~10-instruction IEEE sequences: the kernel is bound by the VALU work of
     // this function, and the result stays within 1e-6 of the f32 GLSL restatement (tolerance of the path: 1e-4).
