@@ -961,7 +961,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         const uint32_t grid = nshards * std::min(2048u, std::max(4u, (per_shard + PACK_LARGE_TILE - 1u) / PACK_LARGE_TILE));
         hipEvent_t ta = nullptr, tb = nullptr;
         if (c->k1_timing && c->k1_kind == RE_TIME_PACK_LARGE) take_timing_events(c, &ta, &tb);
-        hipExtLaunchKernelGGL(k_pack_large, dim3(grid), dim3(256), 0, st, ta, tb, 0, A);
+        hipExtLaunchKernelGGL(k_pack_large, dim3(grid), dim3(PACK_LARGE_THREADS), 0, st, ta, tb, 0, A);
         HIPCHK(c, hipGetLastError());
         c->last_pack.kind = 2; c->last_pack.L = A; c->last_pack.grid = grid; c->last_pack.par = par; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next;
         c->gc_dirty[par] = true; c->gc_dirty[par ^ 1u] = false;                // this frame's arrays stay as they are; the other parity's were cleared by the launch
@@ -2433,7 +2433,7 @@ static int repack_last_frame(re_ctx *c, uint32_t *ids, float *mats, uint32_t cap
     } else if (P.kind == 2) {
         PackLargeArgs A = P.L; A.out_ids = ids; A.out_mats = mats; A.out_cap = cap; A.out_count = nullptr; A.zero_a = nullptr; A.zero_b = nullptr; A.zero_words = 0;
         HIPCHK(c, hipMemsetAsync(A.gfill, 0, (size_t)CURSOR_SHARDS * std::max(c->nslots, 1u) * 4, st));      // the fills of the first run
-        hipLaunchKernelGGL(k_pack_large, dim3(P.grid), dim3(256), 0, st, A);
+        hipLaunchKernelGGL(k_pack_large, dim3(P.grid), dim3(PACK_LARGE_THREADS), 0, st, A);
     } else if (P.kind == 3) {
         uint32_t *ki = c->ext_out_ids; float *km = c->ext_out_mats; uint32_t kc = c->ext_out_cap, *kn = c->ext_out_count;
         c->ext_out_ids = ids; c->ext_out_mats = mats; c->ext_out_cap = cap; c->ext_out_count = nullptr;

@@ -127,7 +127,20 @@ struct ItemSink {
                                             // through a per-wave LDS histogram flushed once per wave -- so that the pack needs no counting pass (nullptr / 0: off)
 };
 constexpr uint32_t COUNT_SLOTS_MAX = 512;   // group slots the in-scan counting (and k_pack_large) handle; larger tables take the count / scan / scatter kernels
-constexpr uint32_t PACK_LARGE_TILE = 1024;  // instances per workgroup iteration of k_pack_large (4 list entries per thread)
+#ifndef RE_PACK_THREADS
+#define RE_PACK_THREADS 512
+#endif
+#ifndef RE_PACK_CHUNK
+#define RE_PACK_CHUNK 8
+#endif
+// k_pack_large: threads per workgroup, 16-byte matrix loads each thread keeps in flight, instances per tile.  512 / 8 / 1024: every thread has its whole
+// share of the tile's matrices in flight at once (256 threads needed two dependent rounds: 21.9 -> 19.6 us at 501 K instances), and the 624 workgroups of that
+// frame are all resident together (1024 threads or 512-instance tiles need a second round of workgroups: 28.6 / 26.0 us).  tools/pack_variants.py, round 2.
+constexpr uint32_t PACK_LARGE_THREADS = RE_PACK_THREADS, PACK_LARGE_CHUNK = RE_PACK_CHUNK;
+#ifndef RE_PACK_TILE
+#define RE_PACK_TILE 1024
+#endif
+constexpr uint32_t PACK_LARGE_TILE = RE_PACK_TILE;  // instances per workgroup iteration of k_pack_large
 struct PackArgs {                           // what k_pack_small needs besides the item list
     uint32_t nslots, out_cap;
     const uint32_t *row_id; const float *row_mat; uint32_t *out_ids; float *out_mats;

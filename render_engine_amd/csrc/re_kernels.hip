@@ -855,13 +855,13 @@ __global__ __launch_bounds__(256) void k_emit_count_sharded(const FrameHeader *h
 //   * every workgroup moves tiles of PACK_LARGE_TILE instances of ONE shard: rank inside the tile with LDS atomics, ONE global atomic per
 //     (tile, non-empty group) on the shard's own fill counter (contention: tiles of one shard only), then id + 64-byte matrix with 4 lanes per
 //     instance; the matrix loads are issued before the atomics return, so the tile costs two dependent round trips (list entry -> matrix).
-__global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
-    constexpr uint32_t NT = 256, TILE = PACK_LARGE_TILE, PER = TILE / NT, CHUNK = 8u, PASSES = TILE / 64u;
+__global__ __launch_bounds__(PACK_LARGE_THREADS) void k_pack_large(PackLargeArgs A) {
+    constexpr uint32_t NT = PACK_LARGE_THREADS, NW = NT / 64u, TILE = PACK_LARGE_TILE, PER = TILE / NT, IPP = NT / 4u, PASSES = TILE / IPP, CHUNK = PACK_LARGE_CHUNK;   // IPP: instances per matrix pass (4 lanes each)
     static_assert(PASSES % CHUNK == 0, "matrix passes go in chunks");
     __shared__ uint32_t s_gbase[COUNT_SLOTS_MAX];             // first instance of each group (absolute)
     __shared__ uint32_t s_hist[COUNT_SLOTS_MAX], s_tbase[COUNT_SLOTS_MAX];
     __shared__ uint32_t s_row[TILE], s_pos[TILE], s_id[TILE], s_tpre[COUNT_SLOTS_MAX];
-    __shared__ uint32_t s_wsum[4], s_wcnt[4], s_whash[4], s_carry, s_gcarry;
+    __shared__ uint32_t s_wsum[NW], s_wcnt[NW], s_whash[NW], s_carry, s_gcarry;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6, bid = blockIdx.x, nslots = A.nslots, nsh = A.nshards;
     if (A.spec->stale) {                                    // cancelled frame (SpecState)
         if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
@@ -925,7 +925,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         if (wid == 0) {
             const FrameCounts fc = load_frame_counts(A.hdr);
             if (lane == 0) {
-                const uint32_t table_hash = s_whash[0] ^ s_whash[1] ^ s_whash[2] ^ s_whash[3];
+                uint32_t table_hash = 0; for (uint32_t w = 0; w < NW; w++) table_hash ^= s_whash[w];
                 HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;
                 r.n_groups = s_gcarry < A.range_cap ? s_gcarry : A.range_cap; r.total = s_carry; r.overflow = 0; r.n_entries = raw_sec; r.n_items = raw_items;
                 r.table_hash = result_seal(table_hash | 1u, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items);
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
         f32x4 mat[CHUNK];
 #pragma unroll
         for (uint32_t ps = 0; ps < CHUNK; ps++)
-            mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[ps * 64u + li] * 16)[part];
+            mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[ps * IPP + li] * 16)[part];
         for (uint32_t i = tid; i < nslots; i += NT) {
             const uint32_t cnt = s_hist[i];
             s_tbase[i] = s_gbase[i] + (cnt ? atomicAdd(&A.gfill[shard * nslots + i], cnt) : 0u);
@@ -999,11 +999,11 @@ __global__ __launch_bounds__(256) void k_pack_large(PackLargeArgs A) {
             if (c0) {
 #pragma unroll
                 for (uint32_t ps = 0; ps < CHUNK; ps++)
-                    mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[(c0 + ps) * 64u + li] * 16)[part];
+                    mat[ps] = reinterpret_cast<const f32x4 *>(A.row_mat + (size_t)s_row[(c0 + ps) * IPP + li] * 16)[part];
             }
 #pragma unroll
             for (uint32_t ps = 0; ps < CHUNK; ps++) {
-                const uint32_t pp = s_pos[(c0 + ps) * 64u + li];
+                const uint32_t pp = s_pos[(c0 + ps) * IPP + li];
                 if (pp < A.out_cap) reinterpret_cast<f32x4 *>(A.out_mats + (size_t)pp * 16)[part] = mat[ps];
             }
         }
