@@ -4,7 +4,10 @@
 // Tiled deferred shading.  One 256-thread workgroup owns a 32x32-pixel tile (4 pixels per lane):
 //   1. tile AABB of the G-buffer positions (wave shuffles + LDS),
 //   2. exact-conservative culling of the radius ("spot") lights against the tile AABB, 256 lights per round, compacted
-//      into an LDS list in ascending light index (ballot + prefix: the per-pixel summation order is deterministic),
+//      into an LDS list (ballot + prefix: the per-pixel summation order is deterministic).  Only the lights that can reach the
+//      tile along one axis are tested: re_lighting_set_lights orders the records by LIGHT_BUCKETS slabs along the axis of the
+//      lights' largest extent (ascending light index inside a slab), and a tile takes the slabs its AABB, grown by the largest
+//      radius, overlaps -- 192 of the 4096 lights of configs[4] instead of all of them,
 //   3. every lane shades its 4 pixels over the list; the light record (64 B) is fetched with scalar loads
 //      (wave-uniform index), so the inner loop is pure f32 VALU -- the kernel is VALU-bound, not HBM-bound,
 //   4. cone ("point") lights cannot be culled (no radius in the shader) and are evaluated for every pixel,
@@ -24,11 +27,21 @@ namespace {
 
 constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 512;
 constexpr uint32_t CULL_CHUNK = 8;      // rounds of 256 lights whose positions are in flight together
+constexpr uint32_t LIGHT_BUCKETS = 4096; // slabs along the sort axis of the radius lights
 
 struct LightParams {
     uint32_t width, height, n_spot, n_point;
     float cam[3]; float cutoff, default_diffuse; uint32_t any_visible;
+    uint32_t axis; float kmin, inv_w, rmax;                                   // slab of a light: light_bucket(position[axis])
 };
+// the slab a coordinate falls into: monotone in `key` (subtraction, multiplication by a positive constant, clamp and floor all are), so every light whose
+// coordinate lies in [a, b] has its slab in [light_bucket(a), light_bucket(b)] -- the host files the lights with this same function
+__host__ __device__ inline uint32_t light_bucket(float key, float kmin, float inv_w) {
+    float b = (key - kmin) * inv_w;
+    b = b > 0.0f ? b : 0.0f;                                                    // (also NaN -> 0)
+    b = b < (float)(LIGHT_BUCKETS - 1u) ? b : (float)(LIGHT_BUCKETS - 1u);
+    return (uint32_t)b;
+}
 
 __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_float3(x, y, z); }
 __device__ __forceinline__ float dot3(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
@@ -46,7 +59,7 @@ __device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3
     const float d2 = dot3(d, d);
     if (radius_cut) {                                                          // :97-100: dist > radius, decided exactly (the cut is a discontinuity) -- the square root only near the boundary
         const float r2 = A.w * A.w;
-        if (d2 > r2 * 1.000001f) return;
+        if (A.w < 0.0f || d2 > r2 * 1.000001f) return;                         // (a distance is never below a negative radius)
         if (d2 > r2 * 0.999999f && sqrtf(d2) > A.w) return;
     }
     const float inv = __builtin_amdgcn_rsqf(d2), dist = d2 * inv;
@@ -62,7 +75,8 @@ __device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3
 }
 
 __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P, const float4 *__restrict__ gpos, const float4 *__restrict__ gnormal, const uchar4 *__restrict__ galbedo,
-                                                                   const float4 *__restrict__ spot,     // 4 float4 per light: A, B, C, D
+                                                                   const float4 *__restrict__ spot,     // 4 float4 per light: A, B, C, D (slab order)
+                                                                   const uint32_t *__restrict__ slab_start,   // LIGHT_BUCKETS + 1: first record of each slab
                                                                    const float4 *__restrict__ point,    // 5 float4 per light: A(pos), B, C, D, E(dir.xyz normalised, -) + F(cutoff, outer, -, -) packed as 6
                                                                    float4 *__restrict__ out) {
     __shared__ float s_red[4][6];
@@ -114,16 +128,21 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
             __syncthreads();                                                   // (s_rec / s_list are refilled afterwards)
             n = 0;
         };
-        for (uint32_t c0 = 0; c0 < P.n_spot; c0 += LT_THREADS * CULL_CHUNK) {
+        // the records a light of this tile can be among: the slabs [lo - rmax, hi + rmax] along the sort axis (a light farther away along that axis alone misses the tile)
+        const float reach = P.rmax * 1.00001f + 1e-3f;                         // (the margin of the test below)
+        const float alo = P.axis == 0 ? lo[0] : (P.axis == 1 ? lo[1] : lo[2]), ahi = P.axis == 0 ? hi[0] : (P.axis == 1 ? hi[1] : hi[2]);
+        uint32_t l_begin = 0, l_end = 0;
+        if (P.n_spot && ahi >= alo) { l_begin = slab_start[light_bucket(alo - reach, P.kmin, P.inv_w)]; l_end = slab_start[light_bucket(ahi + reach, P.kmin, P.inv_w) + 1u]; }
+        for (uint32_t c0 = l_begin; c0 < l_end; c0 += LT_THREADS * CULL_CHUNK) {
             float4 Ac[CULL_CHUNK];
 #pragma unroll
-            for (uint32_t r = 0; r < CULL_CHUNK; r++) { const uint32_t li = c0 + r * LT_THREADS + tid; Ac[r] = li < P.n_spot ? spot[(size_t)li * 4] : make_float4(0.f, 0.f, 0.f, -1.f); }
+            for (uint32_t r = 0; r < CULL_CHUNK; r++) { const uint32_t li = c0 + r * LT_THREADS + tid; Ac[r] = li < l_end ? spot[(size_t)li * 4] : make_float4(0.f, 0.f, 0.f, -1.f); }
 #pragma unroll
             for (uint32_t r = 0; r < CULL_CHUNK; r++) {
                 const uint32_t i0 = c0 + r * LT_THREADS;
-                if (i0 >= P.n_spot) break;                                      // uniform
+                if (i0 >= l_end) break;                                         // uniform
                 const uint32_t li = i0 + tid; bool hit = false;
-                if (li < P.n_spot) {
+                if (li < l_end) {
                     const float4 A = Ac[r];
                     float dx = fmaxf(fmaxf(lo[0] - A.x, A.x - hi[0]), 0.0f), dy = fmaxf(fmaxf(lo[1] - A.y, A.y - hi[1]), 0.0f), dz = fmaxf(fmaxf(lo[2] - A.z, A.z - hi[2]), 0.0f);
                     float rr = A.w * 1.00001f + 1e-3f;                              // conservative: the exact per-pixel radius test follows
@@ -181,7 +200,7 @@ struct re_lighting {
     re_lighting_config cfg{};
     hipStream_t stream = nullptr;
     std::string err;
-    float4 *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr, *d_spot = nullptr, *d_point = nullptr; uchar4 *d_alb = nullptr;
+    float4 *d_pos = nullptr, *d_nrm = nullptr, *d_out = nullptr, *d_spot = nullptr, *d_point = nullptr; uchar4 *d_alb = nullptr; uint32_t *d_slab = nullptr;
     LightParams P{};
     int fail(int code, const char *fmt, ...) { char buf[512]; va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap); err = buf; return code; }
 };
@@ -199,7 +218,7 @@ extern "C" int re_lighting_create(const re_lighting_config *cfg, re_lighting **o
     size_t np = (size_t)cfg->width * cfg->height;
     if (hipSetDevice(cfg->device) != hipSuccess || hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&l->d_pos, np * 16) != hipSuccess || hipMalloc(&l->d_nrm, np * 16) != hipSuccess || hipMalloc(&l->d_out, np * 16) != hipSuccess || hipMalloc(&l->d_alb, np * 4) != hipSuccess ||
-        hipMalloc(&l->d_spot, (size_t)(cfg->max_spot_lights + 1) * 64) != hipSuccess || hipMalloc(&l->d_point, (size_t)(cfg->max_point_lights + 1) * 96) != hipSuccess) {
+        hipMalloc(&l->d_spot, (size_t)(cfg->max_spot_lights + 1) * 64) != hipSuccess || hipMalloc(&l->d_slab, (size_t)(LIGHT_BUCKETS + 1u) * 4) != hipSuccess || hipMalloc(&l->d_point, (size_t)(cfg->max_point_lights + 1) * 96) != hipSuccess) {
         g_lt_error = "re_lighting_create: device allocation failed"; delete l; return RE_E_HIP;
     }
     l->P.width = cfg->width; l->P.height = cfg->height;
@@ -209,7 +228,7 @@ extern "C" void re_lighting_destroy(re_lighting *l) {
     if (!l) return;
     (void)hipSetDevice(l->cfg.device);
     if (l->stream) (void)hipStreamSynchronize(l->stream);
-    (void)hipFree(l->d_pos); (void)hipFree(l->d_nrm); (void)hipFree(l->d_out); (void)hipFree(l->d_alb); (void)hipFree(l->d_spot); (void)hipFree(l->d_point);
+    (void)hipFree(l->d_pos); (void)hipFree(l->d_nrm); (void)hipFree(l->d_out); (void)hipFree(l->d_alb); (void)hipFree(l->d_spot); (void)hipFree(l->d_point); (void)hipFree(l->d_slab);
     if (l->stream) (void)hipStreamDestroy(l->stream);
     delete l;
 }
@@ -228,8 +247,26 @@ extern "C" int re_lighting_set_lights(re_lighting *l, const re_lights *L) {
     if (L->n_spot > l->cfg.max_spot_lights || L->n_point > l->cfg.max_point_lights) return l->fail(RE_E_CAPACITY, "more lights than configured");
     LCHK(l, hipSetDevice(l->cfg.device));
     std::vector<float> s((size_t)L->n_spot * 16), p((size_t)L->n_point * 24);
+    // the radius lights go to the device in slab order along the axis of their largest extent (see k_deferred_lighting): counting sort by light_bucket,
+    // ascending light index inside a slab
+    uint32_t axis = 0; float kmin = 0.0f, inv_w = 0.0f, rmax = 0.0f;
+    std::vector<uint32_t> slab_start(LIGHT_BUCKETS + 1u, 0u), place(L->n_spot);
+    {
+        float mn[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, mx[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+        for (uint32_t i = 0; i < L->n_spot; i++) {
+            for (int k = 0; k < 3; k++) { const float v = L->spot_pos[3 * i + k]; if (v < mn[k]) mn[k] = v; if (v > mx[k]) mx[k] = v; }   // (comparisons with NaN are false: it takes no part)
+            if (L->spot_radius[i] > rmax) rmax = L->spot_radius[i];
+        }
+        float best = -1.0f;
+        for (int k = 0; k < 3; k++) { const float e = mx[k] - mn[k]; if (e > best && e < 3.0e38f) { best = e; axis = (uint32_t)k; } }
+        if (best > 0.0f) { kmin = mn[axis]; inv_w = (float)LIGHT_BUCKETS / best; if (!(inv_w < 3.0e38f)) inv_w = 0.0f; }                // (all lights at one coordinate, or an extent too small to divide by: one slab)
+        for (uint32_t i = 0; i < L->n_spot; i++) slab_start[light_bucket(L->spot_pos[3 * i + axis], kmin, inv_w) + 1u]++;
+        for (uint32_t b = 0; b < LIGHT_BUCKETS; b++) slab_start[b + 1u] += slab_start[b];
+        std::vector<uint32_t> fill(slab_start.begin(), slab_start.end() - 1);
+        for (uint32_t i = 0; i < L->n_spot; i++) place[i] = fill[light_bucket(L->spot_pos[3 * i + axis], kmin, inv_w)]++;
+    }
     for (uint32_t i = 0; i < L->n_spot; i++) {
-        float *o = &s[(size_t)i * 16];
+        float *o = &s[(size_t)place[i] * 16];
         o[0] = L->spot_pos[3 * i]; o[1] = L->spot_pos[3 * i + 1]; o[2] = L->spot_pos[3 * i + 2]; o[3] = L->spot_radius[i];
         o[4] = L->spot_diffuse[3 * i]; o[5] = L->spot_diffuse[3 * i + 1]; o[6] = L->spot_diffuse[3 * i + 2]; o[7] = L->spot_linear[i];
         o[8] = L->spot_specular[3 * i]; o[9] = L->spot_specular[3 * i + 1]; o[10] = L->spot_specular[3 * i + 2]; o[11] = L->spot_quadratic[i];
@@ -247,8 +284,9 @@ extern "C" int re_lighting_set_lights(re_lighting *l, const re_lights *L) {
     }
     if (L->n_spot) LCHK(l, hipMemcpyAsync(l->d_spot, s.data(), s.size() * 4, hipMemcpyHostToDevice, l->stream));
     if (L->n_point) LCHK(l, hipMemcpyAsync(l->d_point, p.data(), p.size() * 4, hipMemcpyHostToDevice, l->stream));
+    LCHK(l, hipMemcpyAsync(l->d_slab, slab_start.data(), slab_start.size() * 4, hipMemcpyHostToDevice, l->stream));
     LCHK(l, hipStreamSynchronize(l->stream));
-    l->P.n_spot = L->n_spot; l->P.n_point = L->n_point;
+    l->P.n_spot = L->n_spot; l->P.n_point = L->n_point; l->P.axis = axis; l->P.kmin = kmin; l->P.inv_w = inv_w; l->P.rmax = rmax;
     for (int k = 0; k < 3; k++) l->P.cam[k] = L->camera_pos[k];
     l->P.cutoff = L->no_light_source_cutoff; l->P.default_diffuse = L->default_diffuse_factor; l->P.any_visible = L->any_light_source_visible;
     return RE_OK;
@@ -259,7 +297,7 @@ extern "C" int re_lighting_run(re_lighting *l, float *kernel_us) {
     hipEvent_t a = nullptr, b = nullptr;
     if (kernel_us) { LCHK(l, hipEventCreate(&a)); LCHK(l, hipEventCreate(&b)); }
     dim3 grid((l->cfg.width + TILE - 1) / TILE, (l->cfg.height + TILE - 1) / TILE);
-    hipExtLaunchKernelGGL(k_deferred_lighting, grid, dim3(LT_THREADS), 0, l->stream, a, b, 0, l->P, l->d_pos, l->d_nrm, l->d_alb, l->d_spot, l->d_point, l->d_out);
+    hipExtLaunchKernelGGL(k_deferred_lighting, grid, dim3(LT_THREADS), 0, l->stream, a, b, 0, l->P, l->d_pos, l->d_nrm, l->d_alb, l->d_spot, l->d_slab, l->d_point, l->d_out);
     LCHK(l, hipGetLastError());
     LCHK(l, hipStreamSynchronize(l->stream));
     if (kernel_us) { float ms = 0; LCHK(l, hipEventElapsedTime(&ms, a, b)); *kernel_us = ms * 1000.f; (void)hipEventDestroy(a); (void)hipEventDestroy(b); }

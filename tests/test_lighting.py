@@ -57,6 +57,36 @@ def test_lighting_matches_oracle_small(w, h, ns, npt):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tall", "one_point", "mixed_radii", "far_apart"])
+def test_lighting_odd_light_sets(case):
+    """light sets that stress the slab order of the records (re_lighting_set_lights): largest extent along y, no extent at all, radii from tiny to
+    larger than the scene and negative (a distance is never below a negative radius: the light never shines), a few lights far outside the scene"""
+    from render_engine_amd import lighting
+    w, h = 160, 96
+    pos, nrm, alb = lighting.synthetic_gbuffer(w, h, patch=200.0)
+    L = lighting.synthetic_lights(n_spot=700, n_point=3, patch=200.0, radius=30.0)
+    rng = np.random.default_rng(11)
+    sp = L["spot_pos"]
+    if case == "tall":
+        sp[:, 1] = 1000.0 + rng.random(700).astype(np.float32) * 900.0 - 450.0; sp[:, 0] = 1100.0 + rng.random(700).astype(np.float32) * 5.0
+    elif case == "one_point":
+        sp[:] = np.array([1090.0, 1012.0, 1060.0], np.float32); L["spot_radius"] = (rng.random(700) * 90.0).astype(np.float32)
+    elif case == "mixed_radii":
+        r = (1.0 + rng.random(700) * 120.0).astype(np.float32); r[5] = 5000.0; r[17] = -40.0; r[300:310] = -1.0; r[400] = 0.0
+        L["spot_radius"] = r
+    else:
+        sp[::50] += np.float32(1.0e6); sp[7] -= np.float32(3.0e7)
+    dl = lighting.DeferredLighting(w, h, max_spot_lights=1024, max_point_lights=16)
+    dl.upload_gbuffer(pos, nrm, alb); dl.set_lights(L)
+    dl.run()
+    got = dl.read()
+    S, keep = oracle_lights(L)
+    exp = ro.deferred_lighting(pos, nrm, alb, S)
+    assert np.abs(got - exp).max() <= TOL, (case, np.abs(got - exp).max())
+    dl.close()
+
+
+@pytest.mark.gpu
 def test_lighting_full_size_sampled():
     """4096x4096 G-buffer, 4096 radius-40 lights (configs[4]): 4096 random pixels against the brute-force CPU evaluation,
     plus size-independent properties (alpha, range, determinism)."""
