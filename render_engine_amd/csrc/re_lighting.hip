@@ -26,7 +26,7 @@
 namespace {
 
 constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 512;
-constexpr uint32_t CULL_CHUNK = 8;      // rounds of 256 lights whose positions are in flight together
+constexpr uint32_t CULL_CHUNK = 2;      // rounds of 256 lights whose positions are in flight together (a tile of configs[4] tests 192 lights; more rounds in flight cost registers: 8 -> 152 VGPRs, 2 -> 128)
 constexpr uint32_t LIGHT_BUCKETS = 4096; // slabs along the sort axis of the radius lights
 
 struct LightParams {
@@ -60,7 +60,11 @@ __device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3
     if (radius_cut) {                                                          // :97-100: dist > radius, decided exactly (the cut is a discontinuity) -- the square root only near the boundary
         const float r2 = A.w * A.w;
         if (A.w < 0.0f || d2 > r2 * 1.000001f) return;                         // (a distance is never below a negative radius)
-        if (d2 > r2 * 0.999999f && sqrtf(d2) > A.w) return;
+        const bool shell = d2 > r2 * 0.999999f;
+        if (__builtin_amdgcn_ballot_w64(shell)) {                              // a wave-uniform branch the compiler cannot flatten (the asm pins the operand inside it): flattened,
+            float t = d2; asm volatile("" : "+v"(t));                           // the IEEE square root (22 instructions) ran for every pixel inside the radius
+            if (shell && sqrtf(t) > A.w) return;
+        }
     }
     const float inv = __builtin_amdgcn_rsqf(d2), dist = d2 * inv;
     float3 nd = f3(d.x * inv, d.y * inv, d.z * inv);
