@@ -78,6 +78,43 @@ __device__ __forceinline__ void shade(float3 frag, float3 nrm, float3 od, float3
     acc.z += (od.z * D.z * D.w) * att; acc.z += (B.z * od.z * dc) * att * intensity; acc.z += (C.z * sf) * att;
 }
 
+// The radius lights' inner loop works on TWO pixels of a lane at a time, as 2-vectors: gfx950 issues v_pk_{add,mul,fma}_f32 on a register pair at the rate of
+// the scalar forms, so everything but the reciprocals / reciprocal square roots costs half the instructions per pixel.  A pixel of the pair that is outside the
+// radius (or outside the image) is computed along and its contribution dropped at the end (selected, not multiplied: its intermediate values may be inf / NaN).
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct PixelPair { f2 fx, fy, fz, nx, ny, nz, ox, oy, oz, cx, cy, cz; };        // position, normal, albedo, direction to the camera
+__device__ __forceinline__ f2 rsq2(f2 v) { f2 r; r.x = __builtin_amdgcn_rsqf(v.x); r.y = __builtin_amdgcn_rsqf(v.y); return r; }
+__device__ __forceinline__ f2 rcp2(f2 v) { f2 r; r.x = __builtin_amdgcn_rcpf(v.x); r.y = __builtin_amdgcn_rcpf(v.y); return r; }
+__device__ __forceinline__ f2 max0(f2 v) { f2 r; r.x = fmaxf(v.x, 0.0f); r.y = fmaxf(v.y, 0.0f); return r; }
+__device__ __forceinline__ void shade_pair(const PixelPair &X, bool live0, bool live1, float4 A, float4 B, float4 C, float4 D, f2 &ax, f2 &ay, f2 &az) {
+#pragma clang fp contract(fast)
+    const f2 dx = A.x - X.fx, dy = A.y - X.fy, dz = A.z - X.fz;
+    const f2 d2 = (dx * dx + dy * dy) + dz * dz;
+    // :97-100: dist > radius, decided exactly (the cut is a discontinuity) -- the square root only near the boundary
+    const float r2 = A.w * A.w, r2_out = r2 * 1.000001f, r2_in = r2 * 0.999999f;
+    bool in0 = live0 && !(A.w < 0.0f) && !(d2.x > r2_out), in1 = live1 && !(A.w < 0.0f) && !(d2.y > r2_out);      // (a distance is never below a negative radius)
+    const bool shell0 = in0 && d2.x > r2_in, shell1 = in1 && d2.y > r2_in;
+    if (__builtin_amdgcn_ballot_w64(shell0 || shell1)) {                      // a wave-uniform branch the compiler cannot flatten (the asm pins the operands inside it): flattened,
+        float t0 = d2.x, t1 = d2.y; asm volatile("" : "+v"(t0), "+v"(t1));     // the IEEE square root (22 instructions) ran for every pixel inside the radius
+        if (shell0 && sqrtf(t0) > A.w) in0 = false;
+        if (shell1 && sqrtf(t1) > A.w) in1 = false;
+    }
+    if (!(in0 || in1)) return;
+    const f2 inv = rsq2(d2), dist = d2 * inv;
+    const f2 ndx = dx * inv, ndy = dy * inv, ndz = dz * inv;
+    const f2 att = rcp2(1.0f + B.w * dist + C.w * dist * dist);                // calculateAttenuation :132-136
+    const f2 dc = max0((X.nx * ndx + X.ny * ndy) + X.nz * ndz);                // calculateDiffuse :118-122
+    const f2 hx = ndx + X.cx, hy = ndy + X.cy, hz = ndz + X.cz;                // calculateSpecular :124-130
+    const f2 invh = rsq2((hx * hx + hy * hy) + hz * hz);
+    f2 sf = max0(((X.nx * hx + X.ny * hy) + X.nz * hz) * invh);
+    sf *= sf; sf *= sf; sf *= sf; sf *= sf; sf *= sf; sf *= sf;                 // pow(., 64)
+    // ambient * albedo + diffuse * albedo * dc + specular * sf, all times the attenuation
+    const f2 tx = (X.ox * (B.x * dc + D.x * D.w) + C.x * sf) * att, ty = (X.oy * (B.y * dc + D.y * D.w) + C.y * sf) * att, tz = (X.oz * (B.z * dc + D.z * D.w) + C.z * sf) * att;
+    f2 cx, cy, cz;
+    cx.x = in0 ? tx.x : 0.0f; cx.y = in1 ? tx.y : 0.0f; cy.x = in0 ? ty.x : 0.0f; cy.y = in1 ? ty.y : 0.0f; cz.x = in0 ? tz.x : 0.0f; cz.y = in1 ? tz.y : 0.0f;
+    ax += cx; ay += cy; az += cz;
+}
+
 __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P, const float4 *__restrict__ gpos, const float4 *__restrict__ gnormal, const uchar4 *__restrict__ galbedo,
                                                                    const float4 *__restrict__ spot,     // 4 float4 per light: A, B, C, D (slab order)
                                                                    const uint32_t *__restrict__ slab_start,   // LIGHT_BUCKETS + 1: first record of each slab
@@ -100,8 +137,11 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
             size_t p = (size_t)y * P.width + tx;
             float4 gp = gpos[p], gn = gnormal[p]; uchar4 ga = galbedo[p];
             frag[k] = f3(gp.x, gp.y, gp.z); nrm[k] = f3(gn.x, gn.y, gn.z);
-            od[k] = f3(ga.x / 255.0f, ga.y / 255.0f, ga.z / 255.0f);
-            camdir[k] = norm3v(sub3(f3(P.cam[0], P.cam[1], P.cam[2]), frag[k]));
+            // (per-pixel setup with the hardware's 1-ulp operations, like the shading itself: the IEEE divisions and square root here were ~300 of a tile's ~1,900 instructions per wave)
+            constexpr float k255 = 1.0f / 255.0f;
+            od[k] = f3(ga.x * k255, ga.y * k255, ga.z * k255);
+            const float3 tc = sub3(f3(P.cam[0], P.cam[1], P.cam[2]), frag[k]); const float itc = __builtin_amdgcn_rsqf(dot3(tc, tc));
+            camdir[k] = f3(tc.x * itc, tc.y * itc, tc.z * itc);
             lo[0] = fminf(lo[0], gp.x); lo[1] = fminf(lo[1], gp.y); lo[2] = fminf(lo[2], gp.z);
             hi[0] = fmaxf(hi[0], gp.x); hi[1] = fmaxf(hi[1], gp.y); hi[2] = fmaxf(hi[2], gp.z);
         }
@@ -119,7 +159,16 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         // together before their tests, and the 64-byte records of the listed lights are fetched into LDS by the whole workgroup in one go, so the
         // per-pixel loop reads them as LDS broadcasts (round 1 loaded each light's record with scalar loads inside that loop: one exposed L2
         // latency per listed light and tile).
-        float3 spot_acc[4]; for (int k = 0; k < 4; k++) spot_acc[k] = f3(0.f, 0.f, 0.f);
+        PixelPair X[2]; f2 sax[2], say[2], saz[2];                              // pixels (0, 1) and (2, 3) of the lane
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int k0 = 2 * q, k1 = 2 * q + 1;
+            X[q].fx.x = frag[k0].x; X[q].fx.y = frag[k1].x; X[q].fy.x = frag[k0].y; X[q].fy.y = frag[k1].y; X[q].fz.x = frag[k0].z; X[q].fz.y = frag[k1].z;
+            X[q].nx.x = nrm[k0].x; X[q].nx.y = nrm[k1].x; X[q].ny.x = nrm[k0].y; X[q].ny.y = nrm[k1].y; X[q].nz.x = nrm[k0].z; X[q].nz.y = nrm[k1].z;
+            X[q].ox.x = od[k0].x; X[q].ox.y = od[k1].x; X[q].oy.x = od[k0].y; X[q].oy.y = od[k1].y; X[q].oz.x = od[k0].z; X[q].oz.y = od[k1].z;
+            X[q].cx.x = camdir[k0].x; X[q].cx.y = camdir[k1].x; X[q].cy.x = camdir[k0].y; X[q].cy.y = camdir[k1].y; X[q].cz.x = camdir[k0].z; X[q].cz.y = camdir[k1].z;
+            sax[q] = say[q] = saz[q] = (f2)(0.0f);
+        }
         uint32_t n = 0;                                                        // listed lights (uniform)
         auto shade_list = [&]() {
             for (uint32_t idx = tid; idx < n * 4u; idx += LT_THREADS) s_rec[idx] = spot[(size_t)s_list[idx >> 2] * 4 + (idx & 3u)];
@@ -127,7 +176,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
             for (uint32_t j = 0; j < n; j++) {
                 const float4 A = s_rec[j * 4u], B = s_rec[j * 4u + 1u], C = s_rec[j * 4u + 2u], D = s_rec[j * 4u + 3u];
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (live[k]) shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, true, 1.0f, spot_acc[k]);
+                for (int q = 0; q < 2; q++) shade_pair(X[q], live[2 * q], live[2 * q + 1], A, B, C, D, sax[q], say[q], saz[q]);
             }
             __syncthreads();                                                   // (s_rec / s_list are refilled afterwards)
             n = 0;
@@ -176,6 +225,9 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
                 shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, false, intensity, point_acc[k]);
             }
         }
+        float3 spot_acc[4];
+#pragma unroll
+        for (int q = 0; q < 2; q++) { spot_acc[2 * q] = f3(sax[q].x, say[q].x, saz[q].x); spot_acc[2 * q + 1] = f3(sax[q].y, say[q].y, saz[q].y); }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             // main() :42-44: lightColour = spot; lightColour += point; lightColour += spot
