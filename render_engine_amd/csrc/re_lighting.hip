@@ -47,6 +47,7 @@ __device__ __forceinline__ float3 f3(float x, float y, float z) { return make_fl
 __device__ __forceinline__ float dot3(float3 a, float3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ float3 sub3(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ float3 norm3v(float3 v) { float n = sqrtf(dot3(v, v)); return f3(v.x / n, v.y / n, v.z / n); }
+__device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }   // a value every lane holds alike -> a scalar register
 __device__ __forceinline__ float pow64(float x) { x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; return x; }
 
 // one light's contribution to one pixel; A = (pos, radius|unused), B = (diffuse, linear), C = (specular, quadratic), D = ambient rgba
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
             for (int d = 32; d >= 1; d >>= 1) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64)); }
         if (lane == 0) for (int a = 0; a < 3; a++) { s_red[wid][a] = lo[a]; s_red[wid][3 + a] = hi[a]; }
         __syncthreads();
-        for (int a = 0; a < 3; a++) { lo[a] = fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a])); hi[a] = fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a])); }
+        for (int a = 0; a < 3; a++) { lo[a] = uniform(fminf(fminf(s_red[0][a], s_red[1][a]), fminf(s_red[2][a], s_red[3][a]))); hi[a] = uniform(fmaxf(fmaxf(s_red[0][3 + a], s_red[1][3 + a]), fmaxf(s_red[2][3 + a], s_red[3][3 + a]))); }
         // ---- radius lights: cull 256 per round into the ordered LDS list, shade whenever the list could overflow ----
         // Two things keep a tile from waiting on one memory round trip after the other: the positions of CULL_CHUNK rounds of lights are requested
         // together before their tests, and the 64-byte records of the listed lights are fetched into LDS by the whole workgroup in one go, so the
