@@ -205,9 +205,9 @@ extern "C" uint32_t re_abi_version(void) { return 2u; }
 
 // Everything the kernels publish to the polling host thread lives in ONE block of mapped, coherent pinned host memory per frame lane
 // (hipHostMallocMapped | hipHostMallocCoherent): the frame result at 0, the speculation word at 128, the tick counters at 256, the
-// InstanceRange table from 4096 on.  (Round 1 used four separate hipHostMalloc(Mapped) blocks; what made its group table arrive after
+// InstanceRange table from 8192 on.  (Round 1 used four separate hipHostMalloc(Mapped) blocks; what made its group table arrive after
 // the "frame done" word was not the number of blocks but the plain store of that word -- see publish_to_host in re_kernels.h.)
-constexpr size_t HB_RES = 0, HB_SPEC = 128, HB_TICK = 256, HB_RANGES = 4096;
+constexpr size_t HB_RES = 0, HB_SPEC = 128, HB_TICK = 256, HB_RANGES = 8192;
 static_assert(sizeof(HostResult) <= HB_SPEC && sizeof(SpecState) <= HB_TICK - HB_SPEC && HB_TICK + sizeof(TickHeader) <= HB_RANGES, "host block layout");
 static hipError_t alloc_host_block(uint32_t nslots, void **host, void **dev) {
     const size_t bytes = HB_RANGES + sizeof(InstanceRange) * (size_t)std::max(nslots, 1u);
@@ -1991,7 +1991,7 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
 static int fetch_tick_counters(re_ctx *c) {
     TickHeader t;
     HIPCHK(c, hipMemcpyAsync(&t, c->d_th.p, sizeof t, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) t.n_changed += t.shard[k * 16u];
+    for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) t.n_changed += t.shard[k * TICK_SHARD_STRIDE];
     c->h_th->n_changed = t.n_changed; c->h_th->n_rebucket = t.n_rebucket; c->h_th->n_oob = t.n_oob;
     return RE_OK;
 }

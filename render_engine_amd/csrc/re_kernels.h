@@ -65,8 +65,8 @@ struct FrameHeader {
                                             // reference), [1] visible sections (map), [2] visible sections (vec, with duplicates)
 };
 struct FrameCounts { uint32_t n_candidates, n_vis_map, n_vis_vec; };
-constexpr uint32_t TICK_TICKET_SHARDS = 32;
-struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * 16]; };   // shard: k_tick's share of n_changed, one counter per 64-byte line (a single address serialises the waves' atomics); readers add them up
+constexpr uint32_t TICK_TICKET_SHARDS = 32, TICK_SHARD_STRIDE = 32;   // counters 128 bytes apart: atomics serialise per 128-byte line
+struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * TICK_SHARD_STRIDE]; };   // shard: k_tick's share of n_changed, one counter per 128-byte line (a single line serialises the waves' atomics); readers add them up
 // Speculation across frames of a world with dynamic entities: frames are enqueued without waiting for the previous tick; a tick that
 // finds entities that change section (or leave the world) raises `stale`, and every kernel enqueued after it cancels itself until the
 // host has patched the tree and replayed those frames.

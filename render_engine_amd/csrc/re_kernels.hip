@@ -1425,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
         const uint32_t lane = lane_id();
         uint32_t base_r = 0, base_o = 0;
         if (lane == 0) {
-            atomicAdd(&th->shard[((blockIdx.x * 4u + (threadIdx.x >> 6)) & (TICK_TICKET_SHARDS - 1u)) * 16u], (uint32_t)__popcll(mc));   // n_changed, sharded: ONE address takes ~88 atomics per us (measured: 1,575 waves = 18 us of a 25 us launch)
+            atomicAdd(&th->shard[((blockIdx.x * 4u + (threadIdx.x >> 6)) & (TICK_TICKET_SHARDS - 1u)) * TICK_SHARD_STRIDE], (uint32_t)__popcll(mc));   // n_changed, sharded: ONE address takes ~88 atomics per us (measured: 1,575 waves = 18 us of a 25 us launch)
             if (mr) base_r = atomicAdd(&th->n_rebucket, (uint32_t)__popcll(mr));
             if (mo) base_o = atomicAdd(&th->n_oob, (uint32_t)__popcll(mo));
             if (mr | mo) {                                                        // {stale = 1, stale_frame = frame} in one store: the host must patch the tree / retire the rows before any later frame runs
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
 // stream synchronise considers finished).
 __global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t a = th->n_changed; for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) a += th->shard[k * 16u];       // (n_changed itself: the per-lane adds of a change batch, k_apply_rows)
+    uint32_t a = th->n_changed; for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) a += th->shard[k * TICK_SHARD_STRIDE];       // (n_changed itself: the per-lane adds of a change batch, k_apply_rows)
     const uint32_t b = th->n_rebucket, c2 = th->n_oob;
     h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
     publish_to_host(&h_th->ticket, seq);
