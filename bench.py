@@ -459,7 +459,8 @@ def lighting_leg(headline, steps=20, warmup=3):
             "ms_per_step": t * 1e-3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["workload"]},
             "roofline": {"bound": "hbm", "note": "the kernel is fp32-VALU bound (no MFMA: per-light branchy shading), so this HBM fraction is low by construction; the VALU fraction is in `lighting`",
-                         "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS, "traffic": None},
+                         "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
+                         "traffic": committed_traffic("lighting")[0], "traffic_source": committed_traffic("lighting")[1]},
             "lighting": res}
 
 
