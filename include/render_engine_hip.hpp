@@ -260,6 +260,7 @@ class Pipeline {
     // caller dispatches FrameResult::collisions to the CollisionFunction of each this_entity's type
     FrameResult execute(const Camera &camera, float delta_time, bool copy = false, bool emit_duplicates = false, bool collide = false) {
         upload_if_needed();
+        executed_ = true;
         re_camera cam{};
         Mat4 pv = detail::mul(camera.get_projection_matrix(), camera.get_view_matrix());
         std::memcpy(cam.projection_view, pv.data(), 64);
@@ -338,6 +339,9 @@ class Pipeline {
     void read(EntityId e, int component, void *dst) { upload_if_needed(); check(re_read_component(ctx_, e, component, dst), "re_read_component"); }
     void upload_if_needed() {
         if (uploaded_) return;
+        // re_upload_entities REPLACES the world (include/re_hip.h): after frames have run it would put every entity back to the state it was registered with.
+        // The reference can register more instances at any time (flows/pipeline.rs:186-208); this path cannot yet, and says so instead of resetting the world.
+        if (executed_) throw Error(RE_E_STATE, "entities registered or re-described after the first executed frame: not supported (re_upload_entities replaces the world)");
         const size_t n = rows_.size();
         std::vector<uint32_t> id(n), model(n), rs(n), sortable(n), flags(n);
         std::vector<float> aabb(n * 6), pos(n * 3), rot(n * 4), scl(n * 3), vel(n * 3), acc(n * 3), rv(n * 4), ra(n * 4);
@@ -360,7 +364,7 @@ class Pipeline {
         check(re_upload_entities(ctx_, &E, &n_rejected_), "re_upload_entities");
         uploaded_ = true;
     }
-    re_ctx *ctx_ = nullptr; std::vector<Row> rows_; bool uploaded_ = false; uint32_t n_rejected_ = 0;
+    re_ctx *ctx_ = nullptr; std::vector<Row> rows_; bool uploaded_ = false, executed_ = false; uint32_t n_rejected_ = 0;
 };
 
 inline void EntityTransformationBuilder::apply_choices(StaticAABB original_aabb, Pipeline &pipeline) {     // entity_transformer.rs:55-75, 99-142
