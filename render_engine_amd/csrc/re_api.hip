@@ -203,6 +203,18 @@ struct re_ctx {
 
 extern "C" uint32_t re_abi_version(void) { return 2u; }
 
+// RE_EXP_TIME_ISSUE=1: host time of a frame's phases (printed by re_destroy): what the calling thread spends per frame outside the kernels
+namespace {
+struct IssueClock {
+    bool on = getenv("RE_EXP_TIME_ISSUE") != nullptr; uint64_t n = 0; double params = 0, spans = 0, scan = 0, pack = 0, wait = 0, finish = 0;
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void report() const { if (on && n) fprintf(stderr, "host us per frame over %llu frames: parameters %.2f  spans %.2f  scan launch %.2f  pack launch %.2f  wait for the result %.2f  finish %.2f\n",
+                                                 (unsigned long long)n, params / n, spans / n, scan / n, pack / n, wait / n, finish / n); }
+};
+IssueClock g_issue_clock;
+}
+static void report_issue_clock() { g_issue_clock.report(); g_issue_clock.n = 0; g_issue_clock.params = g_issue_clock.spans = g_issue_clock.scan = g_issue_clock.pack = g_issue_clock.wait = g_issue_clock.finish = 0; }
+
 // Everything the kernels publish to the polling host thread lives in ONE block of mapped, coherent pinned host memory per frame lane
 // (hipHostMallocMapped | hipHostMallocCoherent): the frame result at 0, the speculation word at 128, the tick counters at 256, the
 // InstanceRange table from 8192 on.  (Round 1 used four separate hipHostMalloc(Mapped) blocks; what made its group table arrive after
@@ -264,6 +276,7 @@ static void free_world(re_ctx *c) {
 
 extern "C" void re_destroy(re_ctx *c) {
     if (!c) return;
+    report_issue_clock();
     (void)hipSetDevice(c->device);
     if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -832,7 +845,15 @@ static ScanSpans candidate_spans(re_ctx *c, uint32_t nchunks) {
         }
         if (x0 >= x1) continue;
         uint64_t k0 = ((uint64_t)l << 48) | ((uint64_t)x0 << 32), k1 = ((uint64_t)l << 48) | ((uint64_t)x1 << 32);
-        size_t i0 = std::lower_bound(K.begin(), K.end(), k0) - K.begin(), i1 = std::lower_bound(K.begin(), K.end(), k1) - K.begin();
+        // two-level search (the block index of every 1024th key stays in cache; a plain binary search over the 80 MB key array costs ~0.5 us of cache misses per bound,
+        // in front of every frame's launch)
+        auto bound = [&](uint64_t k) -> size_t {
+            if (c->base_index.empty()) return (size_t)(std::lower_bound(K.begin(), K.end(), k) - K.begin());
+            const size_t blk = std::lower_bound(c->base_index.begin(), c->base_index.end(), k) - c->base_index.begin();     // first block whose first key is >= k
+            const size_t lo = blk ? (blk - 1) * 1024 : 0, hi = std::min(blk * 1024 + 1, K.size());
+            return (size_t)(std::lower_bound(K.begin() + lo, K.begin() + hi, k) - K.begin());
+        };
+        size_t i0 = bound(k0), i1 = bound(k1);
         if (i0 >= i1) continue;
         sp.push_back({ (uint32_t)(i0 / per), std::min(nchunks, (uint32_t)((i1 + per - 1) / per)) });
     }
@@ -990,6 +1011,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     // resident, and whatever reads them next is ordered behind the pack on the stream.  Not when a tick that may leave the tree
     // stale is in flight: that needs resolve().
     bool done = false;
+    const double t_wait0 = g_issue_clock.on ? IssueClock::now() : 0.0;
     if (!(c->tick_inflight && c->ndyn)) {
         const volatile uint32_t *flag = &c->h_res->done_frame;
         const auto t0 = std::chrono::steady_clock::now();
@@ -998,6 +1020,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         if (done) { std::atomic_thread_fence(std::memory_order_acquire); if (c->h_res->overflow == 2u || (c->h_spec && c->h_spec->stale)) done = false; else c->pending.clear(); }
     }
     if (!done) { int rc = resolve(c); if (rc != RE_OK) return rc; }
+    const double t_wait1 = g_issue_clock.on ? IssueClock::now() : 0.0; g_issue_clock.wait += t_wait1 - t_wait0;
     c->cull_inflight = false; c->lane_busy = false;
     if (c->h_res->overflow == 1) {
         // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
@@ -1033,6 +1056,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
     }
     if (c->h_res->n_items > c->item_cap) return c->fail(RE_E_CAPACITY, "instance expansion capacity exceeded (%u > %u)", c->h_res->n_items, c->item_cap);
     fill_visible(c, out);
+    if (g_issue_clock.on) g_issue_clock.finish += IssueClock::now() - t_wait1;
     return RE_OK;
 }
 
@@ -1106,6 +1130,8 @@ static int flush_deferred_pack(re_ctx *c) {
 
 static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     hipStream_t st = c->stream;
+    IssueClock &IC = g_issue_clock; double t_ic = IC.on ? IssueClock::now() : 0.0;
+    auto lap = [&](double &acc) { if (IC.on) { const double t = IssueClock::now(); acc += t - t_ic; t_ic = t; } };
     if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
     c->frame += 1;
     make_frame_params(c, cam, flags);
@@ -1177,7 +1203,9 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
             probed = true; c->probe_frames++;
         }
     }
+    lap(IC.params);
     const ScanSpans SP = probed ? ScanSpans{} : candidate_spans(c, scan_grid);
+    lap(IC.spans);
     // a pack deferred by the previous frame rides in the first workgroups of this frame's scan (one launch per frame); any other
     // kind of launch here sends it off on its own first
     const bool fuse = c->deferred_pack && !probed && c->deferred_grid < (1u << 20);
@@ -1198,6 +1226,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     if (fuse) { c->deferred_pack = false; c->n_fused_frames++; }
     HIPCHK(c, hipGetLastError());
+    lap(IC.scan);
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[1], st));
     if (small) {
         // workgroup b packs 64 instances of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length (+50 %),
@@ -1219,6 +1248,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         if (rc != RE_OK) return rc;
     }
     HIPCHK(c, hipGetLastError());
+    lap(IC.pack); if (IC.on) IC.n++;
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[2], st));
     c->have_cull = true; c->cull_inflight = true; c->th_clean = true;
     c->pending.push_back(re_ctx::PendingCall{ 0, c->frame, *cam, flags, 0.f, c->ext_out_ids, c->ext_out_mats, c->ext_out_cap, c->ext_out_count });
