@@ -208,7 +208,9 @@ class Pipeline:
 
     # -- Pipeline::register_model_instances ------------------------------------------------------
     def register_model_instances(self, ents):
-        """ents: numpy structured array of ENTITY_DT.  Returns the number rejected as out of bounds."""
+        """ents: numpy structured array of ENTITY_DT.  Returns the number rejected as out of bounds.
+        REPLACES the world (re_upload_entities): the reference's Pipeline::register_model_instances (flows/pipeline.rs:186-208) appends and may be
+        called at any time; here every instance is registered in one call before the first frame (known deviations)."""
         e = np.ascontiguousarray(ents, ENTITY_DT)
         n = len(e)
         cols = dict(
