@@ -121,6 +121,28 @@ def launch_us(p, camc, kernel, n, pipelined, tick_all=False):
     return float(np.mean(us)) if len(us) else None
 
 
+def pin_near_gpu(index):
+    """Runs this process on the CPUs of the GPU's NUMA node (sysfs local_cpulist), before anything is allocated: the result block the kernels publish into is
+    pinned host memory of the calling thread's node and the thread polls it, so a thread (or a block) on the other socket adds a socket hop to every frame
+    (tools/affinity_probe.py: 24.7 us per synchronous frame on a local CPU, 25.2 us on a remote one; runs whose block landed on the remote node were up to 3 us slower).
+    Returns a description for the bench line; does nothing when sysfs does not say or the CPU set is restricted away from that node."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        cpus = set()
+        for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-"); cpus.update(range(int(lo), int(hi or lo) + 1))
+        local = os.sched_getaffinity(0) & cpus
+        if not local:
+            return "unchanged (no allowed CPU on the GPU's NUMA node)"
+        os.sched_setaffinity(0, local)
+        return "%d CPUs of the GPU's NUMA node (%s)" % (len(local), bdf)
+    except Exception as e:      # noqa: BLE001
+        return "unchanged (%s)" % str(e)[:80]
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,6 +156,7 @@ def main():
     if backend != "nccl":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    affinity = pin_near_gpu(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -289,7 +312,7 @@ def main():
                          "achieved_survey_8d": gbs(bytes_8d, k1_mean), "frac_survey_8d": (gbs(bytes_8d, k1_mean) or 0) / HBM_PEAK_GBS if k1_mean == k1_mean else None,
                          "basis": "achieved / frac use bytes_compulsory (what this layout must move); frac_survey_8d > 1 means the kernel does not move SURVEY 8d's bytes: sections outside the frustum cost only their %d-byte stream key" % key_bytes,
                          "traffic": traffic, "traffic_source": tr_src},
-            "setup_s": t_setup,
+            "setup_s": t_setup, "cpu_affinity": affinity,
         }
         if world == 1:
             kt = kernel_times(p, camc, 16, a.tick_all)
