@@ -37,6 +37,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak (MI355X_MICROARCH.md), the bound of the lighting kernel
 PER_GPU_AXIS = 216             # 216^3 = 10,077,696 sections/entities per GPU
 MEDIAN_FRAMES = 128            # median of >= 100 frames
+K1_MIN_LAUNCHES = 96           # launches of the dominant kernel timed with HIP events, whatever --steps is
+CLOCK_WARMUP_FRAMES = 8000     # untimed asynchronous frames (~7 us each) in front of the warm-up steps: the run starts on an idle-clock GPU
 
 
 def parse():
@@ -251,6 +253,13 @@ def main():
             print(json.dumps({"pipelined_ms_per_frame": per * 1e3, "entities_per_s": n_local / per}))
         return
 
+    # Clock warm-up, untimed and in front of the W warm-up steps: the run starts behind seconds of host-side setup with the GPU in its idle power
+    # state, and W = 5 synchronous frames (~0.1 ms) do not bring the clocks up -- round 2's driver run timed its five launches at 17.4 us where a
+    # warm GPU needs 11.  ~50 ms of back-to-back frames, the same treatment the far = 8192 and lighting legs already had.
+    if world == 1:
+        pipelined_frames(p, camc, CLOCK_WARMUP_FRAMES, a.tick_all)
+    else:
+        frames(CLOCK_WARMUP_FRAMES // 8)
     frames(a.warmup)
     fence()
     p.timing_begin(a.steps, every=TIMING_EVERY)
@@ -259,12 +268,22 @@ def main():
     vis = frames(a.steps, wall)
     fence()
     elapsed = time.perf_counter() - t_start
-    k1_us = p.timing_collect(a.steps)
+    k1_region = p.timing_collect(a.steps)
     n_cand = p.last_candidates()
     med_frames = list(wall)
     if len(med_frames) < MEDIAN_FRAMES:                # median of >= 100 frames
         frames(MEDIAN_FRAMES - len(med_frames), med_frames)
         fence()
+    # the dominant kernel's own launches: at least K1_MIN_LAUNCHES of them whatever --steps was (the timed region alone holds steps / TIMING_EVERY),
+    # every launch of further synchronous frames of the same loop, directly behind the timed region
+    n_more = max(K1_MIN_LAUNCHES - len(k1_region), 0)
+    k1_more = np.zeros(0, np.float32)
+    if n_more:
+        p.timing_begin(n_more, every=1)
+        frames(n_more)
+        fence()
+        k1_more = p.timing_collect(n_more)
+    k1_us = np.concatenate([np.asarray(k1_region, np.float32), np.asarray(k1_more, np.float32)])
     if dist is not None:
         t = torch.tensor([elapsed, float(np.median(med_frames))], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, med_us = float(t[0].item()), float(t[1].item())
@@ -306,11 +325,18 @@ def main():
                        "sharding": "none" if world == 1 else "contiguous section-key ranges; per frame one all-gather of fixed %d-instance slabs (header written by the pack kernel), stream-ordered behind the pack" % SLAB_INSTANCES,
                        "exchange": exchange},
             "roofline": {"bound": "hbm", "kernel": "k_probe_cull" if probed else "k_scan_cull", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "mean_launch_us": k1_mean, "launches_timed": int(len(k1_us)), "timed_every": TIMING_EVERY,
+                         "mean_launch_us": k1_mean, "median_launch_us": float(np.median(k1_us)) if len(k1_us) else None, "min_launch_us": float(np.min(k1_us)) if len(k1_us) else None,
+                         "launches_timed": int(len(k1_us)), "launches_in_timed_region": int(len(k1_region)), "timed_every_in_region": TIMING_EVERY,
+                         "mean_launch_us_timed_region": float(np.mean(k1_region)) if len(k1_region) else None,
                          "bytes_compulsory": bytes_comp, "bytes_survey_8d": bytes_8d, "stream_key_bytes": key_bytes,
                          "achieved": gbs(bytes_comp, k1_mean), "frac": (gbs(bytes_comp, k1_mean) or 0) / HBM_PEAK_GBS if k1_mean == k1_mean else None,
                          "achieved_survey_8d": gbs(bytes_8d, k1_mean), "frac_survey_8d": (gbs(bytes_8d, k1_mean) or 0) / HBM_PEAK_GBS if k1_mean == k1_mean else None,
-                         "basis": "achieved / frac use bytes_compulsory (what this layout must move); frac_survey_8d > 1 means the kernel does not move SURVEY 8d's bytes: sections outside the frustum cost only their %d-byte stream key" % key_bytes,
+                         "basis": ("achieved / frac use bytes_compulsory (what this layout must move) over the mean of launches_timed launches (HIP events on the dispatches: those of the timed region "
+                                   "+ further synchronous frames of the same loop); frac_survey_8d > 1 means the kernel does not move SURVEY 8d's bytes: sections outside the frustum cost only their "
+                                   "%d-byte stream key.  The %d MB key array is re-read every frame and stays resident in the 256 MiB Infinity Cache between frames, so this stream is served by the "
+                                   "Infinity Cache, not by HBM: the fraction of the 8 TB/s HBM peak is a label for the byte rate, not a bound the kernel runs against (gfx950's FETCH_SIZE counts "
+                                   "Infinity-Cache hits too)" % (key_bytes, key_bytes * slots // 1000000)),
+                         "clock_warmup": "%d untimed asynchronous frames in front of the %d warm-up steps" % (CLOCK_WARMUP_FRAMES, a.warmup),
                          "traffic": traffic, "traffic_source": tr_src},
             "setup_s": t_setup, "cpu_affinity": affinity,
         }

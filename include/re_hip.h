@@ -360,6 +360,9 @@ typedef struct {
     uint32_t n_sync_fallbacks;  /* of those, blocks that only agreed after a stream synchronise */
     uint32_t n_section_slots;   /* slots of the resident section table == keys the visibility scan streams per frame (world sections + padding / spare slots) */
     uint32_t n_device_rebuckets; /* re-bucket batches (movers of a tick that changed world section) whose bookkeeping ran on the device; the others took the host path */
+    uint32_t n_segment_redos;    /* frames issued a second time because clustered world sections overflowed one cursor segment of the instance list: the frame is redone
+                                  * with the list as one segment (which holds every instance of the world twice), and the context keeps that layout until the next upload */
+    uint32_t reserved2;
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,

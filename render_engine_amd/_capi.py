@@ -79,7 +79,8 @@ class Stats(C.Structure):
     _fields_ = [("n_entities", C.c_uint32), ("n_dynamic", C.c_uint32), ("n_sections", C.c_uint32),
                 ("n_shared_sections", C.c_uint32), ("max_level", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("n_probe_frames", C.c_uint32), ("n_table_rebuilds", C.c_uint32), ("n_fused_frames", C.c_uint32), ("reserved", C.c_uint32),
-                ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32), ("n_section_slots", C.c_uint32), ("n_device_rebuckets", C.c_uint32)]
+                ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32), ("n_section_slots", C.c_uint32), ("n_device_rebuckets", C.c_uint32),
+                ("n_segment_redos", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class Gathered(C.Structure):

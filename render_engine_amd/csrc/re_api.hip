@@ -13,10 +13,12 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "re_hip.h"
+#include "re_guard.h"
 #include "re_kernels.h"
 #include "re_math.h"
 
@@ -171,6 +173,11 @@ struct re_ctx {
     } park;
     bool park_ready = false, lane_busy = false; uint32_t lane_seq = 0, lane_id = 0, n_lane_switches = 0;   // RE_CULL_DEFER_PACK: the pack of the last frame, waiting for the next launch
     re_tick_result last_tick{};
+    // The instance list is CURSOR_SHARDS segments with one cursor each, and a wave reserves in segment (wave index mod 8): sections that sit in few
+    // waves (one crowded section, a cluster) can fill one segment while the list as a whole has room.  The pack kernels report that
+    // (RESULT_SEGMENT_OVERFLOW); finish_cull then redoes the frame with the list as ONE segment -- which holds every instance of the world twice
+    // (duplicates mode) by construction -- and the context stays in that mode until the next upload.
+    bool single_shard = false; uint32_t n_segment_redos = 0; re_camera last_cam{}; uint32_t last_cull_flags = 0;
     // what the last frame's pack was launched with, so that it can be run again into other output buffers (the second, variable-length round of the
     // multi-GPU exchange when a rank's visible set outgrew its slab)
     struct LastPack { int kind = 0; FrameHeader *hdr = nullptr, *hdr_next = nullptr; PackArgs A{}; ItemSink K{}; uint32_t grid = 0, nrows = 0, par = 0; PackLargeArgs L{}; } last_pack;   // kind: 1 k_pack_small, 2 k_pack_large, 3 count / scan / scatter
@@ -201,7 +208,29 @@ struct re_ctx {
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (ctx)->fail(RE_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
-extern "C" uint32_t re_abi_version(void) { return 2u; }
+// Every host wait on a stream of the context has a deadline: a kernel that never finishes (a wave spinning on a condition no other wave will
+// satisfy, a loop whose stride came out as zero) must surface as RE_E_HIP from the entry point -- "no aborts cross the ABI" also means the caller
+// is not left blocked inside the library until something outside kills the process (the likeliest reading of round 2's unexplained
+// `Fatal Python error: Aborted` inside re_cull_pack: a work-in-progress kernel that hung and an external `timeout` that ended the run with
+// SIGABRT).  RE_SYNC_TIMEOUT_MS overrides the 60 s default; 0 = wait without a deadline.
+static hipError_t sync_stream(hipStream_t st) {
+    static const long limit_ms = [] { const char *e = getenv("RE_SYNC_TIMEOUT_MS"); return e ? atol(e) : 60000L; }();
+    if (limit_ms <= 0) return hipStreamSynchronize(st);
+    hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0;; spins++) {
+        e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if ((spins & 63u) == 63u) {
+            const auto dt = std::chrono::steady_clock::now() - t0;
+            if (dt > std::chrono::milliseconds(limit_ms)) return hipErrorLaunchTimeOut;
+            if (dt > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));   // a long wait (an upload, a rebuild): stop burning the core
+        }
+    }
+}
+
+extern "C" uint32_t re_abi_version(void) { return 3u; }
 
 // RE_EXP_TIME_ISSUE=1: host time of a frame's phases (printed by re_destroy): what the calling thread spends per frame outside the kernels
 namespace {
@@ -232,7 +261,7 @@ template <typename T> static inline T *hb_at(void *base, size_t off) { return re
 
 extern "C" const char *re_last_error(const re_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-extern "C" int re_create(const re_config *cfg, re_ctx **out) {
+extern "C" int re_create(const re_config *cfg, re_ctx **out) try {
     if (!cfg || !out) { g_create_error = "re_create: null argument"; return RE_E_ARG; }
     if (cfg->atomic_length == 0 || cfg->outline_length < cfg->atomic_length) { g_create_error = "re_create: outline_length must be >= atomic_length > 0"; return RE_E_ARG; }
     int ndev = 0;
@@ -249,7 +278,7 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) {
     for (auto &ev : c->ev) (void)hipEventCreate(&ev);
     *out = c;
     return RE_OK;
-}
+} RE_ABI_GUARD_NOCTX(g_create_error, "re_create")
 
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
@@ -271,15 +300,16 @@ static void free_world(re_ctx *c) {
     if (c->h_block) { (void)hipHostFree(c->h_block); c->h_block = nullptr; }      // one block: frame result, speculation word, tick counters, group table
     c->h_res = nullptr; c->h_ranges = nullptr; c->h_th = nullptr; c->h_spec = nullptr;
     c->d_spec.release(nullptr); c->pending.clear();
+    c->single_shard = false;
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false; c->deferred_pack = false;
 }
 
-extern "C" void re_destroy(re_ctx *c) {
+extern "C" void re_destroy(re_ctx *c) try {
     if (!c) return;
     report_issue_clock();
     (void)hipSetDevice(c->device);
     if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)sync_stream(c->stream);
     if (c->comm.comm) comm_release(c);
     free_world(c);
     if (c->h_col) { (void)hipHostFree(c->h_col); c->h_col = nullptr; }        // lives with the collision scratch lists (kept across uploads)
@@ -287,7 +317,7 @@ extern "C" void re_destroy(re_ctx *c) {
     for (auto &ev : c->k1_events) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-}
+} catch (...) {}
 
 static RowArrays row_arrays(re_ctx *c) {
     RowArrays R; R.id = c->d_id.p; R.gclass = c->d_gclass.p; R.flags = c->d_flags.p; R.mat = c->d_mat.p; R.aabb = c->d_aabb.p; R.orig = c->d_orig.p;
@@ -313,7 +343,7 @@ static int upload_row_gc(re_ctx *c, const std::vector<Pair32> &pairs) {
     Pair32 *d = nullptr; HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), pairs.size() * sizeof(Pair32)));
     HIPCHK(c, hipMemcpyAsync(d, pairs.data(), pairs.size() * sizeof(Pair32), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)pairs.size() + 255) / 256), dim3(256), 0, c->stream, (uint32_t)pairs.size(), d, c->d_rows_gc.p);
-    HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(d);
+    HIPCHK(c, sync_stream(c->stream)); (void)hipFree(d);
     return RE_OK;
 }
 
@@ -495,7 +525,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, c->d_cell_key32.alloc(k32.size(), acct)); HIPCHK(c, c->d_chunk_level.alloc(lvl.size(), acct));
         HIPCHK(c, hipMemcpyAsync(c->d_cell_key32.p, k32.data(), k32.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_chunk_level.p, lvl.data(), lvl.size() * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, sync_stream(st));
     }
     HIPCHK(c, hipMemcpyAsync(c->d_cell_begin.p, begin.data(), (size_t)(ncells + 1) * 4, hipMemcpyHostToDevice, st));
     if (ncells) {
@@ -536,7 +566,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, hipMemcpyAsync(c->d_sh_owner.p, owner.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_sh_cached.p, cached.data(), nsh, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_sh_dirty.p, dirty.data(), nsh, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, sync_stream(st));
     }
     // --- end_of_changes: tight AABBs.  total_world_aabb_combining of a fresh batch == number of unique adds (:710-744)
     int too_many = carry ? (int)carry->too_many : (int)(recs.size() > 500);
@@ -553,7 +583,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     if (nsh) hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
     if (nsh && carry) {                                                     // unchanged shared sections keep their AABB
         std::vector<Aabb> sa(nsh);
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, sync_stream(st));
         HIPCHK(c, hipMemcpy(sa.data(), c->d_sh_aabb.p, (size_t)nsh * sizeof(Aabb), hipMemcpyDeviceToHost));
         for (uint32_t s2 = 0; s2 < nsh; s2++) {
             if (carry->changed_shared_set.count(shids[s2])) continue;
@@ -563,16 +593,16 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         HIPCHK(c, hipMemcpy(c->d_sh_aabb.p, sa.data(), (size_t)nsh * sizeof(Aabb), hipMemcpyHostToDevice));
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, sync_stream(st));
     c->nlists = std::max(1u, (uint32_t)((ncells + wave_keys - 1) / wave_keys));       // waves of k_scan_cull
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, sync_stream(st));
     d_refold.release(nullptr); d_carried.release(nullptr);
     if (c->cfg.flags & RE_CFG_PROBE) {                                      // key -> slot table at load <= 0.5 (tombstones of later patches included until the next full build)
         uint32_t sz = 1024; while (sz < 2u * (uint32_t)std::min<size_t>(ncells + 1u, 1u << 30)) sz <<= 1;
         if (c->htab_mask + 1u != sz) { c->d_htab.release(acct); HIPCHK(c, c->d_htab.alloc(sz, acct)); c->htab_mask = sz - 1u; }
         HIPCHK(c, hipMemsetAsync(c->d_htab.p, 0xFF, (size_t)sz * sizeof(HashEntry), st));
         if (ncells) hipLaunchKernelGGL(k_hash_build, dim3((ncells + 255) / 256), dim3(256), 0, st, ncells, c->d_cell_key.p, c->d_htab.p, c->htab_mask);
-        HIPCHK(c, hipGetLastError()); HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, hipGetLastError()); HIPCHK(c, sync_stream(st));
         c->htab_keys = (uint32_t)keys.size();
     }
     if (!carry) { c->dirty_pending = true; c->have_cull = false; }
@@ -600,12 +630,12 @@ static int upload_lod_tables(re_ctx *c) {
     return RE_OK;
 }
 
-extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_rejected) {
+extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_rejected) try {
     if (!c) return RE_E_ARG;
     if (!E || (E->n && (!E->entity_id || !E->model_index || !E->flags || !E->original_aabb || !E->position))) return c->fail(RE_E_ARG, "re_upload_entities: missing required array");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     free_world(c);
     const uint32_t n = E->n;
     c->n = n;
@@ -742,7 +772,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
         HIPCHK(c, hipMemcpyAsync(row_nk.data(), c->d_row_nk.p, (size_t)n, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(c, hipMemcpyAsync(&nshrec, c->d_counter.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, sync_stream(st));
     std::vector<SharedRec> shrec(nshrec);
     if (nshrec) HIPCHK(c, hipMemcpy(shrec.data(), c->d_shrec.p, (size_t)nshrec * sizeof(SharedRec), hipMemcpyDeviceToHost));
     uint32_t rejected = 0;
@@ -777,14 +807,14 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     HIPCHK(c, c->d_spec.alloc(1, nullptr)); HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
     HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     c->frame = 0; c->lane_seq = 0; c->th_clean = true; c->pred_total = 0;
     return upload_lod_tables(c);
-}
+} RE_ABI_GUARD(c, "re_upload_entities")
 
 // level_views.custom (flows/render_flow.rs:495-499, 889-893; registered by register_model_with_render_system :1069-1076): a model with custom_level_of_view
 // uses its own bands instead of the render system's default ones.  n == 0 removes a model's bands.
-extern "C" int re_set_model_lod(re_ctx *c, uint32_t model_index, uint32_t render_system, uint32_t n_lod, const float *lod_min, const float *lod_max) {
+extern "C" int re_set_model_lod(re_ctx *c, uint32_t model_index, uint32_t render_system, uint32_t n_lod, const float *lod_min, const float *lod_max) try {
     if (!c || (n_lod && (!lod_min || !lod_max))) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->h_res) { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
@@ -796,7 +826,7 @@ extern "C" int re_set_model_lod(re_ctx *c, uint32_t model_index, uint32_t render
         for (uint32_t k = 0; k < 8; k++) { it->lmin[k] = k < it->n ? lod_min[k] : 0.f; it->lmax[k] = k < it->n ? lod_max[k] : 0.f; }
     }
     return c->h_res ? upload_lod_tables(c) : RE_OK;
-}
+} RE_ABI_GUARD(c, "re_set_model_lod")
 
 // ------------------------------------------------------------------------------------------------
 // frame parameters: RenderFrustumCuller::new(P*V), LogicFrustumCuller::new(wsl, pos) and the two
@@ -934,7 +964,7 @@ static FrameHeader *frame_header(re_ctx *c, uint32_t frame) { return c->d_hdr.p 
 static ItemSink item_sink(re_ctx *c, uint32_t frame) {
     const size_t half = (size_t)(frame & 1u) * c->item_cap;
     ItemSink K; K.item_row = c->d_item_row.p + half; K.item_slot = c->d_item_slot.p + half; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
-    K.nshards = CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0;
+    K.nshards = c->single_shard ? 1u : CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0;
     K.gc_lodtab = c->lod_tables_on ? c->d_gc_lodtab.p : nullptr; K.lod_n = c->d_lod_n.p; K.lod_min = c->d_lod_min.p; K.lod_max = c->d_lod_max.p;
     return K;
 }
@@ -958,8 +988,8 @@ static void take_timing_events(re_ctx *c, hipEvent_t *a, hipEvent_t *b) {
 }
 
 static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next, bool counted_by_scan = false) {
-    const uint32_t nshards = CURSOR_SHARDS, seg_cap = c->item_cap / nshards;
     const ItemSink KS = item_sink(c, c->lane_seq);
+    const uint32_t nshards = KS.nshards, seg_cap = KS.seg_cap;
     hipStream_t st = c->stream;
     uint32_t *out_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; float *out_mats = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     uint32_t out_cap = c->ext_out_ids ? c->ext_out_cap : c->out_cap;
@@ -979,7 +1009,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
         // workgroup b takes tiles b >> 3, (b >> 3) + grid / 8, ... of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length
         // (+25 %; a longer shard makes its workgroups loop, any grid that is a multiple of 8 is correct)
         const uint32_t per_shard = (c->pred_total + c->pred_total / 4u) / nshards + PACK_LARGE_TILE;
-        const uint32_t grid = nshards * std::min(2048u, std::max(4u, (per_shard + PACK_LARGE_TILE - 1u) / PACK_LARGE_TILE));
+        const uint32_t grid = CURSOR_SHARDS * std::min(2048u, std::max(4u, (per_shard + PACK_LARGE_TILE - 1u) / PACK_LARGE_TILE));   // (always a multiple of 8: workgroup b serves segment b & 7, also when only segment 0 exists)
         hipEvent_t ta = nullptr, tb = nullptr;
         if (c->k1_timing && c->k1_kind == RE_TIME_PACK_LARGE) take_timing_events(c, &ta, &tb);
         hipExtLaunchKernelGGL(k_pack_large, dim3(grid), dim3(PACK_LARGE_THREADS), 0, st, ta, tb, 0, A);
@@ -995,7 +1025,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
     // and a handful of hot (model, LOD) groups saturate near 88 atomics/us per address
     hipLaunchKernelGGL(k_emit_count, dim3(std::min(grid, 256u)), dim3(256), lds, st, hdr, KS.item_slot, nshards, seg_cap, c->d_group_count.p, c->nslots, c->d_spec.p);
     hipLaunchKernelGGL(k_group_scan, dim3(1), dim3(1024), 0, st, c->d_group_count.p, c->d_group_begin.p, c->d_group_fill.p, c->nslots, c->d_gc_model.p, c->d_gc_rs.p, c->d_gc_sort.p,
-                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p, c->ext_out_count, c->ext_out_ids ? c->ext_out_cap : c->out_cap, c->frame);
+                       c->d_hranges, c->nslots, hdr, hdr_next, c->d_th.p, c->d_hres, c->d_spec.p, c->ext_out_count, c->ext_out_ids ? c->ext_out_cap : c->out_cap, c->frame, seg_cap);
     hipLaunchKernelGGL(k_emit_scatter, dim3(grid), dim3(256), lds, st, hdr, KS.item_row, KS.item_slot, nshards, seg_cap, c->d_group_begin.p, c->d_group_fill.p, c->nslots,
                        c->d_id.p, c->d_mat.p, out_ids, out_mats, out_cap, c->d_spec.p);
     HIPCHK(c, hipGetLastError());
@@ -1003,6 +1033,7 @@ static int launch_pack_large(re_ctx *c, FrameHeader *hdr, FrameHeader *hdr_next,
     return RE_OK;
 }
 
+static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags);
 static int finish_cull(re_ctx *c, re_visible *out) {
     { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
@@ -1026,7 +1057,22 @@ static int finish_cull(re_ctx *c, re_visible *out) {
         // k_pack_small declined (visible set larger than predicted): run the multi-kernel pack on this frame's entries
         int rc = launch_pack_large(c, frame_header(c, c->lane_seq), frame_header(c, c->lane_seq + 2u));
         if (rc != RE_OK) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c->stream));
+    }
+    if (c->h_res->overflow == RESULT_SEGMENT_OVERFLOW) {
+        // A cursor segment of the instance list overflowed: nothing was packed.  Redo the frame with the list as one segment (see re_ctx::single_shard).
+        if (c->single_shard) return c->fail(RE_E_CAPACITY, "instance list overflow (%u instances reserved, list capacity %u)", c->h_res->n_items, c->item_cap);
+        c->single_shard = true; c->n_segment_redos++;
+        HIPCHK(c, hipMemsetAsync(c->d_hdr.p, 0, NUM_FRAME_HEADERS * sizeof(FrameHeader), c->stream)); c->th_clean = false;
+        if (c->d_gcount.p) {
+            HIPCHK(c, hipMemsetAsync(c->d_gcount.p, 0, c->d_gcount.n * 4, c->stream)); HIPCHK(c, hipMemsetAsync(c->d_gfill.p, 0, c->d_gfill.n * 4, c->stream));
+            c->gc_dirty[0] = c->gc_dirty[1] = false;
+        }
+        c->pending.clear();
+        const re_camera cam = c->last_cam;
+        int rc = issue_cull(c, &cam, c->last_cull_flags & ~(RE_CULL_ASYNC | RE_CULL_DEFER_PACK | RE_CULL_TWO_LANES));
+        if (rc != RE_OK) return rc;
+        return finish_cull(c, out);
     }
     c->timings_pending = c->timed_frame;                                      // the events are read in re_get_timings (they may still be in flight here)
     c->pred_total = c->h_res->total; c->pred_candidates = c->h_res->n_candidates;
@@ -1049,7 +1095,7 @@ static int finish_cull(re_ctx *c, re_visible *out) {
             const auto t0 = std::chrono::steady_clock::now();
             bool ok = false;
             while (!(ok = table_ok()) && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {}
-            if (!ok) { c->n_sync_fallbacks++; HIPCHK(c, hipStreamSynchronize(c->stream)); std::atomic_thread_fence(std::memory_order_acquire); ok = table_ok(); }
+            if (!ok) { c->n_sync_fallbacks++; HIPCHK(c, sync_stream(c->stream)); std::atomic_thread_fence(std::memory_order_acquire); ok = table_ok(); }
             if (!ok) return c->fail(RE_E_STATE, "group table inconsistent with its seal (frame %u, %u groups, %u instances)", c->frame, c->h_res->n_groups, c->h_res->total);
         }
         if (c->h_res->n_items > c->h_res->total + c->n_dead + (uint32_t)c->h_uncached.size() + 2u * c->n_phantom) return c->fail(RE_E_CAPACITY, "instance-list segment overflow (%u reserved, %u packed)", c->h_res->n_items, c->h_res->total);
@@ -1095,7 +1141,7 @@ static int ensure_second_lane(re_ctx *c) {
 static void free_second_lane(re_ctx *c) {
     if (c->lane_id) switch_lane(c);                                          // lane 0 is the one the rest of the context owns
     re_ctx::LanePark &k = c->park; uint64_t *acct = &c->dev_bytes;
-    if (k.stream) { (void)hipStreamSynchronize(k.stream); (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
+    if (k.stream) { (void)sync_stream(k.stream); (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
     k.d_hdr.release(acct); k.d_item_row.release(acct); k.d_item_slot.release(acct); k.d_out_ids.release(acct); k.d_out_mats.release(acct); k.d_cell_stamp.release(acct); k.d_params.release(acct);
     if (k.h_block) { (void)hipHostFree(k.h_block); k.h_block = nullptr; }
     k.h_res = nullptr; k.d_hres = nullptr; k.h_ranges = nullptr; k.d_hranges = nullptr;
@@ -1109,7 +1155,7 @@ static int drain_other_lane(re_ctx *c) {
     if (!c->park_ready || !(c->park.busy || c->park.deferred_pack)) return RE_OK;
     switch_lane(c);
     int rc = flush_deferred_pack(c);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = sync_stream(c->stream);
     c->lane_busy = false;
     switch_lane(c);
     if (rc != RE_OK) return rc;
@@ -1130,6 +1176,7 @@ static int flush_deferred_pack(re_ctx *c) {
 
 static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     hipStream_t st = c->stream;
+    c->last_cam = *cam; c->last_cull_flags = flags;
     IssueClock &IC = g_issue_clock; double t_ic = IC.on ? IssueClock::now() : 0.0;
     auto lap = [&](double &acc) { if (IC.on) { const double t = IssueClock::now(); acc += t - t_ic; t_ic = t; } };
     if (c->cull_inflight && c->h_res->overflow == 0) { c->pred_total = std::max(c->pred_total, c->h_res->total); c->pred_candidates = std::max(c->pred_candidates, c->h_res->n_candidates); }   // hint from an earlier async frame, if it has landed
@@ -1232,7 +1279,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         // workgroup b packs 64 instances of cursor shard b & 7: enough rounds of 8 workgroups for the predicted shard length (+50 %),
         // and never fewer than cover 16 K instances spread evenly would need is not required -- a shard longer than the grid covers
         // makes the pack decline (overflow) and the frame is redone through the large path
-        uint32_t per_shard = (c->pred_total + c->pred_total / 2u) / CURSOR_SHARDS + 64u;
+        uint32_t per_shard = (c->pred_total + c->pred_total / 2u) / (c->single_shard ? 1u : CURSOR_SHARDS) + 64u;
         uint32_t pgrid = CURSOR_SHARDS * std::min(32u, (per_shard + 63u) / 64u);
         // RE_CULL_DEFER_PACK: in a world without dynamic entities nothing changes what the pack reads before the next visibility query,
         // so an asynchronous frame may leave its pack to the launch of the next one (k_scan_cull_fused)
@@ -1256,7 +1303,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
 }
 
 static int resolve(re_ctx *c);
-extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_visible *out) {
+extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_visible *out) try {
     if (!c) return RE_E_ARG;
     if (!cam) return c->fail(RE_E_ARG, "re_cull_pack: camera is NULL");
     if (!c->h_res) return c->fail(RE_E_STATE, "re_cull_pack: no world uploaded");
@@ -1282,7 +1329,7 @@ extern "C" int re_cull_pack(re_ctx *c, const re_camera *cam, uint32_t flags, re_
     int rc = issue_cull(c, cam, flags);
     if (rc != RE_OK || (flags & RE_CULL_ASYNC)) return rc;
     return finish_cull(c, out);
-}
+} RE_ABI_GUARD(c, "re_cull_pack")
 
 // slot of a world section in the resident table, -1 when it does not exist (base = last full build, overlay = created since)
 static int32_t find_slot(const re_ctx *c, uint64_t key) {
@@ -1484,7 +1531,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         HIPCHK(c, hipMemcpyAsync(old_aabb.data(), c->d_sh_aabb.p, (size_t)old_nsh * sizeof(Aabb), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(old_owner.data(), c->d_sh_owner.p, (size_t)old_nsh * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(old_cached.data(), c->d_sh_cached.p, old_nsh, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, sync_stream(st));
     }
     std::map<SharedIdPub, uint32_t> old_index; for (uint32_t s2 = 0; s2 < old_nsh; s2++) old_index.emplace(c->h_shids[s2], s2);
     std::vector<int32_t> owner(nsh, -1); std::vector<uint8_t> cached(nsh, 0), dirty(nsh, 0);
@@ -1533,7 +1580,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         if (!refold.empty()) hipLaunchKernelGGL(k_fold_tight_list, dim3(((uint32_t)refold.size() + 255) / 256), dim3(256), 0, st, (uint32_t)refold.size(), reinterpret_cast<const uint32_t *>(c->d_stage.p + o_rf), c->d_cell_key.p,
                                                 c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p, c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, carry.too_many ? 1 : 0);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(st));                                 // `host` goes out of scope
+        HIPCHK(c, sync_stream(st));                                 // `host` goes out of scope
     }
     lap("G upload");
     if (nsh || old_nsh) {
@@ -1555,7 +1602,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         hipLaunchKernelGGL(k_fold_shared, dim3((nsh + 255) / 256), dim3(256), 0, st, nsh, c->d_sh_begin.p, c->d_sh_nact.p, c->d_sh_nstat.p, c->d_rows.p, c->d_aabb.p, c->d_sh_aabb.p);
         std::vector<Aabb> sa(nsh);
         HIPCHK(c, hipMemcpyAsync(sa.data(), c->d_sh_aabb.p, (size_t)nsh * sizeof(Aabb), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, sync_stream(st));
         for (uint32_t s2 = 0; s2 < nsh; s2++) {
             if (carry.changed_shared_set.count(shids[s2])) continue;
             auto it = old_index.find(shids[s2]);
@@ -1564,7 +1611,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         HIPCHK(c, hipMemcpy(c->d_sh_aabb.p, sa.data(), (size_t)nsh * sizeof(Aabb), hipMemcpyHostToDevice));
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, sync_stream(st));
     for (auto &f : freed) c->free_slots[f.first].push_back(f.second);
     c->nsh = nsh; c->h_shids = shids; sh_nact.resize(nsh); sh_nstat.resize(nsh); c->h_sh_nact = sh_nact; c->h_sh_nstat = sh_nstat; sh_begin.resize(nsh); c->h_sh_begin = sh_begin;
     c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + n_real_delta);
@@ -1603,7 +1650,7 @@ static int sync_mirrors(re_ctx *c) {
     if (hipMemcpyAsync(d_slots.p, c->stale_slots.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: copy"));
     hipLaunchKernelGGL(k_rb_gather_cells, dim3((n + 255) / 256), dim3(256), 0, st, n, d_slots.p, rb_cells(c), d_keys.p, d_hdr.p);
     (void)hipMemcpyAsync(keys.data(), d_keys.p, (size_t)n * 8, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(hdr.data(), d_hdr.p, (size_t)n * 16, hipMemcpyDeviceToHost, st);
-    if (hipStreamSynchronize(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: section headers"));
+    if (sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: section headers"));
     for (uint32_t i = 0; i < n; i++) offs[i + 1] = offs[i] + hdr[(size_t)i * 4 + 2] + hdr[(size_t)i * 4 + 3];
     std::vector<uint32_t> rows(std::max<uint32_t>(offs[n], 1u));
     if (offs[n]) {
@@ -1611,7 +1658,7 @@ static int sync_mirrors(re_ctx *c) {
         (void)hipMemcpyAsync(d_offs.p, offs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st);
         hipLaunchKernelGGL(k_rb_gather_rows, dim3((n + 255) / 256), dim3(256), 0, st, n, d_slots.p, d_offs.p, rb_cells(c), d_rows.p);
         (void)hipMemcpyAsync(rows.data(), d_rows.p, (size_t)offs[n] * 4, hipMemcpyDeviceToHost, st);
-        if (hipStreamSynchronize(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: section rows"));
+        if (sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: section rows"));
     }
     auto is_pad = [](uint64_t k) { return (k & 0xFFFFFFFFFFFFull) == 0xFFFFFFFFFFFFull; };
     for (uint32_t i = 0; i < n; i++) {
@@ -1662,7 +1709,7 @@ static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host
             if (c->d_stage.n < pr.size() * sizeof(Pair64)) HIPCHK(c, c->d_stage.alloc(pr.size() * sizeof(Pair64) * 2, nullptr));
             HIPCHK(c, hipMemcpyAsync(c->d_stage.p, pr.data(), pr.size() * sizeof(Pair64), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k_rb_ovl_insert, dim3(((uint32_t)pr.size() + 255) / 256), dim3(256), 0, st, (uint32_t)pr.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p), rb_tables(c));
-            HIPCHK(c, hipStreamSynchronize(st));                                // `pr` goes out of scope
+            HIPCHK(c, sync_stream(st));                                // `pr` goes out of scope
         }
         c->ovl_count = (uint32_t)c->extra_slots.size(); c->rb_ovl_dirty = false;
     }
@@ -1694,7 +1741,7 @@ static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host
     hipLaunchKernelGGL(k_rb_segments, dim3((nops + 255) / 256), dim3(256), 0, st, nops, c->d_rb_perm.p, c->d_rb_ksorted.p, c->d_rb_row.p, T, C, c->d_rb_segs.p, c->d_rb_status.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(&hs, c->d_rb_status.p, sizeof hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, sync_stream(st));
     lap("phase 1");
     if (hs.fallback) return 1;
     // Movers the host path keeps (hs.n_host): it takes them as a second batch behind this one.  The two batches count total_world_aabb_combining
@@ -1722,7 +1769,7 @@ static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host
     std::vector<RbSeg> segs(nseg); RbStatus h2{};
     HIPCHK(c, hipMemcpyAsync(&h2, c->d_rb_status.p, sizeof h2, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(segs.data(), c->d_rb_segs.p, (size_t)nseg * sizeof(RbSeg), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, sync_stream(st));
     lap("phase 2");
     // ---- what the host keeps in step at once: free slots, pool fill, section count; everything else waits for sync_mirrors
     for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
@@ -1787,7 +1834,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     }
     Carry carry;
     if (ghost_touched) carry.ghost_touched = *ghost_touched;
-    if (M) HIPCHK(c, hipStreamSynchronize(st));
+    if (M) HIPCHK(c, sync_stream(st));
     lap("assign");
     d_list.release(nullptr); d_nk.release(nullptr); d_keys.release(nullptr);
     const uint32_t os = c->nsh;
@@ -2001,7 +2048,7 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
     return RE_OK;
 }
 
-extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out) {
+extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out) try {
     if (!c) return RE_E_ARG;
     if (!c->h_res) return c->fail(RE_E_STATE, "re_tick: no world uploaded");
     if (!(flags & RE_TICK_ALL_DYNAMIC) && !c->have_cull) return c->fail(RE_E_STATE, "re_tick: reference semantics tick entities of the last visibility query; call re_cull_pack first or pass RE_TICK_ALL_DYNAMIC");
@@ -2013,14 +2060,14 @@ extern "C" int re_tick(re_ctx *c, float dt, uint32_t flags, re_tick_result *out)
     int rc = issue_tick(c, dt, flags);
     if (rc != RE_OK || (flags & RE_TICK_ASYNC)) return rc;
     return finish_tick(c, out);
-}
+} RE_ABI_GUARD(c, "re_tick")
 
 // Synchronise and settle speculation: when a tick raised `stale` (entities changed section or left the world), everything enqueued
 // after it has cancelled itself; patch the tree from that tick's lists, then replay the cancelled calls (which may go stale again).
 // the counters of the last tick that ran, copied from the device (stream-ordered); k_tick counts n_changed in shards
 static int fetch_tick_counters(re_ctx *c) {
     TickHeader t;
-    HIPCHK(c, hipMemcpyAsync(&t, c->d_th.p, sizeof t, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&t, c->d_th.p, sizeof t, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, sync_stream(c->stream));
     for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) t.n_changed += t.shard[k * TICK_SHARD_STRIDE];
     c->h_th->n_changed = t.n_changed; c->h_th->n_rebucket = t.n_rebucket; c->h_th->n_oob = t.n_oob;
     return RE_OK;
@@ -2028,7 +2075,7 @@ static int fetch_tick_counters(re_ctx *c) {
 static int resolve(re_ctx *c) {
     { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     if (c->tick_inflight && c->ndyn && c->h_th) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }   // (stream-ordered copy)   // n_changed, n_rebucket, n_oob of the last tick that ran
     while (c->h_spec && c->h_spec->stale) {
         const uint32_t sf = c->h_spec->stale_frame;
@@ -2056,7 +2103,7 @@ static int resolve(re_ctx *c) {
             }
             c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c->stream));
         if (c->ndyn) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }
     }
     c->pending.clear();
@@ -2071,7 +2118,7 @@ static int resolve(re_ctx *c) {
 // AABBs / section decisions run on the GPU (k_write_components, k_apply_rows = the tail of the tick kernel), and the tree is
 // patched by the same re-bucket as after a tick.
 // ------------------------------------------------------------------------------------------------
-extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out) {
+extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out) try {
     if (!c) return RE_E_ARG;
     if (!c->h_res) return c->fail(RE_E_STATE, "re_apply_changes: no world uploaded");
     if (n && !changes) return c->fail(RE_E_ARG, "re_apply_changes: changes is NULL");
@@ -2198,7 +2245,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
         Pair32 *d = nullptr; HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), cl.size() * sizeof(Pair32)));
         HIPCHK(c, hipMemcpyAsync(d, cl.data(), cl.size() * sizeof(Pair32), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_clone_rows, dim3(((uint32_t)cl.size() * 4u + 255) / 256), dim3(256), 0, st, (uint32_t)cl.size(), d, c->d_id.p, c->d_mat.p);   // before any component write of this batch
-        HIPCHK(c, hipStreamSynchronize(st)); (void)hipFree(d);
+        HIPCHK(c, sync_stream(st)); (void)hipFree(d);
     }
     if (new_rotvel) c->has_rotvel = true;
     for (auto &kv : flag_ops) c->h_flags[kv.first] = (c->h_flags[kv.first] & (kv.second.first | F_STATIC)) | (kv.second.second & ~F_STATIC);   // the static bit follows the tree replay
@@ -2234,7 +2281,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
         }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&th, c->d_th.p, sizeof th, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, sync_stream(st));
         d_ops.release(nullptr); d_list.release(nullptr);
         c->th_clean = false;
     }
@@ -2277,14 +2324,14 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     }
     if (out) *out = c->last_tick;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_apply_changes")
 
 // ------------------------------------------------------------------------------------------------
 // re_collide == LogicFlow::handle_collisions (flows/logic_flow.rs:452-651): the broad phase and the AABB tests; the collision
 // logic of the entity types (CollisionFunction callbacks) stays with the caller, which gets the argument pairs.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t COL_REGION_CAP = 1u << 16, COL_SHARED_CAP = 1u << 14;
-extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32_t capacity, uint32_t *n_total) {
+extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32_t capacity, uint32_t *n_total) try {
     (void)flags;
     if (!c) return RE_E_ARG;
     if (!c->h_res) return c->fail(RE_E_STATE, "re_collide: no world uploaded");
@@ -2335,14 +2382,14 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
         const auto t0 = std::chrono::steady_clock::now(); bool done = false;
         for (uint32_t spins = 0; !(done = (*flag == c->col_calls)); spins++)
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
-        if (!done) HIPCHK(c, hipStreamSynchronize(st));
+        if (!done) HIPCHK(c, sync_stream(st));
         std::atomic_thread_fence(std::memory_order_acquire);
         auto sealed = [&]() { const volatile ColHeader *q = c->h_col; return q->pad[0] == (table_word_hash(q->n_region, 1u) ^ table_word_hash(q->n_high, 2u) ^ table_word_hash(q->n_shared, 3u) ^ table_word_hash(q->n_moved, 4u) ^ table_word_hash(q->n_pairs, 5u) ^ table_word_hash(q->n_near, 6u) ^ table_word_hash(c->col_calls, 7u)); };
         if (!sealed()) {                                                      // (as in finish_cull: counted, asserted to be 0 by the tests)
             c->n_seal_waits++;
             const auto t1 = std::chrono::steady_clock::now();
             while (!sealed() && std::chrono::steady_clock::now() - t1 < std::chrono::microseconds(500)) {}
-            if (!sealed()) { c->n_sync_fallbacks++; HIPCHK(c, hipStreamSynchronize(st)); std::atomic_thread_fence(std::memory_order_acquire); }
+            if (!sealed()) { c->n_sync_fallbacks++; HIPCHK(c, sync_stream(st)); std::atomic_thread_fence(std::memory_order_acquire); }
         }
         h = *c->h_col;
     }
@@ -2356,7 +2403,7 @@ extern "C" int re_collide(re_ctx *c, uint32_t flags, re_collision *pairs, uint32
     if (nw) HIPCHK(c, hipMemcpy(pairs, c->d_col_pairs.p, (size_t)nw * sizeof(re_collision), hipMemcpyDeviceToHost));
     if (n_total) *n_total = h.n_pairs;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_collide")
 
 // ------------------------------------------------------------------------------------------------
 // Multi-GPU exchange behind the C ABI (BASELINE configs[3]): one process per GPU, sections sharded by contiguous key range, and
@@ -2418,7 +2465,7 @@ static int comm_setup(re_ctx *c, void *comm, bool owned, int rank, int n_ranks, 
     m.h_hdr.assign((size_t)n_ranks * 4, 0u); m.counts.assign(n_ranks, 0u); m.seq = 0; m.last = -1; m.pending = -1;
     return RE_OK;
 }
-extern "C" int re_comm_unique_id(uint8_t *id) {
+extern "C" int re_comm_unique_id(uint8_t *id) try {
     if (!id) return RE_E_ARG;
     if (!rccl::load()) { g_create_error = rccl::load_error; return RE_E_UNSUPPORTED; }
     rccl::ncclUniqueId u; memset(&u, 0, sizeof u);
@@ -2426,8 +2473,8 @@ extern "C" int re_comm_unique_id(uint8_t *id) {
     if (r != 0) { g_create_error = std::string("ncclGetUniqueId: ") + rccl::GetErrorString(r); return RE_E_HIP; }
     memcpy(id, u.internal, RE_COMM_ID_BYTES);
     return RE_OK;
-}
-extern "C" int re_comm_init(re_ctx *c, const uint8_t *id, int rank, int n_ranks, uint32_t slab_instances) {
+} RE_ABI_GUARD_NOCTX(g_create_error, "re_comm_unique_id")
+extern "C" int re_comm_init(re_ctx *c, const uint8_t *id, int rank, int n_ranks, uint32_t slab_instances) try {
     if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? c->fail(RE_E_ARG, "re_comm_init: bad arguments") : RE_E_ARG;
     if (!rccl::load()) return c->fail(RE_E_UNSUPPORTED, "%s", rccl::load_error.c_str());
     HIPCHK(c, hipSetDevice(c->device));
@@ -2436,21 +2483,21 @@ extern "C" int re_comm_init(re_ctx *c, const uint8_t *id, int rank, int n_ranks,
     rccl::ncclComm_t comm = nullptr;
     NCCLCHK(c, rccl::CommInitRank(&comm, n_ranks, u, rank));
     return comm_setup(c, comm, true, rank, n_ranks, slab_instances);
-}
-extern "C" int re_comm_adopt(re_ctx *c, void *nccl_comm, int rank, int n_ranks, uint32_t slab_instances) {
+} RE_ABI_GUARD(c, "re_comm_init")
+extern "C" int re_comm_adopt(re_ctx *c, void *nccl_comm, int rank, int n_ranks, uint32_t slab_instances) try {
     if (!c || !nccl_comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return c ? c->fail(RE_E_ARG, "re_comm_adopt: bad arguments") : RE_E_ARG;
     if (!rccl::load()) return c->fail(RE_E_UNSUPPORTED, "%s", rccl::load_error.c_str());
     HIPCHK(c, hipSetDevice(c->device));
     if (c->comm.comm) comm_release(c);
     return comm_setup(c, nccl_comm, false, rank, n_ranks, slab_instances);
-}
-extern "C" int re_comm_destroy(re_ctx *c) {
+} RE_ABI_GUARD(c, "re_comm_adopt")
+extern "C" int re_comm_destroy(re_ctx *c) try {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->stream) HIPCHK(c, sync_stream(c->stream));
     comm_release(c);
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_comm_destroy")
 
 // The last frame's pack once more, into other output buffers (everything it reads -- instance list, cursors, group counts -- is still there until the
 // next visibility query): the second round of the exchange needs a rank's FULL packed set, not the slab's truncated prefix.
@@ -2486,7 +2533,7 @@ static int gather_finish(re_ctx *c, re_gathered *out) {
     if (b < 0) return c->fail(RE_E_STATE, "re_allgather_visible: no frame has been packed since re_comm_init");
     m.pending = -1;
     auto read_headers = [&]() -> int {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_stream(c->stream));
         for (int r = 0; r < m.n; r++) HIPCHK(c, hipMemcpy(&m.h_hdr[(size_t)r * 4], m.recv[b].p + (size_t)r * m.words, 16, hipMemcpyDeviceToHost));
         return RE_OK;
     };
@@ -2524,12 +2571,12 @@ static int gather_finish(re_ctx *c, re_gathered *out) {
     }
     NCCLCHK(c, rccl::AllGather(c->d_out_ids.p, m.big_ids.p, max_total, rccl::Uint32, reinterpret_cast<rccl::ncclComm_t>(m.comm), c->stream));
     NCCLCHK(c, rccl::AllGather(c->d_out_mats.p, m.big_mats.p, (size_t)max_total * 16, rccl::Float32, reinterpret_cast<rccl::ncclComm_t>(m.comm), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     m.n_second_rounds++;
     if (out) { out->d_entity_ids = m.big_ids.p; out->ids_rank_stride = max_total; out->d_matrices = m.big_mats.p; out->matrices_rank_stride = max_total * 16u; }
     return RE_OK;
 }
-extern "C" int re_allgather_visible(re_ctx *c, uint32_t flags, re_gathered *out) {
+extern "C" int re_allgather_visible(re_ctx *c, uint32_t flags, re_gathered *out) try {
     if (!c) return RE_E_ARG;
     if (!c->comm.comm) return c->fail(RE_E_STATE, "re_allgather_visible: no communicator (re_comm_init / re_comm_adopt)");
     if (c->comm.last < 0) return c->fail(RE_E_STATE, "re_allgather_visible: call re_cull_pack first");
@@ -2541,15 +2588,15 @@ extern "C" int re_allgather_visible(re_ctx *c, uint32_t flags, re_gathered *out)
     c->comm.pending = c->comm.last;
     if (flags & RE_GATHER_ASYNC) return RE_OK;
     return gather_finish(c, out);
-}
-extern "C" int re_gather_wait(re_ctx *c, re_gathered *out) {
+} RE_ABI_GUARD(c, "re_allgather_visible")
+extern "C" int re_gather_wait(re_ctx *c, re_gathered *out) try {
     if (!c) return RE_E_ARG;
     if (!c->comm.comm) return c->fail(RE_E_STATE, "re_gather_wait: no communicator");
     HIPCHK(c, hipSetDevice(c->device));
     return gather_finish(c, out);
-}
+} RE_ABI_GUARD(c, "re_gather_wait")
 
-extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_tick) {
+extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_tick) try {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int rc = RE_OK;
@@ -2557,11 +2604,11 @@ extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_t
     if (rc != RE_OK) return rc;
     if (c->tick_inflight) rc = finish_tick(c, out_tick); else if (out_tick) *out_tick = c->last_tick;
     return rc;
-}
+} RE_ABI_GUARD(c, "re_wait")
 
 // The frame loop of the reference (threads/render_thread.rs:217-250 -> Pipeline::execute, flows/pipeline.rs:212-276) driven from native code,
 // for measurement without an interpreter between the calls: exactly the two public entry points, n times.
-extern "C" int re_run_frames(re_ctx *c, const re_camera *cam, float dt, uint32_t cull_flags, uint32_t tick_flags, uint32_t n, float *wall_us, re_visible *last_visible, re_tick_result *last_tick) {
+extern "C" int re_run_frames(re_ctx *c, const re_camera *cam, float dt, uint32_t cull_flags, uint32_t tick_flags, uint32_t n, float *wall_us, re_visible *last_visible, re_tick_result *last_tick) try {
     if (!c) return RE_E_ARG;
     if (!cam) return c->fail(RE_E_ARG, "re_run_frames: camera is NULL");
     re_visible vis{}; re_tick_result tr{};
@@ -2575,9 +2622,9 @@ extern "C" int re_run_frames(re_ctx *c, const re_camera *cam, float dt, uint32_t
     if (last_visible && !(cull_flags & RE_CULL_ASYNC)) *last_visible = vis;
     if (last_tick && !(tick_flags & RE_TICK_ASYNC)) *last_tick = tr;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_run_frames")
 
-extern "C" int re_copy_visible(re_ctx *c, uint32_t *ids_host, float *mats_host, uint32_t capacity, uint32_t *n_written) {
+extern "C" int re_copy_visible(re_ctx *c, uint32_t *ids_host, float *mats_host, uint32_t capacity, uint32_t *n_written) try {
     if (!c || !c->h_res) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->cull_inflight) { int rc = finish_cull(c, nullptr); if (rc) return rc; }
@@ -2586,25 +2633,25 @@ extern "C" int re_copy_visible(re_ctx *c, uint32_t *ids_host, float *mats_host, 
     const uint32_t *src_ids = c->ext_out_ids ? c->ext_out_ids : c->d_out_ids.p; const float *src_m = c->ext_out_mats ? c->ext_out_mats : c->d_out_mats.p;
     if (nw && ids_host) HIPCHK(c, hipMemcpyAsync(ids_host, src_ids, (size_t)nw * 4, hipMemcpyDeviceToHost, c->stream));
     if (nw && mats_host) HIPCHK(c, hipMemcpyAsync(mats_host, src_m, (size_t)nw * 64, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     if (n_written) *n_written = nw;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_copy_visible")
 
-extern "C" int re_set_output_buffers(re_ctx *c, uint32_t *d_ids, float *d_mats, uint32_t capacity) {
+extern "C" int re_set_output_buffers(re_ctx *c, uint32_t *d_ids, float *d_mats, uint32_t capacity) try {
     if (!c) return RE_E_ARG;
     if ((d_ids == nullptr) != (d_mats == nullptr)) return c->fail(RE_E_ARG, "re_set_output_buffers: both pointers or neither");
     c->ext_out_ids = d_ids; c->ext_out_mats = d_mats; c->ext_out_cap = d_ids ? capacity : 0;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_set_output_buffers")
 
-extern "C" int re_set_output_count(re_ctx *c, uint32_t *d_count) {
+extern "C" int re_set_output_count(re_ctx *c, uint32_t *d_count) try {
     if (!c) return RE_E_ARG;
     c->ext_out_count = d_count;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_set_output_count")
 
-extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, void *dst) {
+extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, void *dst) try {
     if (!c || !dst) return RE_E_ARG;
     uint32_t r = 0;
     if (!c->row_of(entity_id, &r)) return c->fail(RE_E_ARG, "re_read_component: unknown entity %u", entity_id);
@@ -2637,7 +2684,7 @@ extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, v
         default: return c->fail(RE_E_ARG, "re_read_component: unknown component %d", component);
     }
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_read_component")
 
 // ---- ECS presence semantics (objects/ecs.rs): see include/re_hip.h
 static uint32_t ecs_bits_of_flags(uint32_t fl) {
@@ -2655,7 +2702,7 @@ static uint32_t ecs_bits_of_flags(uint32_t fl) {
     if (fl & F_ALWAYS_EXEC) b |= 1u << RE_ECS_BIT_ALWAYS_EXECUTE_LOGIC;
     return b;
 }
-extern "C" int re_ecs_bitset(re_ctx *c, uint32_t entity_id, uint32_t *bits) {
+extern "C" int re_ecs_bitset(re_ctx *c, uint32_t entity_id, uint32_t *bits) try {
     if (!c || !bits) return RE_E_ARG;
     uint32_t r = 0;
     if (!c->row_of(entity_id, &r)) return c->fail(RE_E_ARG, "re_ecs_bitset: unknown entity %u", entity_id);
@@ -2665,13 +2712,13 @@ extern "C" int re_ecs_bitset(re_ctx *c, uint32_t entity_id, uint32_t *bits) {
     HIPCHK(c, hipMemcpy(&fl, c->d_flags.p + r, 4, hipMemcpyDeviceToHost));     // the device column is the truth (HasMoved / HasRotated are maintained by the tick)
     *bits = ecs_bits_of_flags(fl);
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_ecs_bitset")
 // The world sections an entity is registered in -- one key (its unique section) or the 2..8 keys its shared section links --, for a loader that spreads
 // a world over several GPUs.  The owner of an entity is the shard whose key range holds the SMALLEST of its keys: all
 // entities of a unique section, and a shared section together with the unique section that caches its static entities, then live on one shard (a
 // section's tight AABB -- distance test, LOD -- folds all of its entities).  The other keys tell which entities a shard needs as halo replicas
 // (RE_F_PHANTOM).  Host arithmetic with the functions the upload kernel runs (re_math.h); no device needed.
-extern "C" int re_section_keys(const re_config *cfg, const re_entities *E, uint64_t *keys, uint8_t *n_keys) {
+extern "C" int re_section_keys(const re_config *cfg, const re_entities *E, uint64_t *keys, uint8_t *n_keys) try {
     if (!cfg || !E || (E->n && (!keys || !n_keys || !E->flags || !E->original_aabb || !E->position))) return RE_E_ARG;
     if (!cfg->outline_length || !cfg->atomic_length) return RE_E_ARG;
     for (uint32_t i = 0; i < E->n; i++) {
@@ -2693,11 +2740,11 @@ extern "C" int re_section_keys(const re_config *cfg, const re_entities *E, uint6
         for (int k = 0; k < 8; k++) keys[(size_t)i * 8 + k] = k < nk ? k8[k] : 0ull;
     }
     return RE_OK;
-}
+} RE_ABI_GUARD_NOCTX(g_create_error, "re_section_keys")
 
 // The lights of one type RenderFlow::render finds near the camera (flows/render_flow.rs:249-254 -> flows/shadow_flow.rs:455-513): k_visible_lights over the
 // entities uploaded with RE_F_LIGHT_*.  Stands alone (own visibility test with the AABB culler of radius far_draw); ids in ascending order.
-extern "C" int re_visible_lights(re_ctx *c, const re_camera *cam, uint32_t light_type, uint32_t *ids, uint32_t capacity, uint32_t *n_out) {
+extern "C" int re_visible_lights(re_ctx *c, const re_camera *cam, uint32_t light_type, uint32_t *ids, uint32_t capacity, uint32_t *n_out) try {
     if (!c) return RE_E_ARG;
     if (!cam || !n_out || (capacity && !ids)) return c->fail(RE_E_ARG, "re_visible_lights: NULL argument");
     if (light_type != RE_F_LIGHT_DIRECTIONAL && light_type != RE_F_LIGHT_POINT && light_type != RE_F_LIGHT_SPOT) return c->fail(RE_E_ARG, "re_visible_lights: light_type must be one RE_F_LIGHT_* bit");
@@ -2720,15 +2767,15 @@ extern "C" int re_visible_lights(re_ctx *c, const re_camera *cam, uint32_t light
     HIPCHK(c, hipGetLastError());
     std::vector<uint32_t> out((size_t)nl + 1);
     HIPCHK(c, hipMemcpyAsync(out.data(), c->d_light_out.p, ((size_t)nl + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     const uint32_t cnt = std::min(out[nl], nl);
     std::sort(out.begin(), out.begin() + cnt);
     *n_out = cnt;
     for (uint32_t i = 0; i < cnt && i < capacity; i++) ids[i] = out[i];
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_visible_lights")
 
-extern "C" int re_ecs_query(re_ctx *c, const int *components, uint32_t n_components, uint32_t *ids, uint32_t capacity, uint32_t *n_out) {
+extern "C" int re_ecs_query(re_ctx *c, const int *components, uint32_t n_components, uint32_t *ids, uint32_t capacity, uint32_t *n_out) try {
     if (!c || (n_components && !components) || (capacity && !ids)) return RE_E_ARG;
     if (!c->h_res) return c->fail(RE_E_STATE, "re_ecs_query: no world uploaded");
     uint32_t need = 0;
@@ -2749,7 +2796,7 @@ extern "C" int re_ecs_query(re_ctx *c, const int *components, uint32_t n_compone
     if (c->n) hipLaunchKernelGGL(k_query_flags, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, c->n, c->d_flags.p, c->d_id.p, need, d_out.p, cap, d_cnt.p);
     HIPCHK(c, hipGetLastError());
     uint32_t cnt = 0;
-    HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt.p, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, sync_stream(c->stream));
     std::vector<uint32_t> found(cnt);
     if (cnt) HIPCHK(c, hipMemcpy(found.data(), d_out.p, (size_t)cnt * 4, hipMemcpyDeviceToHost));
     d_out.release(nullptr); d_cnt.release(nullptr);
@@ -2757,9 +2804,9 @@ extern "C" int re_ecs_query(re_ctx *c, const int *components, uint32_t n_compone
     for (uint32_t i = 0; i < cnt && i < capacity; i++) ids[i] = found[i];
     if (n_out) *n_out = cnt;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_ecs_query")
 
-extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity, uint32_t *n) {
+extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity, uint32_t *n) try {
     if (!c || !c->h_th) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc) return rc; } else { int rc = resolve(c); if (rc) return rc; }
@@ -2768,15 +2815,15 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
     if (n) *n = cnt;
     c->h_oob_ids.clear();
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_get_out_of_bounds")
 
-extern "C" int re_get_stats(re_ctx *c, re_stats *out) {
+extern "C" int re_get_stats(re_ctx *c, re_stats *out) try {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->n_device_rebuckets = c->n_device_rebuckets;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->n_device_rebuckets = c->n_device_rebuckets; out->n_segment_redos = c->n_segment_redos; out->reserved2 = 0;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_get_stats")
 
-extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, float *tight, uint32_t *n_local, uint32_t *n_static, uint8_t *is_static_section, uint32_t *n) {
+extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, float *tight, uint32_t *n_local, uint32_t *n_static, uint8_t *is_static_section, uint32_t *n) try {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
@@ -2801,9 +2848,9 @@ extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *key
         if (is_static_section) is_static_section[o] = f[i] & CF_STATIC_SECTION;
     }
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_debug_get_sections")
 
-extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n) {
+extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n) try {
     if (!c || !c->have_cull) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     if (c->cull_inflight) { int rc = finish_cull(c, nullptr); if (rc) return rc; }
@@ -2824,35 +2871,35 @@ extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint6
     for (uint32_t i = 0; i < cnt && i < capacity; i++) { if (keys) keys[i] = c->h_cell_key[idx[order[i]]]; if (multiplicity) multiplicity[i] = mult[order[i]]; }
     if (n) *n = cnt;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_debug_get_visible_sections")
 
-extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *tick_us) {
+extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *tick_us) try {
     if (!c) return RE_E_ARG;
     if (!cull_us && !pack_us && !tick_us) { c->timings_on = false; c->timings_pending = false; return RE_OK; }   // all NULL: switch the recording off again
     c->timings_on = true;                                                     // from now on synchronous frames are timed
     if (c->timings_pending) {
-        HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, sync_stream(c->stream));
         (void)hipEventElapsedTime(&c->t_cull, c->ev[0], c->ev[1]); (void)hipEventElapsedTime(&c->t_pack, c->ev[1], c->ev[2]);
         c->t_cull *= 1000.f; c->t_pack *= 1000.f; c->timings_pending = false;
     }
     if (cull_us) *cull_us = c->t_cull; if (pack_us) *pack_us = c->t_pack; if (tick_us) *tick_us = c->t_tick;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_get_timings")
 
 extern "C" void *re_get_stream(re_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 // per-launch HIP-event timing of the dominant kernel (k_scan_cull) over a timed region, every `every`-th launch (timed dispatches
 // carry completion signals that cost a few microseconds of queue time each, so a throughput run samples):
 // re_timing_begin(ctx, max_launches, every) ... frames ... re_timing_collect(ctx, us[], cap, &n)
-extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches, uint32_t every) {
+extern "C" int re_timing_begin(re_ctx *c, uint32_t max_launches, uint32_t every) try {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     while (c->k1_events.size() < (size_t)max_launches * 2) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->k1_events.push_back(e); }
     c->k1_used = 0; c->k1_timing = max_launches > 0; c->k1_every = std::max(every & 0xFFFFu, 1u); c->k1_kind = every >> 16; c->k1_seen = 0;
     if (c->k1_kind > RE_TIME_PACK_LARGE) return c->fail(RE_E_ARG, "re_timing_begin: unknown kernel selector");
     return RE_OK;
-}
-extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) {
+} RE_ABI_GUARD(c, "re_timing_begin")
+extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32_t *n) try {
     if (!c) return RE_E_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
@@ -2861,16 +2908,16 @@ extern "C" int re_timing_collect(re_ctx *c, float *us, uint32_t capacity, uint32
     if (n) *n = launches;
     c->k1_timing = false; c->k1_used = 0;
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_timing_collect")
 #ifdef RE_EXP_STAMPS
-extern "C" int re_debug_get_timeline(re_ctx *c, unsigned long long *out, uint32_t nwaves) {
+extern "C" int re_debug_get_timeline(re_ctx *c, unsigned long long *out, uint32_t nwaves) try {
     if (!c || !out || !c->d_timeline.p) return RE_E_ARG;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_stream(c->stream));
     HIPCHK(c, hipMemcpy(out, c->d_timeline.p, (size_t)std::min(nwaves, c->nlists) * 64, hipMemcpyDeviceToHost));
     return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_debug_get_timeline")
 #endif
-extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) {
+extern "C" int re_get_last_candidates(re_ctx *c, uint32_t *n_candidates) try {
     if (!c || !c->h_res || !n_candidates) return RE_E_ARG;
     *n_candidates = c->h_res->n_candidates; return RE_OK;
-}
+} RE_ABI_GUARD(c, "re_get_last_candidates")

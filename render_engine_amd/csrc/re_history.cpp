@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "re_hip.h"
+#include "re_guard.h"
 
 namespace {
 struct Frame { re_frame_change fc; std::vector<re_change> changes; };
@@ -148,46 +149,46 @@ struct re_history {
 
 static std::string g_history_error;
 
-extern "C" int re_history_create(const re_type_ids *ids, uint32_t flags, re_history **out) {
+extern "C" int re_history_create(const re_type_ids *ids, uint32_t flags, re_history **out) try {
     if (!ids || !out) return RE_E_ARG;
     re_history *h = new re_history(); h->ids = *ids; h->flags = flags; *out = h;
     return RE_OK;
-}
+} RE_ABI_GUARD_NOCTX(g_history_error, "re_history_create")
 extern "C" void re_history_destroy(re_history *h) { delete h; }
 extern "C" const char *re_history_last_error(const re_history *h) { return h ? h->err.c_str() : g_history_error.c_str(); }
-extern "C" int re_history_set_state(re_history *h, const void *ecs_blob, uint64_t ecs_bytes, const void *tree_blob, uint64_t tree_bytes) {
+extern "C" int re_history_set_state(re_history *h, const void *ecs_blob, uint64_t ecs_bytes, const void *tree_blob, uint64_t tree_bytes) try {
     if (!h || (ecs_bytes && !ecs_blob) || (tree_bytes && !tree_blob)) return RE_E_ARG;
     h->ecs_blob.assign((const uint8_t *)ecs_blob, (const uint8_t *)ecs_blob + ecs_bytes); h->tree_blob.assign((const uint8_t *)tree_blob, (const uint8_t *)tree_blob + tree_bytes);
     return RE_OK;
-}
-extern "C" int re_history_get_state(re_history *h, const void **ecs_blob, uint64_t *ecs_bytes, const void **tree_blob, uint64_t *tree_bytes) {
+} RE_ABI_GUARD(h, "re_history_set_state")
+extern "C" int re_history_get_state(re_history *h, const void **ecs_blob, uint64_t *ecs_bytes, const void **tree_blob, uint64_t *tree_bytes) try {
     if (!h) return RE_E_ARG;
     if (ecs_blob) *ecs_blob = h->ecs_blob.data(); if (ecs_bytes) *ecs_bytes = h->ecs_blob.size();
     if (tree_blob) *tree_blob = h->tree_blob.data(); if (tree_bytes) *tree_bytes = h->tree_blob.size();
     return RE_OK;
-}
-extern "C" int re_history_record(re_history *h, const re_frame_change *fc) {
+} RE_ABI_GUARD(h, "re_history_get_state")
+extern "C" int re_history_record(re_history *h, const re_frame_change *fc) try {
     if (!h || !fc || (fc->n_changes && !fc->changes)) return RE_E_ARG;
     Frame f; f.fc = *fc; f.changes.assign(fc->changes, fc->changes + fc->n_changes);
     std::vector<uint8_t> probe; int rc = h->encode(f, probe); if (rc != RE_OK) return rc;      // refuse what could not be written later
     h->frames.push_back(std::move(f));
     return RE_OK;
-}
+} RE_ABI_GUARD(h, "re_history_record")
 extern "C" int re_history_count(re_history *h, uint32_t *n) { if (!h || !n) return RE_E_ARG; *n = (uint32_t)h->frames.size(); return RE_OK; }
-extern "C" int re_history_get(re_history *h, uint32_t index, re_frame_change *out) {
+extern "C" int re_history_get(re_history *h, uint32_t index, re_frame_change *out) try {
     if (!h || !out || index >= h->frames.size()) return RE_E_ARG;
     Frame &f = h->frames[index]; f.fc.changes = f.changes.data(); f.fc.n_changes = (uint32_t)f.changes.size();
     *out = f.fc;
     return RE_OK;
-}
-extern "C" int re_history_encode(re_history *h, uint32_t index, uint8_t *dst, uint64_t capacity, uint64_t *n) {
+} RE_ABI_GUARD(h, "re_history_get")
+extern "C" int re_history_encode(re_history *h, uint32_t index, uint8_t *dst, uint64_t capacity, uint64_t *n) try {
     if (!h || index >= h->frames.size()) return RE_E_ARG;
     std::vector<uint8_t> b; int rc = h->encode(h->frames[index], b); if (rc != RE_OK) return rc;
     if (n) *n = b.size();
     if (dst) memcpy(dst, b.data(), b.size() < capacity ? b.size() : capacity);
     return RE_OK;
-}
-extern "C" int re_history_write(re_history *h, const char *history_path, const char *lookup_path) {
+} RE_ABI_GUARD(h, "re_history_encode")
+extern "C" int re_history_write(re_history *h, const char *history_path, const char *lookup_path) try {
     if (!h || !history_path || !lookup_path) return RE_E_ARG;
     FILE *fh = fopen(history_path, "wb"), *fl = fopen(lookup_path, "wb");
     if (!fh || !fl) { if (fh) fclose(fh); if (fl) fclose(fl); h->err = "re_history_write: cannot open the output files"; return RE_E_ARG; }
@@ -199,8 +200,8 @@ extern "C" int re_history_write(re_history *h, const char *history_path, const c
     for (uint64_t l : lens) fprintf(fl, "%llu\n", (unsigned long long)l);  // :202-206: one length per line
     fclose(fh); fclose(fl);
     return rc;
-}
-extern "C" int re_history_load(const re_type_ids *ids, uint32_t flags, const char *history_path, const char *lookup_path, re_history **out) {
+} RE_ABI_GUARD(h, "re_history_write")
+extern "C" int re_history_load(const re_type_ids *ids, uint32_t flags, const char *history_path, const char *lookup_path, re_history **out) try {
     if (!ids || !history_path || !lookup_path || !out) return RE_E_ARG;
     FILE *fh = fopen(history_path, "rb"), *fl = fopen(lookup_path, "rb");
     if (!fh || !fl) { if (fh) fclose(fh); if (fl) fclose(fl); g_history_error = "re_history_load: cannot open the input files"; return RE_E_ARG; }
@@ -225,4 +226,4 @@ extern "C" int re_history_load(const re_type_ids *ids, uint32_t flags, const cha
     }
     *out = h;
     return RE_OK;
-}
+} RE_ABI_GUARD_NOCTX(g_history_error, "re_history_load")

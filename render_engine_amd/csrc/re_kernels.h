@@ -102,6 +102,7 @@ struct HostResult {
                                             // posted writes have not all landed yet.  done_frame: written last (after a system-scope fence): the frame whose results above are complete -- a synchronous
                                             // call polls this word instead of paying the driver's stream-synchronise latency
 };
+constexpr uint32_t RESULT_SEGMENT_OVERFLOW = 3u;   // HostResult::overflow: a cursor segment of the instance list overflowed (0 = packed, 1 = k_pack_small declined: too many instances for it, 2 = frame cancelled by cross-frame speculation)
 constexpr uint32_t PACK_SMALL_ITEMS = 16383;   // instances k_pack_small takes (every workgroup counts all of them); more go through the count/scan/scatter path
 struct SharedArrays {                       // shared world sections (bounding_box_tree_v2.rs:113-155, 253-316)
     uint32_t n;
@@ -189,7 +190,7 @@ struct PackLargeArgs {
 __global__ void k_pack_large(PackLargeArgs A);
 __global__ void k_group_scan(uint32_t *group_count, uint32_t *group_begin, uint32_t *group_fill, uint32_t nslots, const uint32_t *gc_model, const uint32_t *gc_rs,
                              const uint32_t *gc_sort, InstanceRange *ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
-                             uint32_t *out_count, uint32_t out_cap, uint32_t frame);
+                             uint32_t *out_count, uint32_t out_cap, uint32_t frame, uint32_t seg_cap);
 __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row, const uint32_t *item_slot, uint32_t nshards, uint32_t seg_cap, const uint32_t *group_begin,
                                uint32_t *group_fill, uint32_t nslots, const uint32_t *row_id, const float *row_mat, uint32_t *out_ids, float *out_mats, uint32_t out_cap, const SpecState *spec);
 __global__ void k_tick(uint32_t ndyn, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,

@@ -726,7 +726,7 @@ __device__ __forceinline__ FrameCounts load_frame_counts(const FrameHeader *hdr)
 __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ group_count, uint32_t *__restrict__ group_begin, uint32_t *__restrict__ group_fill,
                                                      uint32_t nslots, const uint32_t *__restrict__ gc_model, const uint32_t *__restrict__ gc_rs, const uint32_t *__restrict__ gc_sort,
                                                      InstanceRange *__restrict__ ranges, uint32_t range_cap, FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, HostResult *hres, const SpecState *spec,
-                                                     uint32_t *out_count, uint32_t out_cap, uint32_t frame) {
+                                                     uint32_t *out_count, uint32_t out_cap, uint32_t frame, uint32_t seg_cap) {
     __shared__ uint32_t s_wsum[16], s_wcnt[16], s_whash[16];
     if (spec->stale) { if (threadIdx.x == 0) { HostResult r = {}; r.overflow = 2u; *hres = r; cancel_slab_header(out_count, frame); publish_to_host(&hres->done_frame, frame); } return; }
     __shared__ uint32_t s_carry, s_gcarry;
@@ -767,14 +767,14 @@ __global__ __launch_bounds__(1024) void k_group_scan(uint32_t *__restrict__ grou
     FrameCounts fc = {};
     if (wid == 0) fc = load_frame_counts(hdr);
     if (threadIdx.x == 0) {
-        uint32_t nsec = 0, nitems = 0, table_hash = 0;
-        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * CURSOR_STRIDE]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); }
+        uint32_t nsec = 0, nitems = 0, table_hash = 0; bool seg_over = false;
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) { unsigned long long cur = hdr->cursors[k * CURSOR_STRIDE]; nsec += (uint32_t)cur; nitems += (uint32_t)(cur >> 32); seg_over |= (uint32_t)(cur >> 32) > seg_cap; }
         for (uint32_t w = 0; w < 16u; w++) table_hash ^= s_whash[w];
         HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_groups = s_gcarry < range_cap ? s_gcarry : range_cap; r.total = s_carry; r.n_candidates = fc.n_candidates;
-        r.overflow = 0; r.n_entries = nsec; r.n_items = nitems;
+        r.overflow = seg_over ? RESULT_SEGMENT_OVERFLOW : 0u; r.n_entries = nsec; r.n_items = nitems;
         r.table_hash = result_seal(table_hash | 1u, frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items);
         *hres = r;                                              // mapped pinned host memory
-        write_slab_header(out_count, s_carry, out_cap, frame);
+        if (seg_over) cancel_slab_header(out_count, frame); else write_slab_header(out_count, s_carry, out_cap, frame);
         publish_to_host(&hres->done_frame, frame);
     }
     for (uint32_t i = threadIdx.x; i < sizeof(FrameHeader) / 4u; i += 1024u) reinterpret_cast<uint32_t *>(hdr_next)[i] = 0u;   // next frame's cursor/counters
@@ -870,21 +870,30 @@ __global__ __launch_bounds__(PACK_LARGE_THREADS) void k_pack_large(PackLargeArgs
     // ---- workgroup b works on cursor shard b & 7, tiles (b >> 3), (b >> 3) + gridDim / 8, ... of that shard's segment: the mapping does not depend on
     // the counts, so the first tile's list entries are requested together with the cursors and the group counts (entries beyond the shard's
     // count are stale but harmless: masked below)
-    const uint32_t shard = bid & (CURSOR_SHARDS - 1u), tstride = gridDim.x >> 3;
+    const uint32_t shard = bid & (CURSOR_SHARDS - 1u), tstride = (gridDim.x >> 3) ? (gridDim.x >> 3) : 1u;   // (never 0: the tile loop below must advance whatever grid it was launched with)
     uint32_t tile = bid >> 3, slot[PER], row[PER];
 #pragma unroll
     for (uint32_t q = 0; q < PER; q++) {
         const uint32_t j = tile * TILE + q * NT + tid;
         slot[q] = 0xFFFFFFFFu; row[q] = 0;
-        if (j < A.seg_cap) { const uint32_t ii = shard * A.seg_cap + j; slot[q] = A.item_slot[ii]; row[q] = A.item_row[ii]; }
+        if (shard < nsh && j < A.seg_cap) { const uint32_t ii = shard * A.seg_cap + j; slot[q] = A.item_slot[ii]; row[q] = A.item_row[ii]; }
     }
-    uint32_t n_sh = 0, raw_items = 0, raw_sec = 0;
+    uint32_t n_sh = 0, raw_items = 0, raw_sec = 0; bool seg_over = false;
 #pragma unroll
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
         const unsigned long long cur = k < nsh ? A.hdr->cursors[k * CURSOR_STRIDE] : 0ull;
         const uint32_t v = (uint32_t)(cur >> 32);
-        raw_sec += (uint32_t)cur; raw_items += v;
+        raw_sec += (uint32_t)cur; raw_items += v; seg_over |= v > A.seg_cap;
         if (k == shard) n_sh = v < A.seg_cap ? v : A.seg_cap;
+    }
+    if (seg_over) {                                         // a cursor segment overflowed (clustered sections: the shard is the wave index mod 8): nothing is packed, the host redoes the frame with one whole-list segment
+        if (bid == 0) {
+            if (tid == 0) { HostResult r = {}; r.overflow = RESULT_SEGMENT_OVERFLOW; r.n_entries = raw_sec; r.n_items = raw_items; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
+            for (uint32_t i = tid; i < sizeof(FrameHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(A.hdr_next)[i] = 0u;
+            for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += NT) reinterpret_cast<uint32_t *>(A.th)[i] = 0u;
+            for (uint32_t i = tid; i < A.zero_words; i += NT) { if (A.zero_a) A.zero_a[i] = 0u; if (A.zero_b) A.zero_b[i] = 0u; }
+        }
+        return;
     }
     if (bid != 0 && tile * TILE >= n_sh) return;
     if (tid == 0) { s_carry = 0; s_gcarry = 0; }
@@ -1052,9 +1061,9 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     for (uint32_t k = 0; k < CURSOR_SHARDS; k++) cur[k] = hdr->cursors[k * CURSOR_STRIDE];
     uint32_t sl[CURSOR_SHARDS];
 #pragma unroll
-    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) sl[k] = tid < K.seg_cap ? K.item_slot[k * K.seg_cap + tid] : 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) sl[k] = (k < K.nshards && tid < K.seg_cap) ? K.item_slot[k * K.seg_cap + tid] : 0xFFFFFFFFu;   // (a list of ONE segment -- the redo of a frame whose clustered sections overflowed a segment -- has no entries behind it)
     uint32_t my_slot = 0xFFFFFFFFu, my_row = 0;
-    if (tid < 64u && my_j0 + tid < K.seg_cap) { const uint32_t ii = my_shard * K.seg_cap + my_j0 + tid; my_slot = K.item_slot[ii]; my_row = K.item_row[ii]; }
+    if (tid < 64u && my_shard < K.nshards && my_j0 + tid < K.seg_cap) { const uint32_t ii = my_shard * K.seg_cap + my_j0 + tid; my_slot = K.item_slot[ii]; my_row = K.item_row[ii]; }
     if (my_row >= nrows) my_row = 0;                          // a stale entry of an earlier world
     // workgroup 0 reports the frame: its counter shards travel with this first round trip, and its InstanceRange table is staged in
     // LDS so that one wave writes everything the host reads (table, counts, "frame done") behind a single system-scope fence
@@ -1147,10 +1156,11 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
             if (lane == 0) {
                 HostResult r = {}; r.n_vis_map = fc.n_vis_map; r.n_vis_vec = fc.n_vis_vec; r.n_candidates = fc.n_candidates;   // (never read the mapped host struct: a PCIe round trip)
                 r.n_groups = overflow ? 0u : s_gcarry; r.total = overflow ? 0u : s_carry;
-                r.overflow = overflow ? 1u : 0u; r.n_entries = raw_sec; r.n_items = raw_items;
+                r.overflow = seg_over ? RESULT_SEGMENT_OVERFLOW : (overflow ? 1u : 0u); r.n_entries = raw_sec; r.n_items = raw_items;
                 r.table_hash = table_hash ? result_seal(table_hash, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items) : 0u;
                 *A.hres = r;                                        // mapped pinned host memory
                 if (!overflow) write_slab_header(A.out_count, s_carry, A.out_cap, A.frame);
+                else if (seg_over) cancel_slab_header(A.out_count, A.frame);      // the host redoes the frame with one whole-list segment (finish_cull) into the same slab
                 publish_to_host(&A.hres->done_frame, A.frame);      // the group table and the counters above are complete
             }
         }
@@ -1174,7 +1184,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     }
     // ---- a shard longer than the launch anticipated (the grid is sized from the previous frame): further chunks of this workgroup,
     // without the speculative loads; the "before this chunk" histogram is rebuilt per chunk
-    const uint32_t stride = (nblk >> 3) * 64u;
+    const uint32_t stride = ((nblk >> 3) ? (nblk >> 3) : 1u) * 64u;     // (never 0: the loop must advance whatever grid it was launched with)
     for (uint32_t j0 = my_j0 + stride; j0 < my_n; j0 += stride) {           // workgroup-uniform
         __syncthreads();
         for (uint32_t i = tid; i < nslots; i += NT) s_fill[i] = 0;

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 #include "re_hip.h"
+#include "re_guard.h"
 
 namespace {
 
@@ -266,7 +267,7 @@ static thread_local std::string g_lt_error;
 
 extern "C" const char *re_lighting_last_error(const re_lighting *l) { return l ? l->err.c_str() : g_lt_error.c_str(); }
 
-extern "C" int re_lighting_create(const re_lighting_config *cfg, re_lighting **out) {
+extern "C" int re_lighting_create(const re_lighting_config *cfg, re_lighting **out) try {
     if (!cfg || !out || !cfg->width || !cfg->height) { g_lt_error = "re_lighting_create: bad argument"; return RE_E_ARG; }
     int ndev = 0; hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0) { g_lt_error = std::string("re_lighting_create: no HIP device (") + hipGetErrorString(e) + "); no CPU path"; return RE_E_HIP; }
@@ -280,16 +281,16 @@ extern "C" int re_lighting_create(const re_lighting_config *cfg, re_lighting **o
     }
     l->P.width = cfg->width; l->P.height = cfg->height;
     *out = l; return RE_OK;
-}
-extern "C" void re_lighting_destroy(re_lighting *l) {
+} RE_ABI_GUARD_NOCTX(g_lt_error, "re_lighting_create")
+extern "C" void re_lighting_destroy(re_lighting *l) try {
     if (!l) return;
     (void)hipSetDevice(l->cfg.device);
     if (l->stream) (void)hipStreamSynchronize(l->stream);
     (void)hipFree(l->d_pos); (void)hipFree(l->d_nrm); (void)hipFree(l->d_out); (void)hipFree(l->d_alb); (void)hipFree(l->d_spot); (void)hipFree(l->d_point); (void)hipFree(l->d_slab);
     if (l->stream) (void)hipStreamDestroy(l->stream);
     delete l;
-}
-extern "C" int re_lighting_upload_gbuffer(re_lighting *l, const float *g_position, const float *g_normal, const uint8_t *g_albedo_spec) {
+} catch (...) {}
+extern "C" int re_lighting_upload_gbuffer(re_lighting *l, const float *g_position, const float *g_normal, const uint8_t *g_albedo_spec) try {
     if (!l || !g_position || !g_normal || !g_albedo_spec) return RE_E_ARG;
     LCHK(l, hipSetDevice(l->cfg.device));
     size_t np = (size_t)l->cfg.width * l->cfg.height;
@@ -298,8 +299,8 @@ extern "C" int re_lighting_upload_gbuffer(re_lighting *l, const float *g_positio
     LCHK(l, hipMemcpyAsync(l->d_alb, g_albedo_spec, np * 4, hipMemcpyHostToDevice, l->stream));
     LCHK(l, hipStreamSynchronize(l->stream));
     return RE_OK;
-}
-extern "C" int re_lighting_set_lights(re_lighting *l, const re_lights *L) {
+} RE_ABI_GUARD(l, "re_lighting_upload_gbuffer")
+extern "C" int re_lighting_set_lights(re_lighting *l, const re_lights *L) try {
     if (!l || !L) return RE_E_ARG;
     if (L->n_spot > l->cfg.max_spot_lights || L->n_point > l->cfg.max_point_lights) return l->fail(RE_E_CAPACITY, "more lights than configured");
     LCHK(l, hipSetDevice(l->cfg.device));
@@ -347,8 +348,8 @@ extern "C" int re_lighting_set_lights(re_lighting *l, const re_lights *L) {
     for (int k = 0; k < 3; k++) l->P.cam[k] = L->camera_pos[k];
     l->P.cutoff = L->no_light_source_cutoff; l->P.default_diffuse = L->default_diffuse_factor; l->P.any_visible = L->any_light_source_visible;
     return RE_OK;
-}
-extern "C" int re_lighting_run(re_lighting *l, float *kernel_us) {
+} RE_ABI_GUARD(l, "re_lighting_set_lights")
+extern "C" int re_lighting_run(re_lighting *l, float *kernel_us) try {
     if (!l) return RE_E_ARG;
     LCHK(l, hipSetDevice(l->cfg.device));
     hipEvent_t a = nullptr, b = nullptr;
@@ -359,14 +360,14 @@ extern "C" int re_lighting_run(re_lighting *l, float *kernel_us) {
     LCHK(l, hipStreamSynchronize(l->stream));
     if (kernel_us) { float ms = 0; LCHK(l, hipEventElapsedTime(&ms, a, b)); *kernel_us = ms * 1000.f; (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
     return RE_OK;
-}
-extern "C" int re_lighting_read(re_lighting *l, float *out_rgba) {
+} RE_ABI_GUARD(l, "re_lighting_run")
+extern "C" int re_lighting_read(re_lighting *l, float *out_rgba) try {
     if (!l || !out_rgba) return RE_E_ARG;
     LCHK(l, hipSetDevice(l->cfg.device));
     LCHK(l, hipMemcpy(out_rgba, l->d_out, (size_t)l->cfg.width * l->cfg.height * 16, hipMemcpyDeviceToHost));
     return RE_OK;
-}
-extern "C" int re_lighting_read_pixels(re_lighting *l, const uint32_t *idx, uint32_t n, float *out_rgba) {
+} RE_ABI_GUARD(l, "re_lighting_read")
+extern "C" int re_lighting_read_pixels(re_lighting *l, const uint32_t *idx, uint32_t n, float *out_rgba) try {
     if (!l || !idx || !out_rgba) return RE_E_ARG;
     LCHK(l, hipSetDevice(l->cfg.device));
     uint32_t *d_idx = nullptr; float4 *d_o = nullptr;
@@ -377,4 +378,4 @@ extern "C" int re_lighting_read_pixels(re_lighting *l, const uint32_t *idx, uint
     LCHK(l, hipMemcpy(out_rgba, d_o, (size_t)n * 16, hipMemcpyDeviceToHost));
     (void)hipFree(d_idx); (void)hipFree(d_o);
     return RE_OK;
-}
+} RE_ABI_GUARD(l, "re_lighting_read_pixels")

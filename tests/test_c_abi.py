@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/re_hip.h but not exported"
     assert set(R._capi.EXPORTS) <= set(names)
-    assert L.re_abi_version() == 2
+    assert L.re_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_capi.TickResult) == 12
     assert C.sizeof(_capi.Entities) == 8 + 13 * 8
     assert C.sizeof(_capi.Visible) == 5 * 4 + 4 + 3 * 8
-    assert C.sizeof(_capi.Stats) == 5 * 4 + 4 + 8 + 8 * 4            # 5 counts, padding, device_bytes, 8 counters
+    assert C.sizeof(_capi.Stats) == 5 * 4 + 4 + 8 + 10 * 4           # 5 counts, padding, device_bytes, 10 counters
 
 
 def test_fails_loudly_without_a_device():
@@ -81,3 +81,41 @@ def test_synthetic_world_is_deterministic_and_in_bounds():
     lo = a["pos"] + a["original"][:, 0::2] * a["scale"]; hi = a["pos"] + a["original"][:, 1::2] * a["scale"]
     assert np.all(np.floor(lo / 64) == np.floor(hi / 64))   # every box inside one level-0 section
 
+
+
+def test_no_exception_crosses_the_abi():
+    """include/re_hip.h: "no exceptions/aborts cross the ABI".  Every extern "C" entry point is a function-try-block (csrc/re_guard.h); a host-only path
+    that throws is used as the witness: re_history_set_state with a blob length no vector can hold makes std::vector::assign throw std::length_error
+    before a byte is read -- without the guard that is std::terminate -> abort() inside the caller's process."""
+    import render_engine_amd as R
+    from render_engine_amd import _capi
+    L = _capi.load()
+    ids = _capi.TypeIds(*range(1, 10)); h = C.c_void_p()
+    assert L.re_history_create(C.byref(ids), 0, C.byref(h)) == 0
+    blob = (C.c_uint8 * 16)()
+    rc = L.re_history_set_state(h, blob, 1 << 62, blob, 0)
+    assert rc in (-5, -3), rc                                   # RE_E_STATE (std::exception) or RE_E_CAPACITY (std::bad_alloc)
+    msg = L.re_history_last_error(h).decode()
+    assert "re_history_set_state" in msg, msg
+    assert L.re_history_set_state(h, blob, 16, blob, 8) == 0     # the object is still usable
+    L.re_history_destroy(h)
+
+
+def test_every_entry_point_is_guarded():
+    """each extern "C" definition with a body of more than one line is a function-try-block closed by RE_ABI_GUARD*; the one-liners cannot throw"""
+    n = 0
+    for f in ("re_api.hip", "re_lighting.hip", "re_history.cpp"):
+        lines = open(os.path.join(ROOT, "render_engine_amd", "csrc", f)).read().split("\n")
+        for i, ln in enumerate(lines):
+            if not ln.startswith('extern "C"'):
+                continue
+            if ln.rstrip().endswith("{"):
+                assert ln.rstrip().endswith("try {"), (f, i + 1, ln[:80])
+                j = i + 1
+                while not lines[j].startswith("}"):
+                    j += 1
+                assert "RE_ABI_GUARD" in lines[j] or "catch (...)" in lines[j], (f, j + 1, lines[j][:80])
+                n += 1
+            else:
+                assert not re.search(r"\b(new|vector|push_back|resize|assign|std::string\()", ln), (f, i + 1, ln[:120])
+    assert n >= 45

@@ -16,8 +16,8 @@ def R():
     return R
 
 
-def build_pair(R, ents, outline=16384, atomic=64, flags=0):
-    p = R.Pipeline(outline, atomic, flags=flags)
+def build_pair(R, ents, outline=16384, atomic=64, flags=0, max_instances=0):
+    p = R.Pipeline(outline, atomic, flags=flags, max_instances=max_instances)
     plain_close = p.close
 
     def close_checked():                      # every test that closes its pipeline also asserts the publication counters
@@ -87,7 +87,7 @@ def check_entities(R, p, w, ents):
 
 
 def test_library_loaded_and_fails_loudly(R):
-    assert R._capi.load().re_abi_version() == 2
+    assert R._capi.load().re_abi_version() == 3
     with pytest.raises(R.RenderEngineError):
         R.Pipeline(16384, 64, device=99)
 
@@ -861,6 +861,50 @@ def test_device_rebucket_soak(R, dims, first, atomic, every):
         np.testing.assert_array_equal(p.visible_lights(cam, R.F_LIGHT_POINT), w.visible_lights(oracle_camera(cam), ro.F_LIGHT_POINT))     # lights follow the sections the device moved them to
     assert p.stats()["n_device_rebuckets"] >= 1, p.stats()
     check_entities(R, p, w, ents[::3])
+    p.close(); w.close()
+
+
+def crowded_world(R, n_crowd=150000, n_lattice=50000):
+    """n_lattice static entities one per level-0 section + n_crowd entities (a third of them active) whose 300-unit boxes all fall into ONE level-3 world section"""
+    C = R._capi
+    lat = R.synthetic.lattice_world(cells_per_axis=37, first_cell=100)[:n_lattice]
+    e = np.zeros(n_crowd, R.ENTITY_DT)
+    idx = np.arange(n_crowd, dtype=np.uint64)
+    e["id"] = (idx + np.uint64(1_000_000)).astype(np.uint32)
+    e["model_index"] = (idx % np.uint64(5)).astype(np.uint32)
+    e["flags"] = np.where(idx % np.uint64(3) == 0, 0, C.F_STATIC).astype(np.uint32)
+    for k in range(3):
+        e["pos"][:, k] = np.float32(8448.0) + np.float32(120.0) * (R.synthetic.uniform(77, idx, k) - np.float32(0.5))
+        e["original"][:, 2 * k] = -150.0; e["original"][:, 2 * k + 1] = 150.0
+    e["scale"] = 1.0; e["rot_axis"][:, 0] = 1; e["rotvel_axis"][:, 0] = 1; e["rotacc_axis"][:, 0] = 1
+    return np.concatenate([lat, e])
+
+
+def test_crowded_section_overflows_a_cursor_segment(R):
+    """200,000 entities, 150,000 of them in one level-3 world section that both visibility queries return (duplicates mode: 300,000 instances from
+    one reservation of one wave).  The instance list is eight cursor segments and a wave reserves in segment (wave index mod 8), so this frame cannot
+    fit its segment: the pack kernels report it, the library redoes the frame with the list as one segment (re_stats.n_segment_redos) and keeps that
+    layout -- the reference never fails a frame for where its entities sit (round 2 failed it with RE_E_CAPACITY)."""
+    ents = crowded_world(R)
+    p, w = build_pair(R, ents, max_instances=400000)
+    s = p.sections()
+    big = s["keys"][(s["keys"] >> np.uint64(48)) == 3]
+    assert len(big) == 1 and int(s["n_local"][s["keys"] == big[0]][0]) == 50000 and int(s["n_static"][s["keys"] == big[0]][0]) == 100000
+    cam = R.Camera((8680, 8680, 8690), (-0.57, -0.57, -0.57), 2000.0)          # within the logic culler's reach of the section's corner AND in front of the frustum
+    for f, dups in enumerate((True, False, True)):
+        g, o = check_frame(R, p, w, cam, dups)
+        assert g["total"] >= (300000 if dups else 150000)
+        n_o, _ = w.tick(oracle_camera(cam), 0.016); t = p.tick(0.016)
+        assert t["n_changed"] == n_o
+    st = p.stats()
+    assert st["n_segment_redos"] == 1                                            # the first frame found out; the later ones start with one segment
+    # the forced multi-kernel pack (count / scan / scatter) on the same world
+    g, o = check_frame(R, p, w, cam, True, force_large_pack=True)
+    p.close(); w.close()
+    # the same world seen for the first time through the large pack path (the prediction of a fresh context is "small")
+    p, w = build_pair(R, ents, max_instances=400000)
+    g, o = check_frame(R, p, w, cam, True, force_large_pack=True)
+    assert p.stats()["n_segment_redos"] == 1 and g["total"] >= 300000
     p.close(); w.close()
 
 
