@@ -1189,7 +1189,7 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     if (c->timed_frame) HIPCHK(c, hipEventRecord(c->ev[0], st));
     if (c->dirty_pending) {
         if (c->ncells) hipLaunchKernelGGL(k_static_cache_cells, dim3((c->ncells + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_tight.p, c->d_cell_flags.p, P);
-        if (c->nsh) hipLaunchKernelGGL(k_static_cache_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_sh_dirty.p, c->d_sh_owner.p, c->d_sh_cached.p, P);
+        if (c->nsh) hipLaunchKernelGGL(k_static_cache_shared, dim3((c->nsh + 255) / 256), dim3(256), 0, st, c->nsh, c->d_sh_cells.p, c->d_cell_key.p, c->d_sh_aabb.p, c->d_sh_dirty.p, c->d_sh_owner.p, c->d_sh_cached.p, P);
         // the changed-static set is consumed by every render until the frame ends (re_tick clears it)
     }
     hipEvent_t k1a = nullptr, k1b = nullptr;

@@ -117,7 +117,7 @@ __global__ void k_fold_tight(uint32_t ncells, const uint64_t *cell_key, const ui
 __global__ void k_fold_shared(uint32_t nsh, const uint32_t *sh_begin, const uint32_t *sh_nact, const uint32_t *sh_nstat, const uint32_t *rows, const Aabb *ent_aabb, Aabb *sh_aabb);
 __global__ void k_static_cache_cells(uint32_t ncells, const Aabb *cell_tight, uint8_t *cell_flags, FrameParams P);
 __global__ void k_clear_static_dirty(uint32_t ncells, uint8_t *cell_flags, uint32_t nsh, uint8_t *sh_dirty);
-__global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty, int32_t *sh_owner, uint8_t *sh_cached, FrameParams P);
+__global__ void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const uint64_t *cell_key, const Aabb *sh_aabb, uint8_t *sh_dirty, int32_t *sh_owner, uint8_t *sh_cached, FrameParams P);
 struct ItemSink {
     uint32_t *item_row, *item_slot; uint32_t item_cap;
     uint32_t nshards, seg_cap;              // instance list = nshards segments of seg_cap slots, one cursor each

@@ -126,14 +126,14 @@ __global__ __launch_bounds__(256) void k_clear_static_dirty(uint32_t ncells, uin
     if (i < nsh) sh_dirty[i] = 0;
 }
 // shared sections reached from a re-cached unique section (sort_shared_world_sections(is_static) :808-866):
-// the first unique section (ascending key == ascending index) that reaches it caches its static entities
-__global__ __launch_bounds__(256) void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const Aabb *sh_aabb, uint8_t *sh_dirty,
+// the first unique section (ascending key) that reaches it caches its static entities
+__global__ __launch_bounds__(256) void k_static_cache_shared(uint32_t nsh, const int32_t *sh_cells, const uint64_t *cell_key, const Aabb *sh_aabb, uint8_t *sh_dirty,
                                                              int32_t *sh_owner, uint8_t *sh_cached, FrameParams P) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsh) return;
     if (!sh_dirty[s]) return;
-    int32_t owner = -1;
-    for (int k = 0; k < 8; k++) { int32_t c = sh_cells[s * 8 + k]; if (c >= 0 && (owner < 0 || c < owner)) owner = c; }
+    int32_t owner = -1; uint64_t okey = 0;                        // the linking section with the smallest KEY (sections patched in since the last full build sit in spare slots: slot order is not key order)
+    for (int k = 0; k < 8; k++) { int32_t c = sh_cells[s * 8 + k]; if (c >= 0) { const uint64_t kk = cell_key[c]; if (owner < 0 || kk < okey) { owner = c; okey = kk; } } }
     float d2 = distance_to_aabb(sh_aabb[s], P.cam[0], P.cam[1], P.cam[2]);
     sh_owner[s] = owner; sh_cached[s] = (uint8_t)(d2 < P.far_draw);
 }
