@@ -265,7 +265,7 @@ int re_gather_wait(re_ctx *ctx, re_gathered *out /* nullable */);
  * the translation-only path (matrix column 3 + translated OriginalAABB), Rotation / Scale force the full TRS recompute; an
  * entity whose section is unchanged is left where it is; a deleted entity ignores later requests; an entity that leaves the
  * world is kept when RE_F_OOB_LOGIC, otherwise removed and reported (re_get_out_of_bounds).  Velocity-type components can be
- * written for entities uploaded with Velocity or VelocityRotation.  The call belongs to the frame's logic phase (after
+ * written for any entity (one registered without Velocity / VelocityRotation gets its slot of the dynamic table on the first write).  The call belongs to the frame's logic phase (after
  * re_cull_pack): like Pipeline::execute it clears the changed-static-section set afterwards (pipeline.rs:271).
  * The reference's static render cache is a snapshot the logic phase never refreshes: an entity made static by a change is
  * therefore not drawn until it wakes up again (modelled), and a static entity of the snapshot that is woken, deleted or
@@ -282,10 +282,28 @@ int re_gather_wait(re_ctx *ctx, re_gathered *out /* nullable */);
                                        * component = RE_C_ROTATION, RE_C_SCALE, RE_C_VELOCITY, RE_C_ACCELERATION, RE_C_ROTATION_VEL or RE_C_ROTATION_ACC.  The
                                        * presence bit is cleared and nothing else happens (no matrix recompute); later reads of Rotation / Scale see the default
                                        * (movement_components.rs:41-55), kinematics skip an absent velocity component (logic_flow.rs:366-448). */
+#define RE_CHANGE_ADD_ENTITY       5u  /* AddEntity (:48-107): create_entity + EntityTransformationBuilder::apply_choices, inline in list order.  reserved = index into the `added`
+                                       * entities of re_apply_changes_ex; entity_id = the id ECS::create_entity hands out (objects/ecs.rs:384-402: the last freed id, else the next
+                                       * one) -- the host's shim keeps that counter and free list -- and must equal added->entity_id[reserved].  Later changes of the same list may
+                                       * name the new entity (AddEntity applies its own change request right away, :79).  An entity whose AABB lies out of bounds is created but not
+                                       * inserted into the tree (apply_choices prints an error).  A static entity added inside a frame is in the tree's static set but not drawn until
+                                       * its section is re-cached (the frozen static render cache, see above). */
+#define RE_CHANGE_ADD_SORTABLE     6u  /* AddSortableComponent((EntityId, TypeIdentifier)) (:138-141) -> ECS::write_sortable_component (objects/ecs.rs:202-205): component = index of
+                                       * the sortable component in registration order == re_entities.sortable; the entity's instances move to that (ModelId, sortable) group */
+#define RE_CHANGE_REMOVE_SORTABLE  7u  /* RemoveSortableComponent (:142-146) -> back to the default sortable component (index 0) */
 typedef struct re_change { uint32_t kind, entity_id, component, reserved; float value[4]; } re_change;
 /* out: n_changed = entities whose matrix/AABB were recomputed, n_rebucket = of those, entities that changed section,
  * n_out_of_bounds = entities removed because they left the world */
 int re_apply_changes(re_ctx *ctx, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out /*nullable*/);
+/* the same with the entities RE_CHANGE_ADD_ENTITY changes refer to (`added` may be NULL when the list adds none) */
+int re_apply_changes_ex(re_ctx *ctx, const re_change *changes, uint32_t n, const re_entities *added, uint32_t flags, re_tick_result *out /*nullable*/);
+/* Pipeline::register_model_instances at any time (flows/pipeline.rs:186-208): create_entity + apply_choices for every instance, then end_of_changes -- the
+ * entities are APPENDED to the world (re_upload_entities replaces it; on a context without a world this call is the upload).  entity_id: ids not in use
+ * (ids of removed entities may be reused, as ECS::create_entity does).  Between frames: the changed-static set of the tree is still there at the next
+ * re_cull_pack, so a section that received a static entity is re-cached by that render from its live static set (render_flow.rs:549-594) -- unlike an
+ * entity added inside a frame.  A velocity-type component written later to an entity registered without one gets a slot of the dynamic table then
+ * (objects/entity_change_request.rs:29-30: the component is registered on write).  n_rejected (optional): entities out of bounds, created but not inserted. */
+int re_add_entities(re_ctx *ctx, const re_entities *ents, uint32_t *n_rejected);
 
 /* Collision broad phase of the frame == LogicFlow::handle_collisions (flows/logic_flow.rs:452-651) up to the collision-logic
  * callbacks: which (this_entity, other_entity) pairs the reference would hand to the CollisionFunction of this_entity's type.

@@ -140,6 +140,8 @@ def lib():
     L.ro_frame_tick.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_float, C.c_uint32, C.c_void_p, u32p]
     L.ro_apply_changes.restype = C.c_uint32
     L.ro_apply_changes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p]
+    L.ro_apply_changes_ex.restype = C.c_uint32
+    L.ro_apply_changes_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, u32p]
     L.ro_frame_collide.restype = C.c_uint32; L.ro_frame_collide.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_void_p]
     L.ro_related_sections.restype = C.c_uint32; L.ro_related_sections.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
     L.ro_find_related.restype = C.c_uint32
@@ -337,11 +339,13 @@ class World:
         total = self.L.ro_frame_render(self.h, C.byref(cam), int(emit_duplicates), cap, ids.ctypes.data, mats.ctypes.data, gcap, groups.ctypes.data, C.byref(ng))
         return dict(total=total, ids=ids[:min(total, cap)], mats=mats[:min(total, cap)], groups=groups[:ng.value].copy())
 
-    def apply_changes(self, changes, end_of_frame=True, cap=4096):
-        """changes: structured array CHANGE_DT (kind, entity_id, component, pad, value[4]); returns (n entities re-placed, oob ids)"""
+    def apply_changes(self, changes, end_of_frame=True, cap=4096, added=None):
+        """changes: structured array CHANGE_DT (kind, entity_id, component, pad, value[4]); added: ENTITY_DT array the ADD_ENTITY changes index (pad);
+        returns (n entities re-placed, oob ids)"""
         ch = np.ascontiguousarray(changes, dtype=CHANGE_DT)
         oob = np.zeros(cap, np.uint32); noob = C.c_uint32()
-        n = self.L.ro_apply_changes(self.h, ch.ctypes.data, len(ch), 1 if end_of_frame else 0, cap, oob.ctypes.data, C.byref(noob))
+        ad = np.ascontiguousarray(added, ENTITY_DT) if added is not None else np.zeros(0, ENTITY_DT)
+        n = self.L.ro_apply_changes_ex(self.h, ch.ctypes.data, len(ch), ad.ctypes.data if len(ad) else None, len(ad), 1 if end_of_frame else 0, cap, oob.ctypes.data, C.byref(noob))
         return n, oob[:min(noob.value, cap)].copy()
 
     def collide(self, cam, cap=None):

@@ -877,9 +877,12 @@ static void normalize3(const float v[3], float out[3]) {
     out[0] = v[0] / n; out[1] = v[1] / n; out[2] = v[2] / n;
 }
 
-int ro_register_entities(ro_world *w, uint32_t n, const ro_entity_desc *d) {
+/* One instance: ECS::create_entity (the id comes with the description) + EntityTransformationBuilder::apply_choices (exports/entity_transformer.rs:55-75,
+ * 99-142): components, TransformationMatrix, StaticAABB, add_entity(id, aabb, false, is_static, light).  Returns 1 when the tree rejected it (out of bounds).
+ * Called by register_model_instances (flows/pipeline.rs:186-208) and by the AddEntity arm of apply_change (helper_things/entity_change_helpers.rs:48-107). */
+static int register_one(ro_world *w, const ro_entity_desc *d) {
     int rejected = 0;
-    for (uint32_t i = 0; i < n; i++) {
+    for (uint32_t i = 0; i < 1; i++) {
         ent_t *e = ent_slot(w, d[i].id);
         if (e->lookup) ro_tree_remove(w, d[i].id);
         memset(e, 0, sizeof *e);
@@ -912,6 +915,11 @@ int ro_register_entities(ro_world *w, uint32_t n, const ro_entity_desc *d) {
         /* apply_choices: add_entity(id, &transformed, false, is_static, light) (:71) */
         if (ro_tree_add(w, d[i].id, e->aabb, 0, (e->flags & RO_F_STATIC) != 0) != 0) rejected++;
     }
+    return rejected;
+}
+int ro_register_entities(ro_world *w, uint32_t n, const ro_entity_desc *d) {
+    int rejected = 0;
+    for (uint32_t i = 0; i < n; i++) rejected += register_one(w, &d[i]);
     ro_end_of_changes(w);
     return rejected;
 }
@@ -1618,9 +1626,19 @@ uint32_t ro_frame_collide(ro_world *w, const ro_camera *cam, uint32_t cap, uint3
  * Deviation: a DeleteRequest also drops the entity from the translation-only set (the reference would unwrap a removed
  * component there and panic). */
 uint32_t ro_apply_changes(ro_world *w, const ro_change *ch, uint32_t n, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob) {
+    return ro_apply_changes_ex(w, ch, n, NULL, 0, end_of_frame, cap, oob_ids, n_oob);
+}
+uint32_t ro_apply_changes_ex(ro_world *w, const ro_change *ch, uint32_t n, const ro_entity_desc *added, uint32_t n_added, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob) {
     u32set only_translation = { 0 }, kinematics = { 0 }, deleted = { 0 };
     for (uint32_t i = 0; i < n; i++) {
         const ro_change *c = &ch[i];
+        if (c->kind == RO_CHANGE_ADD_ENTITY) {                  /* AddEntity (entity_change_helpers.rs:48-107): inline, in list order; the entity leaves the three sets (:54-56) */
+            if (!added || c->pad >= n_added) continue;
+            const uint32_t nid = added[c->pad].id;
+            u32set_del(&kinematics, nid); u32set_del(&only_translation, nid); u32set_del(&deleted, nid);
+            (void)register_one(w, &added[c->pad]);
+            continue;
+        }
         if (c->entity_id >= w->ents_cap || !w->ents[c->entity_id].alive) continue;
         ent_t *e = &w->ents[c->entity_id];
         const uint32_t id = c->entity_id;
@@ -1655,6 +1673,12 @@ uint32_t ro_apply_changes(ro_world *w, const ro_change *ch, uint32_t n, int end_
             default: break;
             }
             break;
+        case RO_CHANGE_ADD_SORTABLE:                            /* AddSortableComponent -> ECS::write_sortable_component (objects/ecs.rs:202-205): the entity's sortable bucket */
+            if (u32set_has(&deleted, id)) break;
+            e->sortable = c->component; break;
+        case RO_CHANGE_REMOVE_SORTABLE:                         /* RemoveSortableComponent -> the default sortable component (objects/ecs.rs:210-213) */
+            if (u32set_has(&deleted, id)) break;
+            e->sortable = 0; break;
         case RO_CHANGE_DELETE:
             ro_tree_remove(w, id);
             u32set_del(&kinematics, id); u32set_del(&only_translation, id); u32set_add(&deleted, id);

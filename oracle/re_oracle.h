@@ -191,7 +191,11 @@ uint32_t ro_find_related(const ro_world *w, uint64_t key, uint32_t cap, uint64_t
 #define RO_CHANGE_WAKE_UP     3u
 #define RO_CHANGE_REMOVE_COMPONENT 4u   /* component = 1..6 (Rotation, Scale, Velocity, Acceleration, VelocityRotation, AccelerationRotation) */
 typedef struct { uint32_t kind, entity_id, component, pad; float value[4]; } ro_change;
+#define RO_CHANGE_ADD_ENTITY      5u   /* pad = index into `added` (ro_apply_changes_ex) */
+#define RO_CHANGE_ADD_SORTABLE    6u   /* component = sortable index */
+#define RO_CHANGE_REMOVE_SORTABLE 7u
 uint32_t ro_apply_changes(ro_world *w, const ro_change *changes, uint32_t n, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
+uint32_t ro_apply_changes_ex(ro_world *w, const ro_change *changes, uint32_t n, const ro_entity_desc *added, uint32_t n_added, int end_of_frame, uint32_t cap, uint32_t *oob_ids, uint32_t *n_oob);
 
 /* ---- config 5: deferred lighting, CPU evaluation of render_engine_assets/shaders/second_pass_frag.glsl:20-139 ----
  * Light uniform arrays as RenderSystem uploads them (render_system/render_system.rs:752-766, 814-830). */

@@ -53,7 +53,7 @@ CFG_FULL_REBUILD = 0x1
 CFG_TIGHT_SLACK = 0x2
 CFG_PROBE = 0x4
 CFG_PROBE_ALWAYS = 0x8
-CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP, CHANGE_REMOVE_COMPONENT = 0, 1, 2, 3, 4
+CHANGE_MODIFY, CHANGE_DELETE, CHANGE_MAKE_STATIC, CHANGE_WAKE_UP, CHANGE_REMOVE_COMPONENT, CHANGE_ADD_ENTITY, CHANGE_ADD_SORTABLE, CHANGE_REMOVE_SORTABLE = 0, 1, 2, 3, 4, 5, 6, 7
 # bit positions of re_ecs_bitset == registration order of the reference (ECS::new + LogicFlow::new)
 ECS_BIT = dict(TYPE_IDENTIFIER=0, CAN_CAUSE_COLLISIONS=2, HAS_MOVED=3, POSITION=4, VELOCITY=5, ACCELERATION=6, HAS_ROTATED=7, ROTATION=8, VELOCITY_ROTATION=9,
                ACCELERATION_ROTATION=10, SCALE=11, TRANSFORMATION=12, MODEL_ID=13, STATIC_AABB=15, ORIGINAL_AABB=16, ALWAYS_EXECUTE_LOGIC=20)
@@ -105,7 +105,7 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_set_model_lod", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_section_keys", "re_get_out_of_bounds", "re_get_stats",
+           "re_apply_changes", "re_apply_changes_ex", "re_add_entities", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_section_keys", "re_get_out_of_bounds", "re_get_stats",
            "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
@@ -164,6 +164,8 @@ def load():
     L.re_gather_wait.restype = C.c_int; L.re_gather_wait.argtypes = [vp, C.POINTER(Gathered)]
     L.re_collide.restype = C.c_int; L.re_collide.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.POINTER(C.c_uint32)]
     L.re_apply_changes.restype = C.c_int; L.re_apply_changes.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(TickResult)]
+    L.re_apply_changes_ex.restype = C.c_int; L.re_apply_changes_ex.argtypes = [vp, vp, C.c_uint32, C.POINTER(Entities), C.c_uint32, C.POINTER(TickResult)]
+    L.re_add_entities.restype = C.c_int; L.re_add_entities.argtypes = [vp, C.POINTER(Entities), _u32p]
     L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]
     L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]
     L.re_read_component.restype = C.c_int; L.re_read_component.argtypes = [vp, C.c_uint32, C.c_int, vp]

@@ -75,8 +75,22 @@ struct re_ctx {
     uint64_t dev_bytes = 0;
     uint32_t maxlevel = 0;
 
-    // rows
-    uint32_t n = 0, ndyn = 0;
+    // rows.  n = rows in use (every entity ever registered: removed ones keep their row, marked F_DEAD); row_cap = rows the per-entity columns hold
+    // (grown by ensure_row_capacity when entities are added after the upload); the ghost instances of the frozen static cache live in rows
+    // [ghost_base, ghost_base + ghost_cap) of the id / matrix columns, ghost_base == row_cap.  n_base / ndyn0: rows / dynamic entities of the upload
+    // (dynamic entity j < ndyn0 lives in row j; later ones sit in any row, listed in d_dyn_row), dyn_cap: slots of the dynamic table.
+    uint32_t n = 0, ndyn = 0, row_cap = 0, ghost_base = 0, n_base = 0, ndyn0 = 0, dyn_cap = 0;
+    std::unordered_map<uint32_t, uint32_t> id_extra;     // entities added after the upload (and ids reused after a removal): id -> row
+    std::unordered_map<uint32_t, uint32_t> dyn_extra;    // rows that got a slot of the dynamic table after the upload: row -> slot
+    std::unordered_map<GroupKey, uint32_t, GroupKeyHash> gmap;   // (ModelId, sortable) -> group class
+    uint32_t nslots_cap = 0;                             // InstanceRange capacity of the host result block(s)
+    struct AddKeys { uint8_t nk; bool is_static; uint64_t keys[8]; };
+    std::unordered_map<uint32_t, AddKeys> add_keys;      // rows an add batch created, with their section decision: consumed by rebucket() (TreeOp kind 4)
+    bool dyn_index(uint32_t r, uint32_t &j) const {      // slot of row r in the dynamic table
+        if (r < ndyn0) { j = r; return true; }
+        auto e = dyn_extra.find(r); if (e == dyn_extra.end()) return false;
+        j = e->second; return true;
+    }
     DevBuf<uint32_t> d_id, d_gclass, d_flags, d_row_cell;
     DevBuf<float> d_mat, d_pos, d_rot, d_scale;
     DevBuf<Aabb> d_aabb, d_orig;
@@ -89,7 +103,8 @@ struct re_ctx {
     std::vector<uint32_t> id_to_row;                     // otherwise, ids below 4n: direct table (rows are not in id order once the dynamic entities lead)
     std::vector<std::pair<uint32_t, uint32_t>> id_rows;  // otherwise (id, row) sorted by id
     bool row_of(uint32_t id, uint32_t *row) const {
-        if (ids_identity) { if (id >= n) return false; *row = id; return true; }
+        if (!id_extra.empty()) { auto e = id_extra.find(id); if (e != id_extra.end()) { *row = e->second; return true; } }
+        if (ids_identity) { if (id >= n_base) return false; *row = id; return true; }
         if (!id_to_row.empty()) { if (id >= id_to_row.size() || id_to_row[id] == 0xFFFFFFFFu) return false; *row = id_to_row[id]; return true; }
         auto p = std::lower_bound(id_rows.begin(), id_rows.end(), std::make_pair(id, 0u));
         if (p == id_rows.end() || p->first != id) return false;
@@ -300,7 +315,8 @@ static void free_world(re_ctx *c) {
     if (c->h_block) { (void)hipHostFree(c->h_block); c->h_block = nullptr; }      // one block: frame result, speculation word, tick counters, group table
     c->h_res = nullptr; c->h_ranges = nullptr; c->h_th = nullptr; c->h_spec = nullptr;
     c->d_spec.release(nullptr); c->pending.clear();
-    c->single_shard = false;
+    c->single_shard = false; c->id_extra.clear(); c->dyn_extra.clear(); c->gmap.clear(); c->add_keys.clear();
+    c->row_cap = c->ghost_base = c->n_base = c->ndyn0 = c->dyn_cap = 0;
     c->n = c->ndyn = c->ncells = c->nsh = 0; c->have_cull = false; c->cull_inflight = c->tick_inflight = false; c->deferred_pack = false;
 }
 
@@ -326,7 +342,7 @@ static RowArrays row_arrays(re_ctx *c) {
 
 // group class a row-pool entry carries for row r: hidden while the row is not to be drawn (removed, or made static after the cache froze)
 static inline uint32_t effective_gclass(const re_ctx *c, uint32_t r) {
-    if (r >= c->n) return c->h_ghost_gc[r - c->n];                            // a ghost instance keeps the group class it was cloned with
+    if (r >= c->ghost_base) return c->h_ghost_gc[r - c->ghost_base];          // a ghost instance keeps the group class it was cloned with
     return ((c->h_flags[r] & (F_DEAD | F_PHANTOM)) || c->h_uncached.count(r)) ? 0xFFFFFFFFu : c->h_gclass[r];      // (a halo replica is never drawn here)
 }
 // pool positions of row r (one: its section's segment or its shared section's) get the row's current effective group class
@@ -374,7 +390,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     auto cmp = [](const SortRec &a, const SortRec &b) { return a.key != b.key ? a.key < b.key : a.sub < b.sub; };
     if (!std::is_sorted(recs.begin(), recs.end(), cmp)) {
         // rows are the dynamic entities followed by the others, each part in upload order: two sorted runs in a key-ordered world
-        auto mid = std::partition_point(recs.begin(), recs.end(), [&](const SortRec &a) { return a.row < c->ndyn; });
+        auto mid = std::partition_point(recs.begin(), recs.end(), [&](const SortRec &a) { return a.row < c->ndyn0; });
         if (std::is_sorted(recs.begin(), mid, cmp) && std::is_sorted(mid, recs.end(), cmp)) std::inplace_merge(recs.begin(), mid, recs.end(), cmp);
         else std::sort(recs.begin(), recs.end(), cmp);
     }
@@ -511,7 +527,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     HIPCHK(c, c->d_cell_nstatic.alloc(ncells, acct)); HIPCHK(c, c->d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, c->d_cell_flags.alloc(ncells, acct));
     if (c->park_ready) { HIPCHK(c, c->park.d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, hipMemset(c->park.d_cell_stamp.p, 0, (size_t)std::max(ncells, 1u) * 4)); }   // the parked lane's stamps follow a rebuilt table (it is idle: rebuilds happen behind drain_other_lane)
     c->pool_used = (uint32_t)rows.size(); c->pool_cap = c->pool_used + ((c->cfg.flags & RE_CFG_TIGHT_SLACK) ? 96u : c->pool_used / 4u + 65536u);      // slack: re-bucket patches append relocated segments
-    HIPCHK(c, c->d_rows.alloc(c->pool_cap, acct)); HIPCHK(c, c->d_row_cell.alloc(n, acct));
+    HIPCHK(c, c->d_rows.alloc(c->pool_cap, acct)); HIPCHK(c, c->d_row_cell.alloc(std::max(n, c->row_cap), acct));
     HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
     HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));
     HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
@@ -611,6 +627,7 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
 }
 
 static int resolve(re_ctx *c);
+static int size_frame_buffers(re_ctx *c);
 // device tables of the per-model level-of-view bands: table 0 = "default bands", table t >= 1 = custom_lod[t - 1]; one table index per group class
 static int upload_lod_tables(re_ctx *c) {
     c->lod_tables_on = false;
@@ -644,7 +661,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     std::vector<float> rot((size_t)n * 4), scl((size_t)n * 3);
     std::vector<uint32_t> flags(n), gclass(n);
     std::vector<uint32_t> dyn_row; std::vector<float> dvel, dacc, drv, dra;
-    std::unordered_map<GroupKey, uint32_t, GroupKeyHash> gmap; std::vector<GroupKey> gkeys;
+    std::unordered_map<GroupKey, uint32_t, GroupKeyHash> &gmap = c->gmap; std::vector<GroupKey> gkeys;
     // Row order: the dynamic entities (Velocity or VelocityRotation) first, otherwise upload order.  Row j of every per-entity column then IS
     // dynamic entity j, and the tick reads and writes contiguous streams (k_tick) instead of gathering 12..64-byte pieces per entity.
     std::vector<uint32_t> perm; bool permuted = false;
@@ -711,10 +728,12 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     c->user_row = ROW_CELL_NONE; for (uint32_t r = 0; r < n; r++) if (flags[r] & F_USER) { c->user_row = r; break; }
     c->d_row_moved.release(nullptr); c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->col_moved_cap = 0;
     for (uint32_t f : flags) if (f & F_HAS_ROTVEL) { c->has_rotvel = true; break; }
-    c->ndyn = (uint32_t)dyn_row.size();
+    c->ndyn = c->ndyn0 = c->dyn_cap = (uint32_t)dyn_row.size();
     c->ngclass = (uint32_t)gkeys.size(); c->nslots = c->ngclass * 8u; c->h_gkeys = gkeys;
     hipStream_t st = c->stream;
-    c->ghost_cap = std::max(2048u, n / 8u);   // ghost instances of the frozen static cache (68 bytes each) c->n_ghost = 0; c->h_ghost_gc.clear(); c->ghost_map.clear(); c->dormant_cached.clear();
+    c->ghost_cap = std::max(2048u, n / 8u);   // ghost instances of the frozen static cache (68 bytes each)
+    c->n_ghost = 0; c->h_ghost_gc.clear(); c->ghost_map.clear(); c->dormant_cached.clear();      // (round 2 had these four resets inside the comment above: a second upload on a context that held ghosts kept them)
+    c->row_cap = c->ghost_base = c->n_base = n;
     HIPCHK(c, c->d_id.alloc((size_t)n + c->ghost_cap, acct)); HIPCHK(c, c->d_gclass.alloc(n, acct)); HIPCHK(c, c->d_flags.alloc(n, acct)); HIPCHK(c, c->d_mat.alloc(((size_t)n + c->ghost_cap) * 16, acct));
     HIPCHK(c, c->d_pos.alloc((size_t)n * 3, acct)); HIPCHK(c, c->d_rot.alloc((size_t)n * 4, acct)); HIPCHK(c, c->d_scale.alloc((size_t)n * 3, acct));
     HIPCHK(c, c->d_aabb.alloc(n, acct)); HIPCHK(c, c->d_orig.alloc(n, acct));
@@ -763,7 +782,7 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     }
     // TRS -> matrix, AABB, section keys on the GPU
     HIPCHK(c, hipMemsetAsync(c->d_counter.p, 0, 16, st));
-    if (n) hipLaunchKernelGGL(k_transform_assign, dim3((n + 255) / 256), dim3(256), 0, st, row_arrays(c), n, c->cfg.outline_length, c->cfg.atomic_length,
+    if (n) hipLaunchKernelGGL(k_transform_assign, dim3((n + 255) / 256), dim3(256), 0, st, row_arrays(c), 0u, n, c->cfg.outline_length, c->cfg.atomic_length,
                               c->d_row_key.p, c->d_row_nk.p, c->d_shrec.p, c->d_counter.p, n);
     HIPCHK(c, hipGetLastError());
     std::vector<uint64_t> row_key(n); std::vector<uint8_t> row_nk(n); uint32_t nshrec = 0;
@@ -786,18 +805,13 @@ extern "C" int re_upload_entities(re_ctx *c, const re_entities *E, uint32_t *n_r
     rc = upload_dyn_cells(c);
     if (rc != RE_OK) return rc;
     // frame buffers
-    c->out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
-    c->item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
-    if (n <= 65536u) c->item_cap = CURSOR_SHARDS * (2u * (n + std::max(2048u, n / 8u)) + 64u);   // a small world's sections sit in a few waves, i.e. in a few cursor shards: every segment holds the whole world incl. its ghost instances (twice: duplicates mode)
-    c->list_cap = std::max(std::max(c->ndyn, std::min(n, 65536u)), 1u);   // movers of one tick (dynamic rows) or of one change batch (any row)
-    // two instance lists, alternating by frame: a deferred pack (RE_CULL_DEFER_PACK) reads the list of frame f while the scan of frame f + 1 fills the other
-    HIPCHK(c, c->d_item_row.alloc((size_t)c->item_cap * 2, acct)); HIPCHK(c, c->d_item_slot.alloc((size_t)c->item_cap * 2, acct));
-    HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 8)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 8));   // the pack reads speculatively past the cursors
-    HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct));
-    HIPCHK(c, c->d_hdr.alloc(NUM_FRAME_HEADERS, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct)); HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct));
+    c->item_cap = c->out_cap = c->list_cap = 0;
+    { int rc2 = size_frame_buffers(c); if (rc2 != RE_OK) return rc2; }
+    HIPCHK(c, c->d_hdr.alloc(NUM_FRAME_HEADERS, acct)); HIPCHK(c, c->d_th.alloc(1, acct)); HIPCHK(c, c->d_params.alloc(1, acct));
     {
         void *hb = nullptr, *db = nullptr;
-        HIPCHK(c, alloc_host_block(c->nslots, &hb, &db));
+        c->nslots_cap = std::max(2u * c->nslots, 1024u);                           // head-room: entities added later may bring new (ModelId, sortable) groups
+        HIPCHK(c, alloc_host_block(c->nslots_cap, &hb, &db));
         c->h_block = hb;
         c->h_res = hb_at<HostResult>(hb, HB_RES); c->d_hres = hb_at<HostResult>(db, HB_RES);
         c->h_spec = hb_at<SpecState>(hb, HB_SPEC); c->d_hspec = hb_at<SpecState>(db, HB_SPEC);
@@ -1129,7 +1143,7 @@ static int ensure_second_lane(re_ctx *c) {
     HIPCHK(c, hipMemset(k.d_cell_stamp.p, 0, k.d_cell_stamp.n * 4));
     {
         void *hb = nullptr, *db = nullptr;
-        HIPCHK(c, alloc_host_block(c->nslots, &hb, &db));
+        HIPCHK(c, alloc_host_block(c->nslots_cap, &hb, &db));
         k.h_block = hb;
         k.h_res = hb_at<HostResult>(hb, HB_RES); k.d_hres = hb_at<HostResult>(db, HB_RES);
         k.h_ranges = hb_at<InstanceRange>(hb, HB_RANGES); k.d_hranges = hb_at<InstanceRange>(db, HB_RANGES);
@@ -1284,11 +1298,11 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
         // RE_CULL_DEFER_PACK: in a world without dynamic entities nothing changes what the pack reads before the next visibility query,
         // so an asynchronous frame may leave its pack to the launch of the next one (k_scan_cull_fused)
         if ((flags & RE_CULL_DEFER_PACK) && (flags & RE_CULL_ASYNC) && c->ndyn == 0 && !c->dirty_pending && !c->comm.comm) {
-            FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->lane_seq); F.nrows = c->n + c->ghost_cap;
+            FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->lane_seq); F.nrows = c->ghost_base + c->ghost_cap;
             c->deferred = F; c->deferred_grid = pgrid; c->deferred_pack = true;
         } else {
-            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->lane_seq), c->n + c->ghost_cap);
-            c->last_pack.kind = 1; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next; c->last_pack.A = A; c->last_pack.K = item_sink(c, c->lane_seq); c->last_pack.grid = pgrid; c->last_pack.nrows = c->n + c->ghost_cap;
+            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->lane_seq), c->ghost_base + c->ghost_cap);
+            c->last_pack.kind = 1; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next; c->last_pack.A = A; c->last_pack.K = item_sink(c, c->lane_seq); c->last_pack.grid = pgrid; c->last_pack.nrows = c->ghost_base + c->ghost_cap;
         }
     } else {
         int rc = launch_pack_large(c, hdr, hdr_next, count_in_scan);
@@ -1673,7 +1687,7 @@ static int sync_mirrors(re_ctx *c) {
         for (uint32_t k = 0; k < nl + ns; k++) {
             const uint32_t r = rows[offs[i] + k];
             c->h_rows[begin + k] = r;
-            if (r < c->n) { c->h_row_cell[r] = slot; c->h_row_key[r] = kn; c->h_row_nk[r] = 1; }
+            if (r < c->ghost_base) { c->h_row_cell[r] = slot; c->h_row_key[r] = kn; c->h_row_nk[r] = 1; }
         }
     }
     c->stale_slots.clear();
@@ -1803,7 +1817,7 @@ static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host
 // ------------------------------------------------------------------------------------------------
 // pre: tree operations an apply_change batch performs inline, before the kinematic re-adds (MakeObjectStatic / WakeUpRequest:
 // remove + add with the other static flag into the same section; DeleteRequest: remove only), in list order.
-struct TreeOp { uint32_t row; uint8_t kind; };                          // kind: 1 = make static, 2 = wake up, 3 = remove
+struct TreeOp { uint32_t row; uint8_t kind; };                          // kind: 1 = make static, 2 = wake up, 3 = remove, 4 = add (an entity of this batch: re_ctx::add_keys holds its section decision)
 static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre = nullptr, const std::set<uint64_t> *ghost_touched = nullptr) {
     hipStream_t st = c->stream;
     static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
@@ -1912,12 +1926,23 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     };
     if (pre) for (const TreeOp &op : *pre) {
         const uint32_t r = op.row;
+        if (op.kind == 4) {                                                  // apply_choices -> add_entity(id, aabb, false, is_static, ..): nothing to remove first; out of bounds -> not inserted
+            auto ak = c->add_keys.find(r);
+            if (ak != c->add_keys.end() && ak->second.nk) replay(r, false, ak->second.nk, ak->second.keys, ak->second.is_static);
+            continue;
+        }
         uint64_t cur[8] = {}; const uint32_t cnk = c->h_row_nk[r];
         if (cnk > 1) memcpy(cur, c->h_row_shared_keys[r].data(), sizeof cur); else cur[0] = c->h_row_key[r];
         if (op.kind == 3) replay(r, true, 0, nullptr, false);
         else if (cnk) replay(r, false, cnk, cur, op.kind == 1);            // same StaticAABB => same section(s)
     }
-    for (uint32_t i = 0; i < M; i++) replay(movers[i] & 0x7FFFFFFFu, false, nk[i], &nkeys[(size_t)i * 8], false);   // update_entity_in_tree: is_static = false (:330)
+    for (uint32_t i = 0; i < M; i++) {
+        const uint32_t r = movers[i] & 0x7FFFFFFFu;
+        // add_entity returns early for an entity that stays where it is (entity_exists_in_section, bounding_box_tree_v2.rs:765-782).  The device lists
+        // only entities that change section -- except an entity ADDED by this very batch and changed again in it: the device did not know its section yet.
+        if (nk[i] && c->h_row_nk[r] == nk[i] && (nk[i] == 1 ? c->h_row_key[r] == nkeys[(size_t)i * 8] : memcmp(c->h_row_shared_keys[r].data(), &nkeys[(size_t)i * 8], (size_t)nk[i] * 8) == 0) && c->add_keys.count(r)) continue;
+        replay(r, false, nk[i], &nkeys[(size_t)i * 8], false);               // update_entity_in_tree: is_static = false (:330)
+    }
     // a hidden (made-static-after-the-cache-froze) row that a re-add turned non-static again is drawn again
     std::vector<uint32_t> reveal;
     for (auto it = c->h_uncached.begin(); it != c->h_uncached.end();) { if (!(c->h_flags[*it] & F_STATIC)) { reveal.push_back(*it); it = c->h_uncached.erase(it); } else ++it; }
@@ -2031,7 +2056,8 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
         if (c->k1_timing && c->k1_kind == RE_TIME_TICK) take_timing_events(c, &ta, &tb);
         hipExtLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, ta, tb, 0, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
-                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame);
+                           (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame,
+                           c->ndyn0, c->d_dyn_row.p);
         c->th_clean = false;
         c->tick_published = !(flags & RE_TICK_ASYNC);
         if (c->tick_published) hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
@@ -2111,6 +2137,222 @@ static int resolve(re_ctx *c) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Entities added after the upload: Pipeline::register_model_instances at any time (flows/pipeline.rs:186-208) and the AddEntity arm of
+// apply_change (helper_things/entity_change_helpers.rs:48-107).  A new entity takes the next row of the per-entity columns (grown in
+// place, amortised: ensure_row_capacity), a slot of the dynamic table when it carries Velocity / VelocityRotation (k_tick reaches rows
+// outside the leading block through d_dyn_row), possibly a new (ModelId, sortable) group class (regrow_groups), and enters the tree through
+// the same re-bucket as a mover -- an add_entity without the remove_entity in front of it (rebucket(): TreeOp kind 4).
+// ------------------------------------------------------------------------------------------------
+template <typename T> static hipError_t grow_buf(DevBuf<T> &b, size_t keep, size_t count, uint64_t *acct, hipStream_t st) {
+    DevBuf<T> nb; hipError_t e = nb.alloc(count, acct);
+    if (e != hipSuccess) return e;
+    if (keep && b.p) { e = hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, st); if (e == hipSuccess) e = sync_stream(st); }
+    if (e != hipSuccess) { nb.release(acct); return e; }
+    b.release(acct); b = nb;
+    return hipSuccess;
+}
+// per-frame buffers whose size follows the number of rows: instance lists, packed output (when the caller gave no capacity), mover / out-of-bounds lists
+static int size_frame_buffers(re_ctx *c) {
+    uint64_t *acct = &c->dev_bytes;
+    const uint32_t n = c->row_cap;
+    const uint32_t out_cap = c->cfg.max_instances ? c->cfg.max_instances : std::max(n, 1u);
+    uint32_t item_cap = (std::max(4u * n, 64u) + 64u * CURSOR_SHARDS) / CURSOR_SHARDS * CURSOR_SHARDS;   // 2n instances (duplicates mode) with 2x head-room per cursor segment
+    if (n <= 65536u) item_cap = CURSOR_SHARDS * (2u * (n + std::max(2048u, n / 8u)) + 64u);   // a small world's sections sit in a few waves, i.e. in a few cursor shards: every segment holds the whole world incl. its ghost instances (twice: duplicates mode)
+    const uint32_t list_cap = std::max(std::max(c->dyn_cap, std::min(n, 65536u)), 1u);   // movers of one tick (dynamic rows) or of one change batch (any row)
+    if (item_cap > c->item_cap || !c->d_item_row.p) {
+        // two instance lists, alternating by frame: a deferred pack (RE_CULL_DEFER_PACK) reads the list of frame f while the scan of frame f + 1 fills the other
+        c->item_cap = item_cap;
+        HIPCHK(c, c->d_item_row.alloc((size_t)c->item_cap * 2, acct)); HIPCHK(c, c->d_item_slot.alloc((size_t)c->item_cap * 2, acct));
+        HIPCHK(c, hipMemset(c->d_item_row.p, 0, (size_t)c->item_cap * 8)); HIPCHK(c, hipMemset(c->d_item_slot.p, 0xFF, (size_t)c->item_cap * 8));   // the pack reads speculatively past the cursors
+    }
+    if (out_cap > c->out_cap || !c->d_out_ids.p) { c->out_cap = out_cap; HIPCHK(c, c->d_out_ids.alloc(c->out_cap, acct)); HIPCHK(c, c->d_out_mats.alloc((size_t)c->out_cap * 16, acct)); }
+    if (list_cap > c->list_cap || !c->d_movers.p) { c->list_cap = list_cap; HIPCHK(c, c->d_movers.alloc(c->list_cap, acct)); HIPCHK(c, c->d_oob.alloc(c->list_cap, acct)); }
+    return RE_OK;
+}
+static int ensure_row_capacity(re_ctx *c, uint32_t need) {
+    if (need <= c->row_cap) return RE_OK;
+    if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
+    hipStream_t st = c->stream; uint64_t *a = &c->dev_bytes;
+    HIPCHK(c, sync_stream(st));
+    const uint32_t old_cap = c->row_cap, new_cap = std::max(need, old_cap + old_cap / 4u + 1024u), n = c->n;
+    const uint32_t new_ghost_cap = std::max(c->ghost_cap, std::max(2048u, new_cap / 8u));
+    HIPCHK(c, grow_buf(c->d_gclass, n, new_cap, a, st)); HIPCHK(c, grow_buf(c->d_flags, n, new_cap, a, st));
+    HIPCHK(c, grow_buf(c->d_pos, (size_t)n * 3, (size_t)new_cap * 3, a, st)); HIPCHK(c, grow_buf(c->d_rot, (size_t)n * 4, (size_t)new_cap * 4, a, st)); HIPCHK(c, grow_buf(c->d_scale, (size_t)n * 3, (size_t)new_cap * 3, a, st));
+    HIPCHK(c, grow_buf(c->d_aabb, n, new_cap, a, st)); HIPCHK(c, grow_buf(c->d_orig, n, new_cap, a, st));
+    HIPCHK(c, grow_buf(c->d_row_cell, n, new_cap, a, st));
+    HIPCHK(c, hipMemsetAsync(c->d_row_cell.p + n, 0xFF, (size_t)(new_cap - n) * 4, st));                  // ROW_CELL_NONE: not in the tree
+    {   // id / matrix columns: rows, then the ghost instances behind the row capacity
+        DevBuf<uint32_t> nid; DevBuf<float> nmat;
+        HIPCHK(c, nid.alloc((size_t)new_cap + new_ghost_cap, a)); HIPCHK(c, nmat.alloc(((size_t)new_cap + new_ghost_cap) * 16, a));
+        if (n) { HIPCHK(c, hipMemcpyAsync(nid.p, c->d_id.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st)); HIPCHK(c, hipMemcpyAsync(nmat.p, c->d_mat.p, (size_t)n * 64, hipMemcpyDeviceToDevice, st)); }
+        if (c->n_ghost) {
+            HIPCHK(c, hipMemcpyAsync(nid.p + new_cap, c->d_id.p + old_cap, (size_t)c->n_ghost * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHK(c, hipMemcpyAsync(nmat.p + (size_t)new_cap * 16, c->d_mat.p + (size_t)old_cap * 16, (size_t)c->n_ghost * 64, hipMemcpyDeviceToDevice, st));
+        }
+        HIPCHK(c, sync_stream(st));
+        c->d_id.release(a); c->d_mat.release(a); c->d_id = nid; c->d_mat = nmat;
+    }
+    if (c->n_ghost) {                                                        // the row pool names ghost instances by row: they moved up with the capacity
+        const uint32_t delta = new_cap - old_cap;
+        if (c->pool_used) hipLaunchKernelGGL(k_shift_rows, dim3((c->pool_used + 255) / 256), dim3(256), 0, st, c->pool_used, c->d_rows.p, old_cap, delta);
+        for (uint32_t i = 0; i < c->pool_used && i < c->h_rows.size(); i++) if (c->h_rows[i] >= old_cap && c->h_rows[i] != 0xFFFFFFFFu) c->h_rows[i] += delta;
+        for (auto &kv : c->ghost_map) for (uint32_t &g : kv.second) g += delta;
+        HIPCHK(c, hipGetLastError()); HIPCHK(c, sync_stream(st));
+    }
+    c->row_cap = c->ghost_base = new_cap; c->ghost_cap = new_ghost_cap;
+    c->last_pack.kind = 0;                                                   // (what the last pack was launched with names the old columns)
+    c->d_row_moved.release(nullptr); c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->col_moved_cap = 0;   // collision scratch: sized at its next use
+    return size_frame_buffers(c);
+}
+static int ensure_dyn_capacity(re_ctx *c, uint32_t need) {
+    if (need <= c->dyn_cap) return RE_OK;
+    hipStream_t st = c->stream; uint64_t *a = &c->dev_bytes;
+    HIPCHK(c, sync_stream(st));
+    const uint32_t new_cap = std::max(need, c->dyn_cap + c->dyn_cap / 4u + 256u), k = c->ndyn;
+    HIPCHK(c, grow_buf(c->d_dyn_row, k, new_cap, a, st)); HIPCHK(c, grow_buf(c->d_dyn_vel, (size_t)k * 3, (size_t)new_cap * 3, a, st)); HIPCHK(c, grow_buf(c->d_dyn_acc, (size_t)k * 3, (size_t)new_cap * 3, a, st));
+    HIPCHK(c, grow_buf(c->d_dyn_rotvel, (size_t)k * 4, (size_t)new_cap * 4, a, st)); HIPCHK(c, grow_buf(c->d_dyn_rotacc, (size_t)k * 4, (size_t)new_cap * 4, a, st));
+    c->dyn_cap = new_cap;
+    c->col_moved_cap = 0; c->d_col_moved.release(nullptr); c->d_col_tab.release(nullptr); c->d_row_moved.release(nullptr);
+    return size_frame_buffers(c);
+}
+// a slot of the dynamic table for a row that had none (an added entity with a velocity, or Velocity written to an entity registered without one:
+// the reference registers the component on write, objects/entity_change_request.rs:29-30); the velocities start as the defaults of the upload
+static int alloc_dyn_slot(re_ctx *c, uint32_t row, uint32_t *slot) {
+    uint32_t j = 0;
+    if (c->dyn_index(row, j)) { *slot = j; return RE_OK; }
+    { int rc = ensure_dyn_capacity(c, c->ndyn + 1u); if (rc != RE_OK) return rc; }
+    j = c->ndyn++;
+    const float z3[3] = { 0.f, 0.f, 0.f }, ax[4] = { 1.f, 0.f, 0.f, 0.f };
+    HIPCHK(c, hipMemcpy(c->d_dyn_row.p + j, &row, 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dyn_vel.p + (size_t)j * 3, z3, 12, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->d_dyn_acc.p + (size_t)j * 3, z3, 12, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_dyn_rotvel.p + (size_t)j * 4, ax, 16, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->d_dyn_rotacc.p + (size_t)j * 4, ax, 16, hipMemcpyHostToDevice));
+    c->h_dyn_row.push_back(row); c->dyn_extra[row] = j;
+    *slot = j;
+    return RE_OK;
+}
+// group class of a (ModelId, sortable) pair; a new pair is appended to the host table (*grew) and reaches the device with regrow_groups
+static uint32_t group_class_of(re_ctx *c, const GroupKey &gk, bool *grew) {
+    auto it = c->gmap.find(gk);
+    if (it != c->gmap.end()) return it->second;
+    const uint32_t g = (uint32_t)c->h_gkeys.size();
+    c->gmap.emplace(gk, g); c->h_gkeys.push_back(gk); *grew = true;
+    return g;
+}
+static int upload_lod_tables(re_ctx *c);
+static int regrow_groups(re_ctx *c) {
+    uint64_t *acct = &c->dev_bytes; hipStream_t st = c->stream;
+    if (c->park_ready) { (void)drain_other_lane(c); free_second_lane(c); }
+    HIPCHK(c, sync_stream(st));
+    c->ngclass = (uint32_t)c->h_gkeys.size(); c->nslots = c->ngclass * 8u;
+    std::vector<uint32_t> gm(c->ngclass + 1), gr(c->ngclass + 1), gs(c->ngclass + 1);
+    for (uint32_t g = 0; g < c->ngclass; g++) { gm[g] = c->h_gkeys[g].model; gr[g] = c->h_gkeys[g].rs; gs[g] = c->h_gkeys[g].sort; }
+    HIPCHK(c, c->d_gc_model.alloc(c->ngclass, acct)); HIPCHK(c, c->d_gc_rs.alloc(c->ngclass, acct)); HIPCHK(c, c->d_gc_sort.alloc(c->ngclass, acct));
+    HIPCHK(c, c->d_group_count.alloc(c->nslots, acct)); HIPCHK(c, c->d_group_begin.alloc(c->nslots, acct)); HIPCHK(c, c->d_group_fill.alloc(c->nslots, acct));
+    HIPCHK(c, hipMemcpy(c->d_gc_model.p, gm.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice)); HIPCHK(c, hipMemcpy(c->d_gc_rs.p, gr.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_gc_sort.p, gs.data(), (size_t)c->ngclass * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->d_group_count.p, 0, (size_t)std::max(c->nslots, 1u) * 4)); HIPCHK(c, hipMemset(c->d_group_fill.p, 0, (size_t)std::max(c->nslots, 1u) * 4));
+    c->d_gcount.release(acct); c->d_gfill.release(acct); c->gc_dirty[0] = c->gc_dirty[1] = false;
+    if (c->nslots <= COUNT_SLOTS_MAX) {
+        const size_t words = 2u * CURSOR_SHARDS * (size_t)std::max(c->nslots, 1u);
+        HIPCHK(c, c->d_gcount.alloc(words, acct)); HIPCHK(c, c->d_gfill.alloc(words, acct));
+        HIPCHK(c, hipMemset(c->d_gcount.p, 0, words * 4)); HIPCHK(c, hipMemset(c->d_gfill.p, 0, words * 4));
+    }
+    if (c->nslots > c->nslots_cap) {                                        // the InstanceRange table of the result block
+        void *hb = nullptr, *db = nullptr;
+        const uint32_t cap = std::max(2u * c->nslots, 1024u);
+        HIPCHK(c, alloc_host_block(cap, &hb, &db));
+        memcpy(hb, c->h_block, HB_RANGES);                                  // frame result, speculation word, tick counters as they are
+        (void)hipHostFree(c->h_block);
+        c->h_block = hb; c->nslots_cap = cap;
+        c->h_res = hb_at<HostResult>(hb, HB_RES); c->d_hres = hb_at<HostResult>(db, HB_RES);
+        c->h_spec = hb_at<SpecState>(hb, HB_SPEC); c->d_hspec = hb_at<SpecState>(db, HB_SPEC);
+        c->h_th = hb_at<TickHeader>(hb, HB_TICK); c->d_hth = hb_at<TickHeader>(db, HB_TICK);
+        c->h_ranges = hb_at<InstanceRange>(hb, HB_RANGES); c->d_hranges = hb_at<InstanceRange>(db, HB_RANGES);
+    }
+    c->last_pack.kind = 0;
+    return upload_lod_tables(c);
+}
+
+// The rows of an add batch: entity E[src] becomes row `row` (consecutive from c->n).  Columns staged and copied, TransformationMatrix / StaticAABB /
+// section decision on the device (the upload's kernel over the new row range), host mirrors extended; the tree does not know them yet (add_keys).
+struct NewRow { uint32_t src, row; };
+static int create_rows(re_ctx *c, const re_entities *E, const std::vector<NewRow> &rows, uint32_t *n_rejected) {
+    const uint32_t m = (uint32_t)rows.size(), row0 = c->n;
+    if (n_rejected) *n_rejected = 0;
+    if (!m) return RE_OK;
+    hipStream_t st = c->stream;
+    { int rc = ensure_row_capacity(c, row0 + m); if (rc != RE_OK) return rc; }
+    std::vector<uint32_t> ids(m), gcl(m), fls(m); std::vector<float> pos((size_t)m * 3), rot((size_t)m * 4), scl((size_t)m * 3), orig((size_t)m * 6);
+    struct Dyn { uint32_t k; float v[3], a[3], rv[4], ra[4]; }; std::vector<Dyn> dyn;
+    bool grew = false;
+    for (uint32_t k = 0; k < m; k++) {
+        const size_t i = rows[k].src;
+        uint32_t fl = E->flags[i] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
+        if (fl & F_PHANTOM) fl &= ~(F_HAS_VEL | F_HAS_ACC | F_HAS_ROTVEL | F_HAS_ROTACC | F_ALWAYS_EXEC | F_USER | F_LIGHT_ANY);
+        if ((fl & F_HAS_ROT) && !E->rotation) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_ROT but rotation == NULL", (uint32_t)i);
+        if ((fl & F_HAS_SCALE) && !E->scale) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_SCALE but scale == NULL", (uint32_t)i);
+        if ((fl & F_HAS_VEL) && !E->velocity) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_VEL but velocity == NULL", (uint32_t)i);
+        if ((fl & F_HAS_ACC) && !E->acceleration) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_ACC but acceleration == NULL", (uint32_t)i);
+        if ((fl & F_HAS_ROTVEL) && !E->rotation_velocity) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_ROTVEL but rotation_velocity == NULL", (uint32_t)i);
+        if ((fl & F_HAS_ROTACC) && !E->rotation_acceleration) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_ROTACC but rotation_acceleration == NULL", (uint32_t)i);
+        ids[k] = E->entity_id[i]; fls[k] = fl;
+        memcpy(&pos[(size_t)k * 3], E->position + i * 3, 12); memcpy(&orig[(size_t)k * 6], E->original_aabb + i * 6, 24);
+        if (fl & F_HAS_ROT) { const float *a = E->rotation + i * 4; const float nn = norm3(a[0], a[1], a[2]); rot[k * 4 + 0] = a[0] / nn; rot[k * 4 + 1] = a[1] / nn; rot[k * 4 + 2] = a[2] / nn; rot[k * 4 + 3] = a[3]; }
+        else { rot[k * 4 + 0] = 1.f; rot[k * 4 + 1] = rot[k * 4 + 2] = rot[k * 4 + 3] = 0.f; }
+        if (fl & F_HAS_SCALE) memcpy(&scl[(size_t)k * 3], E->scale + i * 3, 12); else scl[k * 3 + 0] = scl[k * 3 + 1] = scl[k * 3 + 2] = 1.f;
+        gcl[k] = group_class_of(c, GroupKey{ E->model_index[i], E->render_system ? E->render_system[i] : 0u, E->sortable ? E->sortable[i] : 0u }, &grew);
+        if (fl & (F_HAS_VEL | F_HAS_ROTVEL)) {
+            Dyn d{}; d.k = k; d.rv[0] = d.ra[0] = 1.f;
+            for (int q = 0; q < 3; q++) { d.v[q] = (fl & F_HAS_VEL) ? E->velocity[i * 3 + q] : 0.f; d.a[q] = (fl & F_HAS_ACC) ? E->acceleration[i * 3 + q] : 0.f; }
+            if (fl & F_HAS_ROTVEL) { const float *a = E->rotation_velocity + i * 4; const float nn = norm3(a[0], a[1], a[2]); d.rv[0] = a[0] / nn; d.rv[1] = a[1] / nn; d.rv[2] = a[2] / nn; d.rv[3] = a[3]; }
+            if (fl & F_HAS_ROTACC) { const float *a = E->rotation_acceleration + i * 4; const float nn = norm3(a[0], a[1], a[2]); d.ra[0] = a[0] / nn; d.ra[1] = a[1] / nn; d.ra[2] = a[2] / nn; d.ra[3] = a[3]; }
+            dyn.push_back(d);
+        }
+    }
+    if (grew) { int rc = regrow_groups(c); if (rc != RE_OK) return rc; }
+    HIPCHK(c, hipMemcpyAsync(c->d_id.p + row0, ids.data(), (size_t)m * 4, hipMemcpyHostToDevice, st)); HIPCHK(c, hipMemcpyAsync(c->d_gclass.p + row0, gcl.data(), (size_t)m * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_flags.p + row0, fls.data(), (size_t)m * 4, hipMemcpyHostToDevice, st)); HIPCHK(c, hipMemcpyAsync(c->d_pos.p + (size_t)row0 * 3, pos.data(), (size_t)m * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_rot.p + (size_t)row0 * 4, rot.data(), (size_t)m * 16, hipMemcpyHostToDevice, st)); HIPCHK(c, hipMemcpyAsync(c->d_scale.p + (size_t)row0 * 3, scl.data(), (size_t)m * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->d_orig.p + row0, orig.data(), (size_t)m * 24, hipMemcpyHostToDevice, st));
+    // TRS -> matrix, AABB, section decision: the upload's kernel over the new rows
+    DevBuf<uint64_t> d_key; DevBuf<uint8_t> d_nk; DevBuf<SharedRec> d_sr; DevBuf<uint32_t> d_cnt;
+    auto done = [&](int rc) { d_key.release(nullptr); d_nk.release(nullptr); d_sr.release(nullptr); d_cnt.release(nullptr); return rc; };
+    if (d_key.alloc(m, nullptr) != hipSuccess || d_nk.alloc(m, nullptr) != hipSuccess || d_sr.alloc(m, nullptr) != hipSuccess || d_cnt.alloc(4, nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "create_rows: out of device memory"));
+    (void)hipMemsetAsync(d_cnt.p, 0, 16, st);
+    hipLaunchKernelGGL(k_transform_assign, dim3((m + 255) / 256), dim3(256), 0, st, row_arrays(c), row0, m, c->cfg.outline_length, c->cfg.atomic_length, d_key.p, d_nk.p, d_sr.p, d_cnt.p, m);
+    std::vector<uint64_t> key(m); std::vector<uint8_t> nk(m); uint32_t nsr = 0;
+    (void)hipMemcpyAsync(key.data(), d_key.p, (size_t)m * 8, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(nk.data(), d_nk.p, m, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(&nsr, d_cnt.p, 4, hipMemcpyDeviceToHost, st);
+    if (hipGetLastError() != hipSuccess || sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "create_rows: kernel / copy failed"));
+    std::vector<SharedRec> sr(std::min(nsr, m));
+    if (!sr.empty() && hipMemcpy(sr.data(), d_sr.p, sr.size() * sizeof(SharedRec), hipMemcpyDeviceToHost) != hipSuccess) return done(c->fail(RE_E_HIP, "create_rows: copy failed"));
+    // the dynamic table
+    for (const Dyn &d : dyn) {
+        uint32_t j = 0; int rc = alloc_dyn_slot(c, row0 + d.k, &j); if (rc != RE_OK) return done(rc);
+        if (hipMemcpy(c->d_dyn_vel.p + (size_t)j * 3, d.v, 12, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_dyn_acc.p + (size_t)j * 3, d.a, 12, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->d_dyn_rotvel.p + (size_t)j * 4, d.rv, 16, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->d_dyn_rotacc.p + (size_t)j * 4, d.ra, 16, hipMemcpyHostToDevice) != hipSuccess) return done(c->fail(RE_E_HIP, "create_rows: copy failed"));
+    }
+    // host mirrors
+    uint32_t rejected = 0;
+    for (uint32_t k = 0; k < m; k++) {
+        const uint32_t r = row0 + k;
+        c->h_id.push_back(ids[k]); c->h_flags.push_back(fls[k] & ~F_STATIC); c->h_gclass.push_back(gcl[k]);      // (the static bit follows the tree replay)
+        c->h_row_key.push_back(0); c->h_row_nk.push_back(0); c->h_row_cell.push_back(ROW_CELL_NONE);
+        c->id_extra[ids[k]] = r;
+        if (fls[k] & F_LIGHT_ANY) { c->h_light_rows.push_back(r); c->light_rows_dirty = true; }
+        if (fls[k] & F_PHANTOM) c->n_phantom++;
+        if ((fls[k] & F_USER) && c->user_row == ROW_CELL_NONE) c->user_row = r;
+        if (fls[k] & F_HAS_ROTVEL) c->has_rotvel = true;
+        re_ctx::AddKeys ak{}; ak.nk = nk[k]; ak.keys[0] = key[k]; ak.is_static = (fls[k] & F_STATIC) != 0;
+        if (!nk[k]) rejected++;
+        c->add_keys[r] = ak;
+    }
+    for (const SharedRec &q : sr) { auto it = c->add_keys.find(q.row); if (it != c->add_keys.end()) memcpy(it->second.keys, q.keys, sizeof q.keys); }
+    c->n += m;
+    if (n_rejected) *n_rejected = rejected;
+    return done(RE_OK);
+}
+
+// ------------------------------------------------------------------------------------------------
 // re_apply_changes == apply_change (helper_things/entity_change_helpers.rs:32-189) for the change requests user logic returns
 // (LogicFunction / CollisionFunction -> Vec<EntityChangeInformation>): ModifyRequest of the kinematic components, DeleteRequest,
 // MakeObjectStatic, WakeUpRequest.  The list is replayed on the host exactly as the reference does it (the three HashSets of
@@ -2118,12 +2360,13 @@ static int resolve(re_ctx *c) {
 // AABBs / section decisions run on the GPU (k_write_components, k_apply_rows = the tail of the tick kernel), and the tree is
 // patched by the same re-bucket as after a tick.
 // ------------------------------------------------------------------------------------------------
-extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out) try {
-    if (!c) return RE_E_ARG;
+// in_frame: the batch belongs to a frame's logic phase (apply_change); false: Pipeline::register_model_instances between frames (re_add_entities) -- the
+// changed-static set then survives until the next render, which re-caches those sections.
+static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, const re_entities *added, re_tick_result *out, bool in_frame) {
     if (!c->h_res) return c->fail(RE_E_STATE, "re_apply_changes: no world uploaded");
     if (n && !changes) return c->fail(RE_E_ARG, "re_apply_changes: changes is NULL");
-    if (!c->have_cull) return c->fail(RE_E_STATE, "re_apply_changes: apply_change runs inside a frame, after its render (flows/pipeline.rs:212-271); call re_cull_pack first");
-    (void)flags;
+    if (in_frame && !c->have_cull) return c->fail(RE_E_STATE, "re_apply_changes: apply_change runs inside a frame, after its render (flows/pipeline.rs:212-271); call re_cull_pack first");
+    if (added && added->n && (!added->entity_id || !added->model_index || !added->flags || !added->original_aabb || !added->position)) return c->fail(RE_E_ARG, "re_apply_changes: added entities miss a required array");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
@@ -2137,18 +2380,20 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
         auto &f = flag_ops.emplace(r, std::make_pair(0xFFFFFFFFu, 0u)).first->second;
         f.first &= ~clear; f.second = (f.second & ~clear) | set;
     };
-    auto dyn_index = [&](uint32_t r, uint32_t &j) -> bool {
-        auto p = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), r);
-        if (p == c->h_dyn_row.end() || *p != r) return false;
-        j = (uint32_t)(p - c->h_dyn_row.begin()); return true;
-    };
+    auto dyn_index = [&](uint32_t r, uint32_t &j) -> bool { return c->dyn_index(r, j); };
     auto normalized = [](const float *v) { std::array<float, 4> o; float nn = norm3(v[0], v[1], v[2]); o[0] = v[0] / nn; o[1] = v[1] / nn; o[2] = v[2] / nn; o[3] = v[3]; return o; };
     // The static render cache of the reference is a snapshot that the logic phase can never refresh (render_flow.rs:549-594 reads
     // changed_static_unique, which pipeline.rs:271 clears before the next render): a cached static entity that is woken, deleted,
     // moved or rewritten stays in the picture with its old bytes, and an entity made static later is never drawn.  Both are
     // modelled: the first as a ghost instance parked in the caching section, the second by hiding the row's group class.
+    // entities this batch adds (RE_CHANGE_ADD_ENTITY): they take rows c->n, c->n + 1, ... when the list has been validated; until then the rows are
+    // only planned, and everything below that looks at a row's flags goes through flags_of
+    std::vector<NewRow> new_rows; std::vector<uint32_t> new_flags; std::unordered_map<uint32_t, uint32_t> new_ids;
+    auto flags_of = [&](uint32_t r) -> uint32_t { return r < c->n ? c->h_flags[r] : new_flags[r - c->n]; };
+    std::set<uint32_t> dyn_alloc;                                             // rows that need a slot of the dynamic table (a velocity-type component written to an entity registered without one)
+    std::map<uint32_t, uint32_t> sortable_ops;                                // row -> sortable index (Add / RemoveSortableComponent, last one wins)
     std::map<uint32_t, bool> is_static;                                       // static bit as the batch evolves (the host mirror changes during the replay)
-    auto stat = [&](uint32_t r) -> bool & { auto it = is_static.find(r); if (it == is_static.end()) it = is_static.emplace(r, (c->h_flags[r] & F_STATIC) != 0).first; return it->second; };
+    auto stat = [&](uint32_t r) -> bool & { auto it = is_static.find(r); if (it == is_static.end()) it = is_static.emplace(r, (flags_of(r) & F_STATIC) != 0).first; return it->second; };
     std::set<uint32_t> hide, unhide; bool new_rotvel = false;
     auto uncached = [&](uint32_t r) { return (c->h_uncached.count(r) && !unhide.count(r)) || hide.count(r); };
     // First touch of a static entity that the frozen cache holds: plan a ghost instance (a copy of id + matrix as they are now,
@@ -2158,6 +2403,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     std::set<uint32_t> ghosted; std::set<uint64_t> shared_ghost_owners;      // sections that park a ghost of a shared section's static member
     std::vector<int32_t> sh_owner_h; std::vector<uint8_t> sh_cached_h, cell_flags_h;
     auto plan_ghost = [&](uint32_t r) -> int {
+        if (r >= c->n) return RE_OK;                                            // an entity this batch added: no cache entry can hold it
         if (ghosted.count(r)) return RE_OK;
         ghosted.insert(r); hide.insert(r);
         if (c->h_row_nk[r] == 1) {                                              // cached by its own section -- unless that lay beyond the draw distance when the cache froze (an empty entry)
@@ -2179,8 +2425,25 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     for (uint32_t i = 0; i < n; i++) {
         const re_change &ch = changes[i];
         uint32_t r = 0;
-        if (!c->row_of(ch.entity_id, &r)) return c->fail(RE_E_ARG, "re_apply_changes: unknown entity %u (change %u)", ch.entity_id, i);
-        if ((c->h_flags[r] & F_DEAD) || (deleted.count(r) && ch.kind != RE_CHANGE_MODIFY)) continue;   // removed earlier (out of bounds or deleted)
+        if (ch.kind == RE_CHANGE_ADD_ENTITY) {
+            // AddEntity (entity_change_helpers.rs:48-107): create_entity + apply_choices -- components, matrix, StaticAABB, add_entity(.., false, is_static) -- inline, in list order
+            if (!added || ch.reserved >= added->n) return c->fail(RE_E_ARG, "re_apply_changes: change %u adds entity %u of %u", i, ch.reserved, added ? added->n : 0u);
+            const uint32_t id = added->entity_id[ch.reserved];
+            if (ch.entity_id != id) return c->fail(RE_E_ARG, "re_apply_changes: change %u names entity %u, the entity it adds has id %u", i, ch.entity_id, id);
+            uint32_t r0 = 0;
+            if (new_ids.count(id) || (c->row_of(id, &r0) && !(c->h_flags[r0] & F_DEAD) && !deleted.count(r0))) return c->fail(RE_E_ARG, "re_apply_changes: entity id %u is in use (change %u)", id, i);
+            r = c->n + (uint32_t)new_rows.size();
+            uint32_t fl = added->flags[ch.reserved] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
+            if (fl & F_PHANTOM) fl &= ~(F_HAS_VEL | F_HAS_ACC | F_HAS_ROTVEL | F_HAS_ROTACC | F_ALWAYS_EXEC | F_USER | F_LIGHT_ANY);
+            new_rows.push_back(NewRow{ ch.reserved, r }); new_flags.push_back(fl); new_ids[id] = r;
+            pre.push_back({ r, 4 });
+            is_static[r] = (fl & F_STATIC) != 0;
+            if ((fl & F_STATIC) && in_frame) hide.insert(r);                   // static after the cache froze: in the tree's static set, drawn only once its section is re-cached
+            if (fl & F_HAS_ROTVEL) new_rotvel = true;
+            continue;
+        }
+        { auto nr = new_ids.find(ch.entity_id); if (nr != new_ids.end()) r = nr->second; else if (!c->row_of(ch.entity_id, &r)) return c->fail(RE_E_ARG, "re_apply_changes: unknown entity %u (change %u)", ch.entity_id, i); }
+        if ((flags_of(r) & F_DEAD) || (deleted.count(r) && ch.kind != RE_CHANGE_MODIFY)) continue;   // removed earlier (out of bounds or deleted)
         switch (ch.kind) {
             case RE_CHANGE_MODIFY: {
                 if (deleted.count(r)) break;                                   // :281-284
@@ -2191,7 +2454,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
                     case RE_C_ROTATION: rot = true; v = normalized(ch.value); flag_op(r, 0, F_HAS_ROT); break;       // Rotation::new normalises the axis (movement_components.rs:108-118)
                     case RE_C_SCALE: scl = true; flag_op(r, 0, F_HAS_SCALE); break;
                     case RE_C_VELOCITY: case RE_C_ACCELERATION: case RE_C_ROTATION_VEL: case RE_C_ROTATION_ACC:
-                        if (!dyn_index(r, j)) return c->fail(RE_E_UNSUPPORTED, "re_apply_changes: entity %u was uploaded without Velocity / VelocityRotation; it has no slot in the dynamic table", ch.entity_id);
+                        if (!dyn_index(r, j) && !(r >= c->n && (flags_of(r) & (F_HAS_VEL | F_HAS_ROTVEL)))) dyn_alloc.insert(r);   // registered on write (objects/entity_change_request.rs:29-30): a slot of the dynamic table
                         if (ch.component == RE_C_ROTATION_VEL || ch.component == RE_C_ROTATION_ACC) v = normalized(ch.value);
                         flag_op(r, 0, ch.component == RE_C_VELOCITY ? F_HAS_VEL : ch.component == RE_C_ACCELERATION ? F_HAS_ACC : ch.component == RE_C_ROTATION_VEL ? F_HAS_ROTVEL : F_HAS_ROTACC);
                         if (ch.component == RE_C_ROTATION_VEL) new_rotvel = true;
@@ -2212,7 +2475,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
                     case RE_C_SCALE: writes[{ r, (uint32_t)RE_C_SCALE }] = { 1.f, 1.f, 1.f, 0.f }; flag_op(r, F_HAS_SCALE, 0); break;         // Scale::default
                     case RE_C_VELOCITY: case RE_C_ACCELERATION: case RE_C_ROTATION_VEL: case RE_C_ROTATION_ACC:
                         writes.erase({ r, ch.component });
-                        if (dyn_index(r, j)) flag_op(r, ch.component == RE_C_VELOCITY ? F_HAS_VEL : ch.component == RE_C_ACCELERATION ? F_HAS_ACC : ch.component == RE_C_ROTATION_VEL ? F_HAS_ROTVEL : F_HAS_ROTACC, 0);
+                        if (dyn_index(r, j) || dyn_alloc.count(r) || r >= c->n) flag_op(r, ch.component == RE_C_VELOCITY ? F_HAS_VEL : ch.component == RE_C_ACCELERATION ? F_HAS_ACC : ch.component == RE_C_ROTATION_VEL ? F_HAS_ROTVEL : F_HAS_ROTACC, 0);
                         break;                                                  // (an entity without a slot in the dynamic table never carried it: no effect, like the reference)
                     default: return c->fail(RE_E_ARG, "re_apply_changes: component %u cannot be removed (change %u)", ch.component, i);
                 }
@@ -2232,6 +2495,16 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
                 pre.push_back({ r, 2 }); flag_op(r, F_STATIC, 0);
                 if (stat(r)) { stat(r) = false; if (hide.count(r)) hide.erase(r); else unhide.insert(r); }
                 break;
+            case RE_CHANGE_ADD_SORTABLE: case RE_CHANGE_REMOVE_SORTABLE: {
+                // AddSortableComponent / RemoveSortableComponent (entity_change_helpers.rs:138-146 -> ECS::write_sortable_component / remove_sortable_component,
+                // objects/ecs.rs:202-213): the entity moves to another sortable bucket, i.e. to another (ModelId, sortable) group; a cached static entity stays in the
+                // snapshot under its old bucket (a ghost), the live one is hidden like any entity that became static after the freeze
+                if (deleted.count(r)) break;
+                if (ch.kind == RE_CHANGE_ADD_SORTABLE && ch.component > 0xFFFFu) return c->fail(RE_E_ARG, "re_apply_changes: sortable index %u (change %u)", ch.component, i);
+                if (stat(r) && !uncached(r)) { int rc = plan_ghost(r); if (rc != RE_OK) return rc; }
+                sortable_ops[r] = ch.kind == RE_CHANGE_ADD_SORTABLE ? ch.component : 0u;
+                break;
+            }
             default: return c->fail(RE_E_ARG, "re_apply_changes: unknown change kind %u (change %u)", ch.kind, i);
         }
     }
@@ -2241,11 +2514,40 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     std::set<uint64_t> ghost_touched;
     if (!ghosts.empty()) {
         std::vector<Pair32> cl; cl.reserve(ghosts.size());
-        for (auto &g : ghosts) { const uint32_t gr = c->n + c->n_ghost++; cl.push_back(Pair32{ g.first, gr }); c->h_ghost_gc.push_back(c->h_gclass[g.first]); c->ghost_map[g.second].push_back(gr); ghost_touched.insert(g.second); }
+        for (auto &g : ghosts) { const uint32_t gr = c->ghost_base + c->n_ghost++; cl.push_back(Pair32{ g.first, gr }); c->h_ghost_gc.push_back(c->h_gclass[g.first]); c->ghost_map[g.second].push_back(gr); ghost_touched.insert(g.second); }
         Pair32 *d = nullptr; HIPCHK(c, hipMalloc(reinterpret_cast<void **>(&d), cl.size() * sizeof(Pair32)));
         HIPCHK(c, hipMemcpyAsync(d, cl.data(), cl.size() * sizeof(Pair32), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_clone_rows, dim3(((uint32_t)cl.size() * 4u + 255) / 256), dim3(256), 0, st, (uint32_t)cl.size(), d, c->d_id.p, c->d_mat.p);   // before any component write of this batch
         HIPCHK(c, sync_stream(st)); (void)hipFree(d);
+    }
+    // ---- the entities this batch adds: rows, columns, matrices, section decisions (the tree sees them in rebucket(): TreeOp kind 4, in list order)
+    if (!new_rows.empty()) { int rc = create_rows(c, added, new_rows, nullptr); if (rc != RE_OK) return rc; }
+    for (uint32_t r : dyn_alloc) { uint32_t j = 0; int rc = alloc_dyn_slot(c, r, &j); if (rc != RE_OK) return rc; }
+    std::vector<uint32_t> regrouped;                                          // rows whose group class changed: device column + their entry of the row pool
+    if (!sortable_ops.empty()) {
+        bool grew = false;
+        for (auto &kv : sortable_ops) {
+            const GroupKey old = c->h_gkeys[c->h_gclass[kv.first]];
+            const uint32_t g = group_class_of(c, GroupKey{ old.model, old.rs, kv.second }, &grew);
+            if (g != c->h_gclass[kv.first]) { c->h_gclass[kv.first] = g; regrouped.push_back(kv.first); }
+        }
+        if (grew) { int rc = regrow_groups(c); if (rc != RE_OK) return rc; }
+    }
+    if (!in_frame) {
+        // Between frames the changed-static set is still there at the next render (nothing clears it before: pipeline.rs:271 runs inside execute), so the
+        // sections that received a static entity are RE-CACHED then, from their live static sets: ghost instances parked there go, rows hidden there show again.
+        for (const NewRow &nr : new_rows) {
+            auto ak = c->add_keys.find(nr.row);
+            if (ak == c->add_keys.end() || !ak->second.is_static) continue;
+            for (uint32_t k = 0; k < ak->second.nk; k++) {
+                const uint64_t K = ak->second.keys[k];
+                if (c->ghost_map.erase(K)) ghost_touched.insert(K);
+                c->dormant_cached.erase(K);
+                const int32_t sl = find_slot(c, K);
+                if (sl < 0) continue;
+                for (uint32_t q = c->h_cell_nl[sl], e = c->h_cell_nl[sl] + c->h_cell_ns[sl], b = c->h_cell_begin[sl]; q < e; q++) { const uint32_t r2 = c->h_rows[b + q]; if (r2 < c->n && c->h_uncached.count(r2)) unhide.insert(r2); }
+            }
+        }
     }
     if (new_rotvel) c->has_rotvel = true;
     for (auto &kv : flag_ops) c->h_flags[kv.first] = (c->h_flags[kv.first] & (kv.second.first | F_STATIC)) | (kv.second.second & ~F_STATIC);   // the static bit follows the tree replay
@@ -2260,6 +2562,7 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
     }
     for (uint32_t r : hide) { WriteOp w{}; w.comp = WRITE_GCLASS; w.index = r; w.v[0] = 0xFFFFFFFFu; ops.push_back(w); }
     for (uint32_t r : unhide) if (!deleted.count(r)) { WriteOp w{}; w.comp = WRITE_GCLASS; w.index = r; w.v[0] = c->h_gclass[r]; ops.push_back(w); }
+    for (uint32_t r : regrouped) if (!deleted.count(r) && !c->h_uncached.count(r)) { WriteOp w{}; w.comp = WRITE_GCLASS; w.index = r; w.v[0] = c->h_gclass[r]; ops.push_back(w); }
     for (auto &kv : flag_ops) { WriteOp w{}; w.comp = WRITE_FLAGS; w.index = kv.first; w.v[0] = kv.second.first; w.v[1] = kv.second.second; w.v[2] = (kv.second.second & F_DEAD) ? 1u : 0u; ops.push_back(w); }
     std::vector<uint32_t> list; list.reserve(trans.size() + kin.size());
     for (uint32_t r : trans) list.push_back(r | 0x80000000u);
@@ -2314,17 +2617,45 @@ extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n,
         for (uint32_t r : newly_hidden) collect_row_gc(c, r, gc);
         for (uint32_t r : hide) collect_row_gc(c, r, gc);
         for (uint32_t r : unhide) if (!deleted.count(r)) collect_row_gc(c, r, gc);
+        for (uint32_t r : regrouped) if (!deleted.count(r)) collect_row_gc(c, r, gc);
         int rc = upload_row_gc(c, gc);
         if (rc != RE_OK) return rc;
     }
-    if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique after the logic flow (pipeline.rs:271)
+    c->add_keys.clear();
+    if (in_frame && c->dirty_pending) {                                         // Pipeline::execute: clear_changed_static_unique after the logic flow (pipeline.rs:271)
         uint32_t m = std::max(c->ncells, c->nsh);
         if (m) hipLaunchKernelGGL(k_clear_static_dirty, dim3((m + 255) / 256), dim3(256), 0, st, c->ncells, c->d_cell_flags.p, c->nsh, c->d_sh_dirty.p);
         c->dirty_pending = false;
     }
     if (out) *out = c->last_tick;
     return RE_OK;
+}
+extern "C" int re_apply_changes(re_ctx *c, const re_change *changes, uint32_t n, uint32_t flags, re_tick_result *out) try {
+    (void)flags;
+    if (!c) return RE_E_ARG;
+    return apply_changes_impl(c, changes, n, nullptr, out, true);
 } RE_ABI_GUARD(c, "re_apply_changes")
+extern "C" int re_apply_changes_ex(re_ctx *c, const re_change *changes, uint32_t n, const re_entities *added, uint32_t flags, re_tick_result *out) try {
+    (void)flags;
+    if (!c) return RE_E_ARG;
+    return apply_changes_impl(c, changes, n, added, out, true);
+} RE_ABI_GUARD(c, "re_apply_changes_ex")
+// Pipeline::register_model_instances at any time (flows/pipeline.rs:186-208): create_entity + apply_choices per instance, then end_of_changes.
+extern "C" int re_add_entities(re_ctx *c, const re_entities *E, uint32_t *n_rejected) try {
+    if (!c) return RE_E_ARG;
+    if (!E) return c->fail(RE_E_ARG, "re_add_entities: entities is NULL");
+    if (!c->h_res) return re_upload_entities(c, E, n_rejected);               // the first registration of a context
+    if (n_rejected) *n_rejected = 0;
+    if (!E->n) return RE_OK;
+    if (!E->entity_id) return c->fail(RE_E_ARG, "re_add_entities: missing required array");
+    std::vector<re_change> ch(E->n);
+    for (uint32_t i = 0; i < E->n; i++) { ch[i] = re_change{}; ch[i].kind = RE_CHANGE_ADD_ENTITY; ch[i].entity_id = E->entity_id[i]; ch[i].reserved = i; }
+    const uint32_t row0 = c->n;
+    int rc = apply_changes_impl(c, ch.data(), E->n, E, nullptr, false);
+    if (rc != RE_OK) return rc;
+    if (n_rejected) { uint32_t rej = 0; for (uint32_t r = row0; r < c->n; r++) if (c->h_row_nk[r] == 0) rej++; *n_rejected = rej; }
+    return RE_OK;
+} RE_ABI_GUARD(c, "re_add_entities")
 
 // ------------------------------------------------------------------------------------------------
 // re_collide == LogicFlow::handle_collisions (flows/logic_flow.rs:452-651): the broad phase and the AABB tests; the collision
@@ -2657,11 +2988,7 @@ extern "C" int re_read_component(re_ctx *c, uint32_t entity_id, int component, v
     if (!c->row_of(entity_id, &r)) return c->fail(RE_E_ARG, "re_read_component: unknown entity %u", entity_id);
     HIPCHK(c, hipSetDevice(c->device));
     { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
-    auto dynidx = [&](uint32_t &j) -> bool {                      // dynamic rows are kept in ascending row order
-        auto p = std::lower_bound(c->h_dyn_row.begin(), c->h_dyn_row.end(), r);
-        if (p == c->h_dyn_row.end() || *p != r) return false;
-        j = (uint32_t)(p - c->h_dyn_row.begin()); return true;
-    };
+    auto dynidx = [&](uint32_t &j) -> bool { return c->dyn_index(r, j); };
     uint32_t j = 0;
     {   // ECS::get_copy -> None for a component the entity does not carry (objects/ecs.rs:653-664, check_component_written :348-367)
         static const uint32_t need[] = { 0, F_HAS_ROT, F_HAS_SCALE, F_HAS_VEL, F_HAS_ACC, F_HAS_ROTVEL, F_HAS_ROTACC };

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_col_moved(uint32_t ndyn, const uint32_t
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > ndyn || (j == ndyn && user_row == ROW_CELL_NONE)) return;
     const bool is_user = j == ndyn;
-    const uint32_t r = is_user ? user_row : dyn_row[j], rc = is_user ? user_cell : dyn_cell[j];
+    const uint32_t r = is_user ? user_row : dyn_row[j], rc = is_user ? user_cell : dyn_cell[r];      // (dyn_cell: the row -> section column; dynamic entities added later sit in any row)
     const uint32_t fl = R.flags[r];
     if ((fl & F_DEAD) || rc == ROW_CELL_NONE) return;
     const FrameParams &P = *Pp;

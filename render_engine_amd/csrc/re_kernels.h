@@ -110,7 +110,7 @@ struct SharedArrays {                       // shared world sections (bounding_b
 };
 struct InstanceRange { uint32_t model_index, render_system, sortable, begin, count; };
 
-__global__ void k_transform_assign(RowArrays R, uint32_t n, uint32_t outline, uint32_t atomic, uint64_t *row_key, uint8_t *row_nk,
+__global__ void k_transform_assign(RowArrays R, uint32_t row0, uint32_t n, uint32_t outline, uint32_t atomic, uint64_t *row_key, uint8_t *row_nk,
                                    SharedRec *shrec, uint32_t *shrec_count, uint32_t shrec_cap);
 __global__ void k_fold_tight(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal, const uint32_t *cell_nstatic,
                              const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many);
@@ -196,7 +196,9 @@ __global__ void k_emit_scatter(const FrameHeader *hdr, const uint32_t *item_row,
 __global__ void k_tick(uint32_t ndyn, float *dyn_vel, const float *dyn_acc, float *dyn_rotvel, const float *dyn_rotacc, RowArrays R,
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
-                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame);
+                       uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame,
+                       uint32_t ndyn0, const uint32_t *dyn_row);
+__global__ void k_shift_rows(uint32_t m, uint32_t *rows, uint32_t from, uint32_t delta);   // pool entries >= from (ghost instances) move up by delta when the row columns grow
 // Probe path of the visibility query (opt-in, RE_CFG_PROBE): instead of streaming every section key, enumerate the cells of the two
 // candidate boxes (their bounding box per level) and look each one up in a device hash table key -> slot, like the reference's
 // own contains_key probes (visible_world_flow.rs:96-104).  Work is O(candidates), not O(sections).

@@ -29,10 +29,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // section decision of BoundingBoxTree::add_entity (world/bounding_box_tree_v2.rs:563-579).
 // mode 0 = registration (EntityTransformationBuilder::write_components: only supplied factors)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_transform_assign(RowArrays R, uint32_t n, uint32_t outline, uint32_t atomic,
+// Rows [row0, row0 + n): the whole world at upload (row0 = 0), or the rows an add-entity batch appended (re_add_entities / RE_CHANGE_ADD_ENTITY);
+// row_key / row_nk are indexed by the row's position in the range.
+__global__ __launch_bounds__(256) void k_transform_assign(RowArrays R, uint32_t row0, uint32_t n, uint32_t outline, uint32_t atomic,
                                                            uint64_t *row_key, uint8_t *row_nk, SharedRec *shrec, uint32_t *shrec_count, uint32_t shrec_cap) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = row0 + i;
     uint32_t fl = R.flags[r];
     float pos[3] = { R.pos[r * 3 + 0], R.pos[r * 3 + 1], R.pos[r * 3 + 2] };
     float axis[3] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2] }; float angle = R.rot[r * 4 + 3];
@@ -56,8 +59,8 @@ __global__ __launch_bounds__(256) void k_transform_assign(RowArrays R, uint32_t 
     uint64_t keys[8];
     int nk = oob ? 0 : assign_sections(bv, atomic, keys);      // apply_choices adds with add_if_out_bounds = false
     if (nk < 0) nk = 0;
-    row_nk[r] = (uint8_t)nk;
-    row_key[r] = nk >= 1 ? keys[0] : 0ull;
+    row_nk[i] = (uint8_t)nk;
+    row_key[i] = nk >= 1 ? keys[0] : 0ull;
     if (nk > 1) {
         uint32_t slot = atomicAdd(shrec_count, 1u);
         if (slot < shrec_cap) {
@@ -1327,12 +1330,15 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
                                               const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
                                               const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
                                               TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
-                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame) {
+                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame, uint32_t ndyn0, const uint32_t *__restrict__ dyn_row) {
     // An EARLIER tick left the tree stale: this frame is replayed by the host.  The flag a workgroup of THIS tick raises when it finds a
     // mover must not stop the workgroups of the same tick that start later (they would skip their entities for good): the frame travels
     // with the flag in one 64-bit word.
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, r = j;
+    // Dynamic entity j < ndyn0 lives in row j (the upload's leading block); entities that became dynamic later -- added with a velocity, or given one
+    // by a change request -- sit in any row, listed in dyn_row (one more coalesced load for the waves of the tail only).
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = j < ndyn;
+    const uint32_t r = (j < ndyn0 || !in) ? j : dyn_row[j];
     const FrameParams &P = *Pp;
     // ---- round trip 1: flag word and section slot of the row (coalesced), the frame number, and -- in the same round trip, not in front of it -- the speculation word
     const uint32_t fl = in ? R.flags[r] : F_DEAD, rc = in ? row_cell[r] : ROW_CELL_NONE;
@@ -1540,6 +1546,10 @@ __global__ __launch_bounds__(256) void k_clone_rows(uint32_t m, const Pair32 *__
     const Pair32 p = src_dst[i >> 2];
     reinterpret_cast<float4 *>(row_mat + (size_t)p.val * 16)[i & 3u] = reinterpret_cast<const float4 *>(row_mat + (size_t)p.idx * 16)[i & 3u];
     if ((i & 3u) == 0) row_id[p.val] = row_id[p.idx];
+}
+__global__ __launch_bounds__(256) void k_shift_rows(uint32_t m, uint32_t *__restrict__ rows, uint32_t from, uint32_t delta) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { const uint32_t r = rows[i]; if (r >= from && r != 0xFFFFFFFFu) rows[i] = r + delta; }
 }
 __global__ __launch_bounds__(256) void k_scatter32(uint32_t m, const Pair32 *__restrict__ pairs, uint32_t *__restrict__ dst) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -207,13 +207,11 @@ class Pipeline:
             raise RenderEngineError(f"{what} failed ({rc}): {self._L.re_last_error(self._h).decode()}")
 
     # -- Pipeline::register_model_instances ------------------------------------------------------
-    def register_model_instances(self, ents):
-        """ents: numpy structured array of ENTITY_DT.  Returns the number rejected as out of bounds.
-        REPLACES the world (re_upload_entities): the reference's Pipeline::register_model_instances (flows/pipeline.rs:186-208) appends and may be
-        called at any time; here every instance is registered in one call before the first frame (known deviations)."""
+    @staticmethod
+    def _columns(ents):
         e = np.ascontiguousarray(ents, ENTITY_DT)
         n = len(e)
-        cols = dict(
+        return n, dict(
             entity_id=np.ascontiguousarray(e["id"]), model_index=np.ascontiguousarray(e["model_index"]),
             render_system=np.ascontiguousarray(e["render_system"]), sortable=np.ascontiguousarray(e["sortable"]),
             flags=np.ascontiguousarray(e["flags"]), original_aabb=np.ascontiguousarray(e["original"]),
@@ -223,11 +221,10 @@ class Pipeline:
             rotation_velocity=np.ascontiguousarray(np.concatenate([e["rotvel_axis"], e["rotvel"][:, None]], axis=1)) if n else np.zeros((0, 4), np.float32),
             rotation_acceleration=np.ascontiguousarray(np.concatenate([e["rotacc_axis"], e["rotacc"][:, None]], axis=1)) if n else np.zeros((0, 4), np.float32),
         )
-        return self.upload_columns(n, **cols)
 
-    def upload_columns(self, n, entity_id, model_index, flags, original_aabb, position, render_system=None, sortable=None,
-                       rotation=None, scale=None, velocity=None, acceleration=None, rotation_velocity=None, rotation_acceleration=None):
-        """SoA upload straight into re_upload_entities (no structured-array staging)."""
+    @staticmethod
+    def _entities_struct(n, entity_id, model_index, flags, original_aabb, position, render_system=None, sortable=None,
+                         rotation=None, scale=None, velocity=None, acceleration=None, rotation_velocity=None, rotation_acceleration=None):
         E = _capi.Entities(); E.n = n
         keep = []
 
@@ -244,6 +241,28 @@ class Pipeline:
         E.flags = u32(flags); E.original_aabb = f32(original_aabb); E.position = f32(position); E.rotation = f32(rotation)
         E.scale = f32(scale); E.velocity = f32(velocity); E.acceleration = f32(acceleration)
         E.rotation_velocity = f32(rotation_velocity); E.rotation_acceleration = f32(rotation_acceleration)
+        return E, keep
+
+    def register_model_instances(self, ents):
+        """Pipeline::register_model_instances (flows/pipeline.rs:186-208): create_entity + apply_choices per instance, then end_of_changes.  ents: numpy
+        structured array of ENTITY_DT.  The first call of a pipeline uploads the world; later calls -- at any time, as in the reference -- APPEND
+        (re_add_entities).  Returns the number of instances rejected as out of bounds."""
+        n, cols = self._columns(ents)
+        E, keep = self._entities_struct(n, **cols)
+        rej = C.c_uint32()
+        self._check(self._L.re_add_entities(self._h, C.byref(E), C.byref(rej)), "re_add_entities")
+        return rej.value
+
+    def replace_world(self, ents):
+        """re_upload_entities: the world of this context is REPLACED by these entities (a fresh tree, a fresh static render cache)"""
+        n, cols = self._columns(ents)
+        return self.upload_columns(n, **cols)
+
+    def upload_columns(self, n, entity_id, model_index, flags, original_aabb, position, render_system=None, sortable=None,
+                       rotation=None, scale=None, velocity=None, acceleration=None, rotation_velocity=None, rotation_acceleration=None):
+        """SoA upload straight into re_upload_entities (no structured-array staging)."""
+        E, keep = self._entities_struct(n, entity_id, model_index, flags, original_aabb, position, render_system, sortable,
+                                        rotation, scale, velocity, acceleration, rotation_velocity, rotation_acceleration)
         rej = C.c_uint32()
         self._check(self._L.re_upload_entities(self._h, C.byref(E), C.byref(rej)), "re_upload_entities")
         return rej.value
@@ -294,12 +313,18 @@ class Pipeline:
         sync = not (cull_flags & _capi.CULL_ASYNC)
         return us[:n], (self._visible_to_py(vis, copy=False) if sync and n else None), dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
 
-    def apply_changes(self, changes):
+    def apply_changes(self, changes, added=None):
         """helper_things/entity_change_helpers.rs:32-189 for the change requests of user logic.
-        `changes`: structured array CHANGE_DT (kind, entity_id, component, reserved, value[4])."""
+        `changes`: structured array CHANGE_DT (kind, entity_id, component, reserved, value[4]); `added`: ENTITY_DT array of the entities that
+        CHANGE_ADD_ENTITY changes add (reserved = index into it)."""
         ch = np.ascontiguousarray(changes, dtype=CHANGE_DT)
         tr = _capi.TickResult()
-        self._check(self._L.re_apply_changes(self._h, ch.ctypes.data, len(ch), 0, C.byref(tr)), "re_apply_changes")
+        if added is not None:
+            n, cols = self._columns(added)
+            E, keep = self._entities_struct(n, **cols)
+            self._check(self._L.re_apply_changes_ex(self._h, ch.ctypes.data, len(ch), C.byref(E), 0, C.byref(tr)), "re_apply_changes_ex")
+        else:
+            self._check(self._L.re_apply_changes(self._h, ch.ctypes.data, len(ch), 0, C.byref(tr)), "re_apply_changes")
         return dict(n_changed=tr.n_changed, n_rebucket=tr.n_rebucket, n_out_of_bounds=tr.n_out_of_bounds)
 
     def collide(self, capacity=None):

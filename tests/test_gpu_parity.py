@@ -358,6 +358,124 @@ def test_apply_changes_parity(R):
     p.close(); w.close()
 
 
+def test_add_entities_between_frames(R):
+    """Pipeline::register_model_instances after the first frame (flows/pipeline.rs:186-208): new rows, slots of the dynamic table, new (ModelId, sortable)
+    groups, shared sections created by straddlers, an instance out of bounds -- in a world with unique and shared sections, spinners and movers.  The added
+    entities here are non-static (a static one re-caches its section: the lattice test below)."""
+    C = R._capi
+    ents = R.synthetic.mixed_world(2500, seed=31, spread=500.0)
+    p, w = build_pair(R, ents)
+    cams = [R.Camera((8192 + 30 * i, 8192, 8450 - 20 * i), (0.04 * i, 0, -1), 1100.0) for i in range(6)]
+    all_ents = ents
+    next_id = int(ents["id"].max()) + 1
+    for f, cam in enumerate(cams):
+        check_frame(R, p, w, cam, f % 2 == 1)
+        n_o, oob_o = w.tick(oracle_camera(cam), 0.016); t = p.tick(0.016)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        if f in (0, 2, 3):
+            new = R.synthetic.mixed_world(180 + 40 * f, seed=100 + f, spread=450.0)
+            new["id"] = np.arange(next_id, next_id + len(new), dtype=np.uint32); next_id += len(new)
+            new["flags"] &= ~np.uint32(C.F_STATIC)
+            new["model_index"] += np.uint32(3 * f)                       # model ids the upload did not know: new group classes
+            if f == 2:
+                new["pos"][5] = (-900.0, 100.0, 100.0)                   # out of bounds: created, not inserted
+            assert p.register_model_instances(new) == w.register(to_oracle(new)) == (1 if f == 2 else 0)
+            all_ents = np.concatenate([all_ents, new])
+            check_sections(p, w)
+            assert p.stats()["n_entities"] == len(all_ents)
+    check_entities(R, p, w, all_ents)
+    assert len(p.get_indexes_for_components([C.C_VELOCITY])) == len([e for e in all_ents if w.entity(int(e["id"])) is not None and w.entity(int(e["id"]))["flags"] & C.F_HAS_VEL])
+    p.close(); w.close()
+
+
+def test_add_entities_static_recache_and_in_frame(R):
+    """A world without shared sections (one entity per level-0 section).  Between frames a static instance re-caches its section at the next render
+    (the changed-static set survives until then): ghosts parked there go, rows hidden there show again.  Inside a frame (AddEntity of apply_change,
+    helper_things/entity_change_helpers.rs:48-107) the list is processed in order: the added entity is modified, deleted and its id added again in the
+    same batch; a static one stays undrawn until a later re-cache; sortable components come and go; Velocity written to an entity registered without it."""
+    C = R._capi
+    ents = R.synthetic.lattice_world(cells_per_axis=16, first_cell=120, spinner_every=5)
+    p, w = build_pair(R, ents)
+    cam = R.Camera((8192, 8192, 8500), (0, 0, -1), 900.0); oc = oracle_camera(cam)
+
+    def frame(dups=False):
+        check_frame(R, p, w, cam, dups)
+        n_o, _ = w.tick(oc, 0.016); t = p.tick(0.016)
+        assert t["n_changed"] == n_o
+
+    def small(ids, cells, static, model=2, vel=None):
+        e = np.zeros(len(ids), R.ENTITY_DT)
+        e["id"] = ids; e["model_index"] = model
+        e["flags"] = C.F_STATIC if static else 0
+        for k in range(3):
+            e["original"][:, 2 * k] = -1.0; e["original"][:, 2 * k + 1] = 1.0
+        e["scale"] = 1.0; e["rot_axis"][:, 0] = 1; e["rotvel_axis"][:, 0] = 1; e["rotacc_axis"][:, 0] = 1
+        for i, (cx, cy, cz) in enumerate(cells):
+            e["pos"][i] = (cx * 64.0 + 20.0 + 3 * i, cy * 64.0 + 30.0, cz * 64.0 + 25.0)
+        if vel is not None:
+            e["flags"] |= C.F_HAS_VEL; e["vel"][:] = vel
+        return e
+
+    frame(); frame(True)
+    static_ids = [int(e["id"]) for e in ents if e["flags"] & C.F_STATIC]
+    # a change batch that leaves ghosts and hidden rows behind: wake a cached static entity, move another, make an active one static
+    ch = np.zeros(3, R.CHANGE_DT)
+    ch[0] = (C.CHANGE_WAKE_UP, static_ids[700], 0, 0, (0, 0, 0, 0))
+    ch[1] = (C.CHANGE_MODIFY, static_ids[701], C.C_POSITION, 0, tuple(ents[ents["id"] == static_ids[701]]["pos"][0] + np.float32(3.0)) + (0,))
+    ch[2] = (C.CHANGE_MAKE_STATIC, int(ents["id"][0]), 0, 0, (0, 0, 0, 0))
+    w.apply_changes(ch.view(ro.CHANGE_DT)); p.apply_changes(ch)
+    frame(); check_sections(p, w)
+    # between frames: static and active instances; two of the static ones land in the sections that hold the ghost / the hidden row
+    def cell_of(eid):
+        q = ents[ents["id"] == eid]["pos"][0]
+        return (int(q[0] // 64), int(q[1] // 64), int(q[2] // 64))
+    cells = [cell_of(static_ids[700]), cell_of(static_ids[701]), cell_of(int(ents["id"][0])), (125, 126, 127), (126, 126, 131)]
+    nid = 900000
+    new = np.concatenate([small(np.arange(nid, nid + 5, dtype=np.uint32), cells, True, model=11),
+                          small(np.arange(nid + 5, nid + 9, dtype=np.uint32), [(124, 125, 130), (125, 125, 130), (127, 128, 131), (60, 300, 60)], False, model=12, vel=(15.0, 0.0, -4.0))])
+    assert p.register_model_instances(new) == w.register(to_oracle(new)) == 1         # (60, 300, 60): y = 19230 lies outside the world
+    check_sections(p, w)
+    frame(True); frame()
+    # inside a frame: AddEntity, interleaved with changes of the added entities
+    add = np.concatenate([small(np.array([nid + 20, nid + 21, nid + 22], np.uint32), [(126, 127, 130), (127, 127, 130), (128, 127, 130)], False, model=13),
+                          small(np.array([nid + 23], np.uint32), [(126, 128, 130)], True, model=13),
+                          small(np.array([nid + 21], np.uint32), [(129, 127, 130)], False, model=14)])            # the id of a deleted entity, added again
+    A = lambda k, i: (C.CHANGE_ADD_ENTITY, int(add["id"][i]), 0, i, (0, 0, 0, 0))
+    ch = np.zeros(12, R.CHANGE_DT)
+    ch[0] = A(0, 0)
+    ch[1] = (C.CHANGE_MODIFY, nid + 20, C.C_POSITION, 0, (126 * 64.0 + 40.0, 127 * 64.0 + 31.0, 130 * 64.0 + 25.0, 0))      # stays in its section: add_entity returns early
+    ch[2] = A(0, 1)
+    ch[3] = (C.CHANGE_MODIFY, nid + 21, C.C_VELOCITY, 0, (5.0, 0.0, 0.0, 0))
+    ch[4] = (C.CHANGE_DELETE, nid + 21, 0, 0, (0, 0, 0, 0))
+    ch[5] = A(0, 4)                                                                                                    # id nid + 21 again (ECS::create_entity reuses freed ids)
+    ch[6] = A(0, 2)
+    ch[7] = (C.CHANGE_MODIFY, nid + 22, C.C_POSITION, 0, (140 * 64.0 + 10.0, 127 * 64.0 + 31.0, 130 * 64.0 + 25.0, 0))      # leaves for another section
+    ch[8] = A(0, 3)                                                                                                    # static, inside a frame: not drawn until re-cached
+    ch[9] = (C.CHANGE_ADD_SORTABLE, int(ents["id"][5]), 2, 0, (0, 0, 0, 0))                                            # an active spinner
+    ch[10] = (C.CHANGE_ADD_SORTABLE, static_ids[300], 3, 0, (0, 0, 0, 0))                                              # a cached static entity: the snapshot keeps its old bucket
+    ch[11] = (C.CHANGE_MODIFY, static_ids[301], C.C_VELOCITY, 0, (0.0, 9.0, 0.0, 0))                                   # Velocity on an entity registered without one
+    n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT), added=to_oracle(add)); g = p.apply_changes(ch, added=add)
+    assert g["n_changed"] == n_a and g["n_out_of_bounds"] == len(oob_a)
+    check_sections(p, w)
+    frame(); frame(True)
+    ch = np.zeros(3, R.CHANGE_DT)
+    ch[0] = (C.CHANGE_REMOVE_SORTABLE, int(ents["id"][5]), 0, 0, (0, 0, 0, 0))
+    ch[1] = (C.CHANGE_WAKE_UP, static_ids[301], 0, 0, (0, 0, 0, 0))                                                    # now it moves with its new velocity
+    ch[2] = (C.CHANGE_MODIFY, nid + 21, C.C_ROTATION_VEL, 0, (0.0, 1.0, 0.0, 0.3))
+    w.apply_changes(ch.view(ro.CHANGE_DT)); p.apply_changes(ch)
+    for _ in range(3):
+        frame()
+    # a static instance between frames into the section of the in-frame static one: the re-cache shows both
+    more = small(np.array([nid + 40], np.uint32), [(126, 128, 130)], True, model=13)
+    assert p.register_model_instances(more) == w.register(to_oracle(more)) == 0
+    frame(True); frame()
+    everything = np.concatenate([ents, new, add[[0, 2, 3, 4]], more])
+    check_entities(R, p, w, everything)
+    check_sections(p, w)
+    st = p.stats(); assert st["n_entities"] == len(ents) + len(new) + len(add) + len(more)
+    p.close(); w.close()
+
+
 def test_frozen_static_cache_ghosts(R):
     """the static render cache is a snapshot taken at the first render (render_flow.rs:549-594; pipeline.rs:271 clears the
     changed set): a cached static entity that is deleted, woken or moved stays in the picture with its old matrix; the section that
@@ -537,7 +655,7 @@ def test_context_reuse_and_call_order_errors(R):
     w.close()
     # a different world into the same context: static lattice, deferred packs, an empty view, then a populated one
     b = R.synthetic.lattice_world(cells_per_axis=20, first_cell=118)
-    p.register_model_instances(b)
+    p.replace_world(b)
     w = ro.World(16384, 64); w.register(to_oracle(b))
     empty = R.Camera((200, 200, 200), (0, 0, -1), 100.0)
     check_frame(R, p, w, empty, False); w.tick(oracle_camera(empty), 0.016); p.tick(0.016)      # the cache freezes with nothing in range
