@@ -225,7 +225,8 @@ class EntityTransformationBuilder {
 };
 
 // Pipeline (flows/pipeline.rs): owns the ECS columns the path needs and the GPU context.  Registration is collected on the host
-// (create_entity / write_component / add_entity of the reference) and handed to the GPU once, before the first frame.
+// (create_entity / write_component / add_entity of the reference) and handed to the GPU before the next frame: the whole world before the
+// first one, the instances registered since afterwards (re_add_entities).
 class Pipeline {
   public:
     Pipeline(uint32_t tree_outline_length, uint32_t tree_atomic_length, int device = 0, uint32_t max_instances = 0) {
@@ -251,7 +252,11 @@ class Pipeline {
         r.model = model_id; r.original = original_aabb; r.pos = camera_pos; r.flags = RE_F_USER | RE_F_HAS_VEL | RE_F_HAS_ACC | RE_F_CAN_COLLIDE; r.placed = true;   // CanCauseCollisions + UserAlwaysCausesCollisions (pipeline.rs:135-136)
         uploaded_ = false; return e;
     }
-    void write_sortable_component(EntityId e, uint32_t sortable_index) { row(e).sortable = sortable_index; uploaded_ = false; }   // ecs.rs:202-205
+    void write_sortable_component(EntityId e, uint32_t sortable_index) {                                                           // ecs.rs:202-205
+        row(e).sortable = sortable_index;
+        if (e < n_sent_) { re_change ch{}; ch.kind = RE_CHANGE_ADD_SORTABLE; ch.entity_id = e; ch.component = sortable_index; check(re_apply_changes(ctx_, &ch, 1, 0, nullptr), "re_apply_changes"); }
+        else uploaded_ = false;
+    }
     void write_always_execute_logic(EntityId e) { row(e).flags |= RE_F_ALWAYS_EXEC; uploaded_ = false; }
     void write_out_of_bounds_logic(EntityId e) { row(e).flags |= RE_F_OOB_LOGIC; uploaded_ = false; }                           // the entity type has OutOfBoundsLogic
 
@@ -339,14 +344,14 @@ class Pipeline {
     void read(EntityId e, int component, void *dst) { upload_if_needed(); check(re_read_component(ctx_, e, component, dst), "re_read_component"); }
     void upload_if_needed() {
         if (uploaded_) return;
-        // re_upload_entities REPLACES the world (include/re_hip.h): after frames have run it would put every entity back to the state it was registered with.
-        // The reference can register more instances at any time (flows/pipeline.rs:186-208); this path cannot yet, and says so instead of resetting the world.
-        if (executed_) throw Error(RE_E_STATE, "entities registered or re-described after the first executed frame: not supported (re_upload_entities replaces the world)");
-        const size_t n = rows_.size();
+        // Before the first executed frame every registration is collected and uploaded once (re_upload_entities REPLACES the world).  Afterwards the
+        // instances registered since are APPENDED (re_add_entities == Pipeline::register_model_instances at any time, flows/pipeline.rs:186-208).
+        const size_t first = executed_ ? n_sent_ : 0, n = rows_.size() - first;
         std::vector<uint32_t> id(n), model(n), rs(n), sortable(n), flags(n);
         std::vector<float> aabb(n * 6), pos(n * 3), rot(n * 4), scl(n * 3), vel(n * 3), acc(n * 3), rv(n * 4), ra(n * 4);
         size_t m = 0;
-        for (const Row &r : rows_) {
+        for (size_t ri = first; ri < rows_.size(); ri++) {
+            const Row &r = rows_[ri];
             if (!r.placed) continue;                                                   // created but never given a transformation: not in the tree
             id[m] = r.id; model[m] = r.model.model_index; rs[m] = r.model.render_system_index; sortable[m] = r.sortable; flags[m] = r.flags;
             const float a6[6] = { r.original.x_range.min, r.original.x_range.max, r.original.y_range.min, r.original.y_range.max, r.original.z_range.min, r.original.z_range.max };
@@ -361,10 +366,11 @@ class Pipeline {
         re_entities E{}; E.n = (uint32_t)m; E.entity_id = id.data(); E.model_index = model.data(); E.render_system = rs.data(); E.sortable = sortable.data(); E.flags = flags.data();
         E.original_aabb = aabb.data(); E.position = pos.data(); E.rotation = rot.data(); E.scale = scl.data(); E.velocity = vel.data(); E.acceleration = acc.data();
         E.rotation_velocity = rv.data(); E.rotation_acceleration = ra.data();
-        check(re_upload_entities(ctx_, &E, &n_rejected_), "re_upload_entities");
-        uploaded_ = true;
+        if (executed_) { uint32_t rej = 0; check(re_add_entities(ctx_, &E, &rej), "re_add_entities"); n_rejected_ += rej; }
+        else check(re_upload_entities(ctx_, &E, &n_rejected_), "re_upload_entities");
+        n_sent_ = rows_.size(); uploaded_ = true;
     }
-    re_ctx *ctx_ = nullptr; std::vector<Row> rows_; bool uploaded_ = false, executed_ = false; uint32_t n_rejected_ = 0;
+    re_ctx *ctx_ = nullptr; std::vector<Row> rows_; bool uploaded_ = false, executed_ = false; uint32_t n_rejected_ = 0; size_t n_sent_ = 0;
 };
 
 inline void EntityTransformationBuilder::apply_choices(StaticAABB original_aabb, Pipeline &pipeline) {     // entity_transformer.rs:55-75, 99-142

@@ -2431,7 +2431,8 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
             const uint32_t id = added->entity_id[ch.reserved];
             if (ch.entity_id != id) return c->fail(RE_E_ARG, "re_apply_changes: change %u names entity %u, the entity it adds has id %u", i, ch.entity_id, id);
             uint32_t r0 = 0;
-            if (new_ids.count(id) || (c->row_of(id, &r0) && !(c->h_flags[r0] & F_DEAD) && !deleted.count(r0))) return c->fail(RE_E_ARG, "re_apply_changes: entity id %u is in use (change %u)", id, i);
+            { auto ni = new_ids.find(id); if (ni != new_ids.end() && !deleted.count(ni->second)) return c->fail(RE_E_ARG, "re_apply_changes: entity id %u is in use (change %u)", id, i); }
+            if (new_ids.find(id) == new_ids.end() && c->row_of(id, &r0) && !(c->h_flags[r0] & F_DEAD) && !deleted.count(r0)) return c->fail(RE_E_ARG, "re_apply_changes: entity id %u is in use (change %u)", id, i);
             r = c->n + (uint32_t)new_rows.size();
             uint32_t fl = added->flags[ch.reserved] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
             if (fl & F_PHANTOM) fl &= ~(F_HAS_VEL | F_HAS_ACC | F_HAS_ROTVEL | F_HAS_ROTACC | F_ALWAYS_EXEC | F_USER | F_LIGHT_ANY);

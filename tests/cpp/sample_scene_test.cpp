@@ -141,7 +141,37 @@ int main(int argc, char **argv) {
         TransformationMatrix tm = pipeline.get_copy_transformation_matrix(wormhole);
         for (uint32_t i = 0; i < total; i++) if (oids[i] == wormhole && std::memcmp(&omats[(size_t)i * 16], tm.m.data(), 64) != 0) return fail("wormhole matrix after apply_change");
     }
+    // an instance registered AFTER frames have run (Pipeline::register_model_instances at any time, flows/pipeline.rs:186-208): appended, not a new world
+    {
+        size_t src = 0; for (size_t i = 0; i < ents.size(); i++) if (ents[i].kind == 1) { src = i; break; }          // a copy of the first asteroid, elsewhere
+        const Ent e = ents[src];
+        StaticAABB box{ { e.box[0], e.box[1] }, { e.box[2], e.box[3] }, { e.box[4], e.box[5] } };
+        const float px = 1004.0f, py = 1001.0f, pz = 1040.0f;
+        EntityId created_id = 0;
+        pipeline.register_model_instances(ModelId{ e.model, 0 }, 1, box, [&](Pipeline &p, const std::vector<EntityId> &created, StaticAABB aabb) {
+            created_id = created[0];
+            EntityTransformationBuilder b(created[0], false, std::nullopt, true);
+            b.with_translation(Position::new_(vec3(px, py, pz))).with_scale(Scale::new_(vec3(e.s, e.s, e.s)))
+             .with_rotation(Rotation::new_(vec3(e.rot[0], e.rot[1], e.rot[2]), e.rot[3])).with_rotation_velocity(VelocityRotation::new_(vec3(e.rv[0], e.rv[1], e.rv[2]), e.rv[3]));
+            b.apply_choices(aabb, p);
+        });
+        ro_entity_desc d{}; d.id = created_id; d.model_index = e.model; d.original = ro_aabb{ e.box[0], e.box[1], e.box[2], e.box[3], e.box[4], e.box[5] };
+        d.pos[0] = px; d.pos[1] = py; d.pos[2] = pz; d.scale[0] = d.scale[1] = d.scale[2] = e.s; d.rotacc_axis[0] = 1.0f;
+        d.flags = RO_F_HAS_SCALE | RO_F_HAS_ROT | RO_F_HAS_ROTVEL | RO_F_CAN_COLLIDE;
+        d.rot_axis[0] = e.rot[0]; d.rot_axis[1] = e.rot[1]; d.rot_axis[2] = e.rot[2]; d.rot_angle = e.rot[3]; d.rotvel_axis[0] = e.rv[0]; d.rotvel_axis[1] = e.rv[1]; d.rotvel_axis[2] = e.rv[2]; d.rotvel = e.rv[3];
+        if (ro_register_entities(w, 1, &d) != 0) return fail("oracle rejected the late instance");
+        for (int frame = 0; frame < 2; frame++) {
+            FrameResult fr = pipeline.execute(camera, 1.0f / 60.0f, true);
+            ro_frame_cull(w, &oc, cap, okeys.data());
+            uint32_t ng = 0, total = ro_frame_render(w, &oc, 0, cap, oids.data(), omats.data(), (uint32_t)ogroups.size(), ogroups.data(), &ng);
+            uint32_t noob = 0, ochanged = ro_frame_tick(w, &oc, 1.0f / 60.0f, 0, nullptr, &noob);
+            if (fr.instances != total || fr.tick.n_changed != ochanged) return fail("frame after a late registration");
+            bool seen = false;
+            for (uint32_t i = 0; i < total; i++) if (oids[i] == created_id) { seen = true; TransformationMatrix tm = pipeline.get_copy_transformation_matrix(created_id); (void)tm; }
+            if (!seen) return fail("the late instance is not drawn");
+        }
+    }
     ro_world_free(w);
-    std::printf("OK %zu entities, 9 frames bit-exact, %zu collision invocations\n", ents.size(), n_collisions);
+    std::printf("OK %zu entities, 11 frames bit-exact, %zu collision invocations, 1 instance registered after the first frame\n", ents.size(), n_collisions);
     return 0;
 }
