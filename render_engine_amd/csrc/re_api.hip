@@ -172,9 +172,9 @@ struct re_ctx {
     bool th_clean = true; uint32_t pred_total = 0;
     std::vector<re_instance_range> groups_out;
     bool cull_inflight = false, tick_inflight = false;
-    bool tick_published = false;                      // the tick in flight is followed by k_tick_publish (synchronous ticks; asynchronous ones are settled by resolve())
+    bool tick_published = false;                      // the tick in flight publishes its counters itself (synchronous ticks; asynchronous ones are settled by resolve())
     uint32_t tick_frame = 0xFFFFFFFFu;                // frame of the last tick issued
-    uint32_t tick_seq = 0;                            // ticks issued with a kernel: k_tick_publish writes the number into h_th->ticket behind the tick
+    uint32_t tick_seq = 0;                            // synchronous ticks issued with a kernel: the last wave of k_tick writes the number into h_th->ticket (tick_sign_off)
     bool timings_on = false;                          // re_get_timings was asked for: synchronous frames record their kernel events (5 event records cost ~12 us per frame)
     bool deferred_pack = false; FusedPack deferred{}; uint32_t deferred_grid = 0, n_fused_frames = 0;
     // RE_CULL_TWO_LANES: a second set of per-frame resources ("lane": stream, frame headers, instance lists, section stamps, frame
@@ -337,7 +337,7 @@ extern "C" void re_destroy(re_ctx *c) try {
 
 static RowArrays row_arrays(re_ctx *c) {
     RowArrays R; R.id = c->d_id.p; R.gclass = c->d_gclass.p; R.flags = c->d_flags.p; R.mat = c->d_mat.p; R.aabb = c->d_aabb.p; R.orig = c->d_orig.p;
-    R.pos = c->d_pos.p; R.rot = c->d_rot.p; R.scale = c->d_scale.p; return R;
+    R.pos = c->d_pos.p; R.rot = c->d_rot.p; R.scale = c->d_scale.p; R.key = c->d_row_key.p; return R;
 }
 
 // group class a row-pool entry carries for row r: hidden while the row is not to be drawn (removed, or made static after the cache froze)
@@ -565,6 +565,10 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
         if (!gc.empty()) HIPCHK(c, hipMemcpy(c->d_rows_gc.p, gc.data(), gc.size() * 4, hipMemcpyHostToDevice));
     }
     if (n) HIPCHK(c, hipMemcpyAsync(c->d_row_cell.p, row_cell.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    if (n) {                                                                 // the key of every row's own world section, row by row: the tick reads it as a stream instead of gathering cell_key[row_cell]
+        if (c->d_row_key.n < std::max(n, c->row_cap)) HIPCHK(c, c->d_row_key.alloc(std::max(n, c->row_cap), acct));
+        HIPCHK(c, hipMemcpyAsync(c->d_row_key.p, row_key.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
     if (nsh) {
         HIPCHK(c, hipMemcpyAsync(c->d_sh_cells.p, sh_cells.data(), (size_t)nsh * 8 * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_sh_begin.p, sh_begin.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
@@ -1401,7 +1405,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     auto ghosts_of = [&](uint64_t K) -> const std::vector<uint32_t> * { auto g = c->ghost_map.find(K); return g == c->ghost_map.end() ? nullptr : &g->second; };
     for (uint64_t k : linked) if (find_slot(c, k) < 0) affected.insert(k);
     for (const SharedIdPub &id : c->h_shids) for (uint32_t k = 0; k < id.nk; k++) if (!linked.count(id.keys[k])) affected.insert(id.keys[k]);
-    std::vector<Pair64> p_key; std::vector<Pair32> p_begin, p_nl, p_ns, p_ng, p_rows, p_rowcell, p_stamp, p_cap;
+    std::vector<Pair64> p_key, p_rowkey; std::vector<Pair32> p_begin, p_nl, p_ns, p_ng, p_rows, p_rowcell, p_stamp, p_cap;
     std::map<uint32_t, FlagOp> fops;                                          // one merged op per slot
     auto fop = [&](uint32_t slot) -> FlagOp & { auto it = fops.find(slot); if (it == fops.end()) { FlagOp f{}; f.idx = slot; f.and_mask = 0xFF; f.or_mask = 0; it = fops.emplace(slot, f).first; } return it->second; };
     std::vector<uint32_t> refold; std::set<uint32_t> created; std::vector<std::pair<uint32_t, uint32_t>> freed;   // (level, slot): reusable from the next patch on
@@ -1477,7 +1481,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         for (uint32_t i = 0; i < size; i++) {
             const uint32_t pos = c->h_cell_begin[slot] + i, r = mem[i];
             if (c->h_rows[pos] != r || relocated) { c->h_rows[pos] = r; p_rows.push_back(Pair32{ pos, r }); }
-            if (i < nmem && c->h_row_cell[r] != (uint32_t)slot) { c->h_row_cell[r] = (uint32_t)slot; p_rowcell.push_back(Pair32{ r, (uint32_t)slot }); }
+            if (i < nmem && c->h_row_cell[r] != (uint32_t)slot) { c->h_row_cell[r] = (uint32_t)slot; p_rowcell.push_back(Pair32{ r, (uint32_t)slot }); p_rowkey.push_back(Pair64{ r, 0, K }); }
         }
         if (carry.changed_cells.count(K) || created.count((uint32_t)slot)) refold.push_back((uint32_t)slot);
     }
@@ -1566,7 +1570,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         std::vector<Pair32> *v32[9] = { &p_begin, &p_nl, &p_ns, &p_stamp, &p_rows, &p_rowcell, &p_cap, &p_rowsgc, &p_ng };      // (p_cap: the capacities the device-side re-bucket reads)
         uint32_t *dst32[9] = { c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_cell_stamp.p, c->d_rows.p, c->d_row_cell.p, c->d_cell_cap.p, c->d_rows_gc.p, c->d_cell_nghost.p };
         std::vector<Pair32> p_key32; p_key32.reserve(p_key.size()); for (const Pair64 &pk : p_key) p_key32.push_back(Pair32{ pk.idx, to_key32(pk.val) });   // the compact stream keys follow
-        size_t bytes = p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + (vf.size() + link_ops.size()) * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
+        size_t bytes = p_rowkey.size() * sizeof(Pair64) + 32 + p_key.size() * (sizeof(Pair64) + sizeof(Pair32)) + (vf.size() + link_ops.size()) * sizeof(FlagOp) + refold.size() * 4 + p_rows.size() * sizeof(Pair32) + 256;
         for (auto *v : v32) bytes += v->size() * sizeof(Pair32) + 16;
         if (c->d_stage.n < bytes) HIPCHK(c, c->d_stage.alloc(bytes * 2, nullptr));
         std::vector<uint8_t> host(bytes); size_t off = 0;
@@ -1575,6 +1579,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         size_t o32[9]; for (int k = 0; k < 9; k++) o32[k] = put(v32[k]->data(), v32[k]->size() * sizeof(Pair32));
         const size_t o_k32 = put(p_key32.data(), p_key32.size() * sizeof(Pair32));
         const size_t o_lk = put(link_ops.data(), link_ops.size() * sizeof(FlagOp));
+        const size_t o_rk = put(p_rowkey.data(), p_rowkey.size() * sizeof(Pair64));
         HIPCHK(c, hipMemcpyAsync(c->d_stage.p, host.data(), off, hipMemcpyHostToDevice, st));
         if ((c->cfg.flags & RE_CFG_PROBE) && !p_key.empty()) {                // the key -> slot table follows: retire the old keys of those slots, then enter the new ones
             for (uint32_t pass = 0; pass < 2; pass++)
@@ -1583,6 +1588,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         }
         if (!p_key32.empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)p_key32.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key32.size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o_k32), c->d_cell_key32.p);
         if (!p_key.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_key.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_key.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_key), c->d_cell_key.p);
+        if (!p_rowkey.empty()) hipLaunchKernelGGL(k_scatter64, dim3(((uint32_t)p_rowkey.size() + 255) / 256), dim3(256), 0, st, (uint32_t)p_rowkey.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p + o_rk), c->d_row_key.p);
         for (int k = 0; k < 9; k++) if (!v32[k]->empty()) hipLaunchKernelGGL(k_scatter32, dim3(((uint32_t)v32[k]->size() + 255) / 256), dim3(256), 0, st, (uint32_t)v32[k]->size(), reinterpret_cast<const Pair32 *>(c->d_stage.p + o32[k]), dst32[k]);
         std::vector<uint32_t> sh_gc(sh_total);
         for (uint32_t i = 0; i < sh_total; i++) sh_gc[i] = effective_gclass(c, c->h_rows[sh_region + i]);
@@ -1646,7 +1652,7 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
 static RbCells rb_cells(re_ctx *c) {
     RbCells C; C.cell_key = c->d_cell_key.p; C.cell_key32 = c->d_cell_key32.p; C.cell_begin = c->d_cell_begin.p; C.cell_cap = c->d_cell_cap.p; C.cell_nl = c->d_cell_nlocal.p;
     C.cell_ns = c->d_cell_nstatic.p; C.cell_ng = c->d_cell_nghost.p; C.cell_stamp = c->d_cell_stamp.p; C.cell_flags = c->d_cell_flags.p;
-    C.rows = c->d_rows.p; C.rows_gc = c->d_rows_gc.p; C.row_cell = c->d_row_cell.p; C.pool_cap = c->pool_cap; C.cell_links = c->d_cell_links.p;
+    C.rows = c->d_rows.p; C.rows_gc = c->d_rows_gc.p; C.row_cell = c->d_row_cell.p; C.row_key = c->d_row_key.p; C.pool_cap = c->pool_cap; C.cell_links = c->d_cell_links.p;
     return C;
 }
 static RbTables rb_tables(re_ctx *c) { RbTables T; T.base_keys = c->d_base_keys.p; T.nbase = (uint32_t)c->base_keys.size(); T.ovl_keys = c->d_ovl_keys.p; T.ovl_slots = c->d_ovl_slots.p; T.ovl_mask = c->ovl_cap - 1u; return T; }
@@ -2010,7 +2016,7 @@ static int finish_tick(re_ctx *c, re_tick_result *out) {
         if (out) *out = c->last_tick;
         return RE_OK;
     }
-    // fast completion: the counters arrive in mapped host memory behind the tick (k_tick_publish).  A tick that found movers or entities
+    // fast completion: the counters arrive in mapped host memory with the last wave of the tick (tick_sign_off).  A tick that found movers or entities
     // leaving the world (the stale word is raised before the counters are published) still needs resolve(): patch the tree, replay.
     bool done = false;
     if (c->tick_published && (!c->park_ready || !(c->park.busy || c->park.deferred_pack))) {
@@ -2057,10 +2063,10 @@ static int issue_tick(re_ctx *c, float dt, uint32_t flags) {
         hipExtLaunchKernelGGL(k_tick, dim3((c->ndyn + 255) / 256), dim3(256), 0, st, ta, tb, 0, c->ndyn, c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
                            row_arrays(c), c->d_row_cell.p, c->d_cell_key.p, c->d_cell_stamp.p, c->d_cell_flags.p, c->d_sh_cells.p, c->d_sh_aabb.p, c->d_params.p, dt,
                            (flags & RE_TICK_ALL_DYNAMIC) ? 1u : 0u, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_spec.p, c->d_hspec, c->frame,
-                           c->ndyn0, c->d_dyn_row.p);
+                           c->ndyn0, c->d_dyn_row.p, c->d_hth, (flags & RE_TICK_ASYNC) ? 0u : c->tick_seq + 1u);      // a synchronous tick publishes its counters itself (tick_sign_off): no second launch
         c->th_clean = false;
         c->tick_published = !(flags & RE_TICK_ASYNC);
-        if (c->tick_published) hipLaunchKernelGGL(k_tick_publish, dim3(1), dim3(64), 0, st, (const TickHeader *)c->d_th.p, c->d_hth, ++c->tick_seq);
+        if (c->tick_published) ++c->tick_seq;
     }
     if (c->dirty_pending) {                                                     // Pipeline::execute: clear_changed_static_unique (pipeline.rs:271)
         uint32_t m = std::max(c->ncells, c->nsh);
@@ -2179,7 +2185,7 @@ static int ensure_row_capacity(re_ctx *c, uint32_t need) {
     HIPCHK(c, grow_buf(c->d_gclass, n, new_cap, a, st)); HIPCHK(c, grow_buf(c->d_flags, n, new_cap, a, st));
     HIPCHK(c, grow_buf(c->d_pos, (size_t)n * 3, (size_t)new_cap * 3, a, st)); HIPCHK(c, grow_buf(c->d_rot, (size_t)n * 4, (size_t)new_cap * 4, a, st)); HIPCHK(c, grow_buf(c->d_scale, (size_t)n * 3, (size_t)new_cap * 3, a, st));
     HIPCHK(c, grow_buf(c->d_aabb, n, new_cap, a, st)); HIPCHK(c, grow_buf(c->d_orig, n, new_cap, a, st));
-    HIPCHK(c, grow_buf(c->d_row_cell, n, new_cap, a, st));
+    HIPCHK(c, grow_buf(c->d_row_cell, n, new_cap, a, st)); HIPCHK(c, grow_buf(c->d_row_key, n, new_cap, a, st));
     HIPCHK(c, hipMemsetAsync(c->d_row_cell.p + n, 0xFF, (size_t)(new_cap - n) * 4, st));                  // ROW_CELL_NONE: not in the tree
     {   // id / matrix columns: rows, then the ghost instances behind the row capacity
         DevBuf<uint32_t> nid; DevBuf<float> nmat;

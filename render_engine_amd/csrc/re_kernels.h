@@ -30,6 +30,7 @@ struct RowArrays {                          // one row per entity, in upload ord
     float *mat;                             // 16 floats, column-major, 64 B per row
     Aabb *aabb, *orig;                      // StaticAABB, OriginalAABB
     float *pos, *rot, *scale;               // 3, 4 (axis+angle), 3 floats
+    uint64_t *key;                          // the key of the row's own (unique) world section, kept in step with row_cell: the tick streams it instead of gathering cell_key[row_cell]
 };
 struct SharedRec { uint32_t row, nk; uint64_t keys[8]; };
 
@@ -66,7 +67,7 @@ struct FrameHeader {
 };
 struct FrameCounts { uint32_t n_candidates, n_vis_map, n_vis_vec; };
 constexpr uint32_t TICK_TICKET_SHARDS = 32, TICK_SHARD_STRIDE = 32;   // counters 128 bytes apart: atomics serialise per 128-byte line
-struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * TICK_SHARD_STRIDE]; };   // shard: k_tick's share of n_changed, one counter per 128-byte line (a single line serialises the waves' atomics); readers add them up
+struct TickHeader { uint32_t n_changed, n_rebucket, n_oob, ticket; uint32_t pad[12]; uint32_t shard[TICK_TICKET_SHARDS * TICK_SHARD_STRIDE]; };   // shard[k * STRIDE]: k_tick's share of n_changed, one counter per 128-byte line (a single line serialises the waves' atomics); readers add them up.  shard[k * STRIDE + 1] and pad[1] (device copy): the waves' sign-off counters (tick_sign_off); pad[0] (host copy): the seal
 // Speculation across frames of a world with dynamic entities: frames are enqueued without waiting for the previous tick; a tick that
 // finds entities that change section (or leave the world) raises `stale`, and every kernel enqueued after it cancels itself until the
 // host has patched the tree and replayed those frames.
@@ -197,7 +198,7 @@ __global__ void k_tick(uint32_t ndyn, float *dyn_vel, const float *dyn_acc, floa
                        const uint32_t *row_cell, const uint64_t *cell_key, const uint32_t *cell_stamp, const uint8_t *cell_flags, const int32_t *sh_cells,
                        const Aabb *sh_aabb, const FrameParams *P, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic, TickHeader *th,
                        uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, SpecState *spec, SpecState *h_spec, uint32_t tick_frame,
-                       uint32_t ndyn0, const uint32_t *dyn_row);
+                       uint32_t ndyn0, const uint32_t *dyn_row, TickHeader *h_th, uint32_t publish_seq);
 __global__ void k_shift_rows(uint32_t m, uint32_t *rows, uint32_t from, uint32_t delta);   // pool entries >= from (ghost instances) move up by delta when the row columns grow
 // Probe path of the visibility query (opt-in, RE_CFG_PROBE): instead of streaming every section key, enumerate the cells of the two
 // candidate boxes (their bounding box per level) and look each one up in a device hash table key -> slot, like the reference's
@@ -232,7 +233,6 @@ __global__ void k_col_pairs(ColHeader *hdr, const ColMoved *moved, uint32_t move
                             uint2 *pairs, uint32_t pair_cap);
 __global__ void k_col_clear(const ColHeader *hdr, const ColMoved *moved, uint32_t moved_cap, uint8_t *row_moved, unsigned long long *tab_key, unsigned long long *tab_min,
                             ColHeader *h_hdr, uint32_t call);
-__global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq);
 struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)
@@ -266,7 +266,7 @@ struct RbTables {                                            // key -> slot of t
 };
 struct RbCells {
     uint64_t *cell_key; uint32_t *cell_key32; uint32_t *cell_begin, *cell_cap, *cell_nl, *cell_ns, *cell_ng, *cell_stamp; uint8_t *cell_flags;
-    uint32_t *rows, *rows_gc, *row_cell; uint32_t pool_cap;
+    uint32_t *rows, *rows_gc, *row_cell; uint64_t *row_key; uint32_t pool_cap;
     const uint8_t *cell_links;                               // shared sections linking each unique section (maintained by the host paths)
 };
 hipError_t sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,

@@ -1248,13 +1248,15 @@ __device__ __forceinline__ void normalize3(const float v[3], float o[3]) {
 // OutOfBoundsLogic (ecs.remove_entity, :347; the tree keeps the stale entry -- the caller marks the row dead).  No atomics here.
 // what place_core reads from memory, so that a caller can request it early together with its own loads
 struct PlaceInputs { Aabb orig; float scl[3]; float c3w; uint64_t key; };
-__device__ __forceinline__ void place_prefetch(PlaceInputs &in, bool on, uint32_t r, uint32_t rc, const RowArrays &R, const uint64_t *__restrict__ cell_key) {
+// (nothing here depends on another load: the key column holds the key of the row's own section -- == cell_key[row_cell[r]] for a row in a unique
+// section, meaningless otherwise: place_core looks at it only then)
+__device__ __forceinline__ void place_prefetch(PlaceInputs &in, bool on, uint32_t r, const RowArrays &R) {
     in.orig = Aabb{ 0.f, 0.f, 0.f, 0.f, 0.f, 0.f }; in.scl[0] = in.scl[1] = in.scl[2] = 1.f; in.c3w = 1.f; in.key = 0;
     if (!on) return;
     in.orig = R.orig[r];
     in.scl[0] = R.scale[r * 3 + 0]; in.scl[1] = R.scale[r * 3 + 1]; in.scl[2] = R.scale[r * 3 + 2];
     in.c3w = R.mat[(size_t)r * 16 + 15];
-    if (rc != ROW_CELL_NONE && !(rc & ROW_CELL_SHARED)) in.key = cell_key[rc];
+    in.key = R.key[r];
 }
 __device__ __forceinline__ uint32_t place_core(uint32_t r, uint32_t fl, uint32_t rc, const float pos[3], const float rot[4], bool translation_only,
                                                 RowArrays R, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells, uint32_t outline, uint32_t atomic,
@@ -1323,7 +1325,7 @@ __device__ __forceinline__ void place_changed_entity(uint32_t r, uint32_t fl, ui
 // read -- and TransformationMatrix, StaticAABB, Rotation written -- as contiguous streams (80 B read + 104 B written per
 // ticking entity); the only gathers are the section stamp (the visibility gate) and, for ticking entities, the key of their section.
 // Counters: one atomic per wave (ballot + mbcnt), as in the cull kernel.
-__global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+__device__ __forceinline__ void tick_body(uint32_t ndyn, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
                                               float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
                                               RowArrays R, const uint32_t *__restrict__ row_cell,
                                               const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
@@ -1343,6 +1345,23 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     // ---- round trip 1: flag word and section slot of the row (coalesced), the frame number, and -- in the same round trip, not in front of it -- the speculation word
     const uint32_t fl = in ? R.flags[r] : F_DEAD, rc = in ? row_cell[r] : ROW_CELL_NONE;
     const uint32_t cull_frame = P.frame;
+    // RE_TICK_ALL_DYNAMIC: every live entity ticks, so every component is requested NOW, together with the flag word (one round trip from launch to
+    // arithmetic instead of two); a lane that turns out not to use a component -- or not to tick -- ignores what arrives.
+    float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f }, v[3] = { 0.f, 0.f, 0.f }, a[3] = { 0.f, 0.f, 0.f };
+    float4 wq = make_float4(1.f, 0.f, 0.f, 0.f), aq = make_float4(1.f, 0.f, 0.f, 0.f);
+    PlaceInputs pin;                                                              // what place_core needs from memory, requested in the same round trip
+    auto load_components = [&](bool on, bool by_flags) {
+        if (on) {
+            pos[0] = R.pos[r * 3 + 0]; pos[1] = R.pos[r * 3 + 1]; pos[2] = R.pos[r * 3 + 2];
+            const float4 q = reinterpret_cast<const float4 *>(R.rot)[r]; rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
+            if (!by_flags || (fl & F_HAS_VEL)) { v[0] = dyn_vel[j * 3 + 0]; v[1] = dyn_vel[j * 3 + 1]; v[2] = dyn_vel[j * 3 + 2]; }
+            if (!by_flags || (fl & F_HAS_ACC)) { a[0] = dyn_acc[j * 3 + 0]; a[1] = dyn_acc[j * 3 + 1]; a[2] = dyn_acc[j * 3 + 2]; }
+            if (!by_flags || (fl & F_HAS_ROTVEL)) wq = reinterpret_cast<const float4 *>(dyn_rotvel)[j];
+            if (!by_flags || (fl & F_HAS_ROTACC)) aq = reinterpret_cast<const float4 *>(dyn_rotacc)[j];
+        }
+        place_prefetch(pin, on, r, R);
+    };
+    if (tick_all) load_components(in, false);
     {
         const unsigned long long w = *reinterpret_cast<const volatile unsigned long long *>(spec);
         if ((uint32_t)w != 0u && (uint32_t)(w >> 32) != tick_frame) return;     // tick_frame: the frame this tick was issued for (a cancelled frame never wrote its parameters, so Pp->frame would be the stale one's)
@@ -1379,20 +1398,9 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
         if (in && nfl != fl) R.flags[r] = nfl;
         return;
     }
-    // ---- round trip 2: every component a ticking lane may need, requested together (all contiguous by row); whether a lane uses
-    // them is decided by its flag word afterwards -- no load below depends on another
-    float pos[3] = { 0.f, 0.f, 0.f }, rot[4] = { 1.f, 0.f, 0.f, 0.f }, v[3] = { 0.f, 0.f, 0.f }, a[3] = { 0.f, 0.f, 0.f };
-    float4 wq = make_float4(1.f, 0.f, 0.f, 0.f), aq = make_float4(1.f, 0.f, 0.f, 0.f);
-    if (run) {
-        pos[0] = R.pos[r * 3 + 0]; pos[1] = R.pos[r * 3 + 1]; pos[2] = R.pos[r * 3 + 2];
-        const float4 q = reinterpret_cast<const float4 *>(R.rot)[r]; rot[0] = q.x; rot[1] = q.y; rot[2] = q.z; rot[3] = q.w;
-        if (fl & F_HAS_VEL) { v[0] = dyn_vel[j * 3 + 0]; v[1] = dyn_vel[j * 3 + 1]; v[2] = dyn_vel[j * 3 + 2]; }
-        if (fl & F_HAS_ACC) { a[0] = dyn_acc[j * 3 + 0]; a[1] = dyn_acc[j * 3 + 1]; a[2] = dyn_acc[j * 3 + 2]; }
-        if (fl & F_HAS_ROTVEL) wq = reinterpret_cast<const float4 *>(dyn_rotvel)[j];
-        if (fl & F_HAS_ROTACC) aq = reinterpret_cast<const float4 *>(dyn_rotacc)[j];
-    }
-    PlaceInputs pin;                                                              // what place_core needs from memory, requested in the same round trip
-    place_prefetch(pin, run, r, rc, R, cell_key);
+    // ---- round trip 2 (the visibility-gated tick; RE_TICK_ALL_DYNAMIC asked for all of it in round trip 1): every component a ticking lane may need,
+    // requested together (all contiguous by row) -- no load below depends on another
+    if (!tick_all) load_components(run, true);
     // ---- apply_kinematics (logic_flow.rs:366-448)
     bool pos_set = false, rot_set = false;
     if (run) {
@@ -1454,15 +1462,41 @@ __global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__
     }
 }
 
-// The tick's counters for the host: a one-wave kernel behind k_tick copies them into mapped host memory and then publishes the tick's
-// sequence number there; the host polls that word instead of synchronising the stream and copying (and does not depend on what a
-// stream synchronise considers finished).
-__global__ void k_tick_publish(const TickHeader *th, TickHeader *h_th, uint32_t seq) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t a = th->n_changed; for (uint32_t k = 0; k < TICK_TICKET_SHARDS; k++) a += th->shard[k * TICK_SHARD_STRIDE];       // (n_changed itself: the per-lane adds of a change batch, k_apply_rows)
-    const uint32_t b = th->n_rebucket, c2 = th->n_oob;
+// The tick's counters for the host, published by the LAST wave of the tick itself (synchronous ticks: seq != 0), so that no second launch sits between
+// the tick and the host that polls for it.  Every wave signs off when it is done -- after a fence that puts its counter atomics in front of the
+// signature -- on one of 32 counters (each in the 128-byte line of a changed-count shard: atomics serialise per line), the wave that completes a
+// counter signs the top-level one, and the wave that completes that one reads the counters (agent-scope loads: the atomics live in L2), copies them
+// into mapped host memory and publishes the tick's sequence number there (publish_to_host).  Nobody waits for anybody: no wave spins.
+__device__ __forceinline__ void tick_sign_off(TickHeader *th, TickHeader *h_th, uint32_t seq) {
+    if (lane_id() != 0) return;
+    // Only ATOMICS are handed from wave to wave here (agent scope: performed at the device's coherence point, not in the XCD's L2), so the order
+    // that matters is "this wave's counter atomics have been performed before its signature is": s_waitcnt vmcnt(0).  A release FENCE in this
+    // place writes the XCD's L2 back once per wave -- measured: 57 us instead of 11 for 1,575 waves, 674 instead of 53 for 15,747.  (The mover /
+    // out-of-bounds lists are plain stores; their reader is the host behind the end of the kernel.)
+    wait_own_stores();
+    const uint32_t wpb = blockDim.x >> 6, W = gridDim.x * wpb, wv = blockIdx.x * wpb + (threadIdx.x >> 6), sh = wv & (TICK_TICKET_SHARDS - 1u);
+    const uint32_t expect = (W - sh + TICK_TICKET_SHARDS - 1u) / TICK_TICKET_SHARDS;          // waves whose index is sh modulo 32
+    if (atomicAdd(&th->shard[sh * TICK_SHARD_STRIDE + 1u], 1u) + 1u != expect) return;
+    const uint32_t ntop = W < TICK_TICKET_SHARDS ? W : TICK_TICKET_SHARDS;
+    if (atomicAdd(&th->pad[1], 1u) + 1u != ntop) return;                    // (issued after the atomic above has returned)
+    uint32_t a = __hip_atomic_load(&th->n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (n_changed itself: the per-lane adds of a change batch, k_apply_rows)
+    for (uint32_t k2 = 0; k2 < TICK_TICKET_SHARDS; k2++) a += __hip_atomic_load(&th->shard[k2 * TICK_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t b = __hip_atomic_load(&th->n_rebucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), c2 = __hip_atomic_load(&th->n_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);   // seal: the reader checks it
     publish_to_host(&h_th->ticket, seq);
+}
+__global__ __launch_bounds__(256) void k_tick(uint32_t ndyn, float *__restrict__ dyn_vel, const float *__restrict__ dyn_acc,
+                                              float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc,
+                                              RowArrays R, const uint32_t *__restrict__ row_cell,
+                                              const uint64_t *__restrict__ cell_key, const uint32_t *__restrict__ cell_stamp, const uint8_t *__restrict__ cell_flags,
+                                              const int32_t *__restrict__ sh_cells, const Aabb *__restrict__ sh_aabb,
+                                              const FrameParams *__restrict__ Pp, float dt, uint32_t tick_all, uint32_t outline, uint32_t atomic,
+                                              TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap,
+                                              SpecState *spec, SpecState *h_spec, uint32_t tick_frame, uint32_t ndyn0, const uint32_t *__restrict__ dyn_row,
+                                              TickHeader *h_th, uint32_t publish_seq) {
+    tick_body(ndyn, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc, R, row_cell, cell_key, cell_stamp, cell_flags, sh_cells, sh_aabb, Pp, dt, tick_all, outline, atomic, th, mover_rows, oob_rows,
+              list_cap, spec, h_spec, tick_frame, ndyn0, dyn_row);
+    if (publish_seq) tick_sign_off(th, h_th, publish_seq);                  // every wave, whichever way it left the body
 }
 
 // section decision (add_entity with add_if_out_bounds = true: the box is clamped) for a list of rows, from their current StaticAABB;
@@ -1742,7 +1776,7 @@ __global__ __launch_bounds__(64) void k_rb_apply(const uint32_t *__restrict__ pe
     // merge the arrivals into the kept rows, from the back
     for (int32_t i = (int32_t)m - 1, j = (int32_t)a - 1, k = (int32_t)nl1 - 1; j >= 0; k--) {
         if (i >= 0 && R.id[C.rows[begin + i]] > R.id[tmp_row[S.op_begin + j]]) { C.rows[begin + k] = C.rows[begin + i]; C.rows_gc[begin + k] = C.rows_gc[begin + i]; i--; }
-        else { const uint32_t r = tmp_row[S.op_begin + j]; C.rows[begin + k] = r; C.rows_gc[begin + k] = R.gclass[r]; C.row_cell[r] = sl; j--; }
+        else { const uint32_t r = tmp_row[S.op_begin + j]; C.rows[begin + k] = r; C.rows_gc[begin + k] = R.gclass[r]; C.row_cell[r] = sl; C.row_key[r] = S.key; j--; }
     }
     C.cell_nl[sl] = nl1;
     const uint8_t f = S.created ? (uint8_t)0 : C.cell_flags[sl];
