@@ -259,6 +259,21 @@ int re_comm_destroy(re_ctx *ctx);      /* also done by re_destroy */
 int re_allgather_visible(re_ctx *ctx, uint32_t flags, re_gathered *out /* nullable */);
 int re_gather_wait(re_ctx *ctx, re_gathered *out /* nullable */);
 
+/* ---- entities that move from one GPU's share of the world to another's ("movers that cross a shard boundary need a second, sparse exchange") ----
+ * A context owns the world sections whose key lies in [key_lo, key_hi) (re_set_shard_range; the smallest key of an entity's section(s) decides, as in
+ * re_section_keys).  After a tick, re_list_migrants names the entities of this context whose section has left that range; re_export_entities returns
+ * their complete state -- the record layout of EntityTransformationBuilder's choices, one re_entity_state per entity, the components as they are NOW --;
+ * the host removes them here (RE_CHANGE_DELETE), routes each record to the owner of its new section over its own channel (a few records per frame) and
+ * registers them there with re_add_entities.  Entities of a unique section live on exactly one GPU, so a mover between unique sections needs nothing
+ * else; halo replicas (RE_F_PHANTOM) of shared sections that straddle the boundary are not migrated. */
+typedef struct re_entity_state {
+    uint32_t entity_id, model_index, render_system, sortable, flags;
+    float original_aabb[6], position[3], rotation[4], scale[3], velocity[3], acceleration[3], rotation_velocity[4], rotation_acceleration[4];
+} re_entity_state;
+int re_set_shard_range(re_ctx *ctx, uint64_t key_lo, uint64_t key_hi);      /* key_lo == key_hi == 0: the context owns everything (default) */
+int re_list_migrants(re_ctx *ctx, uint32_t *entity_ids, uint32_t capacity, uint32_t *n);   /* entities re-bucketed since the last call whose smallest section key is outside the range; drains the list */
+int re_export_entities(re_ctx *ctx, const uint32_t *entity_ids, uint32_t n, re_entity_state *out);
+
 /* Change requests returned by user logic (LogicFunction / CollisionFunction -> Vec<EntityChangeInformation>,
  * objects/entity_change_request.rs) == apply_change (helper_things/entity_change_helpers.rs:32-189) for the kinds that touch
  * this path.  Processed in list order with the reference's rules: the last write of a component wins; Position alone takes
@@ -404,6 +419,9 @@ int re_timing_begin(re_ctx *ctx, uint32_t max_launches, uint32_t every);
 int re_timing_collect(re_ctx *ctx, float *microseconds, uint32_t capacity, uint32_t *n);
 /* number of world sections inside a candidate box in the last cull (== hash probes the reference would make) */
 int re_get_last_candidates(re_ctx *ctx, uint32_t *n_candidates);
+/* bytes of DEVICE memory of the ctx (a packed or gathered buffer) into host memory, ordered behind the work on the ctx's stream -- for hosts that hold no HIP
+ * runtime of their own, or a different one (a process may carry a second ROCm stack: a pointer of this library means nothing to that one) */
+int re_debug_copy_to_host(re_ctx *ctx, const void *d_src, void *dst, uint64_t bytes);
 /* the HIP stream of the ctx (hipStream_t as void*) so callers can order their own work after it */
 void *re_get_stream(re_ctx *ctx);
 

@@ -105,8 +105,8 @@ class Lights(C.Structure):
 
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_set_model_lod", "re_cull_pack", "re_tick",
-           "re_apply_changes", "re_apply_changes_ex", "re_add_entities", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_section_keys", "re_get_out_of_bounds", "re_get_stats",
-           "re_debug_get_sections", "re_debug_get_visible_sections", "re_get_timings", "re_get_stream",
+           "re_apply_changes", "re_apply_changes_ex", "re_add_entities", "re_set_shard_range", "re_list_migrants", "re_export_entities", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_section_keys", "re_get_out_of_bounds", "re_get_stats",
+           "re_debug_get_sections", "re_debug_get_visible_sections", "re_debug_copy_to_host", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
            "re_lighting_run", "re_lighting_read", "re_lighting_read_pixels",
@@ -114,20 +114,16 @@ EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upl
            "re_history_count", "re_history_get", "re_history_encode", "re_history_write", "re_history_load"]
 
 _lib = None
-_hip = None
 
 
-def device_to_host(ptr, nbytes):
-    """bytes of device memory (hipMemcpy through the HIP runtime the library itself links): used by tests / the bench to look at gathered buffers"""
-    global _hip
+def device_to_host(handle, ptr, nbytes):
+    """bytes of device memory through the library itself (re_debug_copy_to_host): the process may hold a second HIP runtime (a PyTorch wheel brings its
+    own), and a pointer of this library means nothing to that one"""
     import numpy as np
-    if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
-        _hip.hipMemcpy.restype = C.c_int; _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     out = np.zeros(max(nbytes, 1), np.uint8)
-    rc = _hip.hipMemcpy(out.ctypes.data, ptr, nbytes, 2)
+    rc = load().re_debug_copy_to_host(handle, ptr, out.ctypes.data, nbytes)
     if rc != 0:
-        raise RuntimeError(f"hipMemcpy failed ({rc})")
+        raise RuntimeError(f"re_debug_copy_to_host failed ({rc})")
     return out[:nbytes]
 
 
@@ -166,6 +162,9 @@ def load():
     L.re_apply_changes.restype = C.c_int; L.re_apply_changes.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(TickResult)]
     L.re_apply_changes_ex.restype = C.c_int; L.re_apply_changes_ex.argtypes = [vp, vp, C.c_uint32, C.POINTER(Entities), C.c_uint32, C.POINTER(TickResult)]
     L.re_add_entities.restype = C.c_int; L.re_add_entities.argtypes = [vp, C.POINTER(Entities), _u32p]
+    L.re_set_shard_range.restype = C.c_int; L.re_set_shard_range.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.re_list_migrants.restype = C.c_int; L.re_list_migrants.argtypes = [vp, vp, C.c_uint32, _u32p]
+    L.re_export_entities.restype = C.c_int; L.re_export_entities.argtypes = [vp, vp, C.c_uint32, vp]
     L.re_copy_visible.restype = C.c_int; L.re_copy_visible.argtypes = [vp, vp, vp, C.c_uint32, _u32p]
     L.re_set_output_buffers.restype = C.c_int; L.re_set_output_buffers.argtypes = [vp, vp, vp, C.c_uint32]
     L.re_read_component.restype = C.c_int; L.re_read_component.argtypes = [vp, C.c_uint32, C.c_int, vp]
@@ -178,6 +177,7 @@ def load():
     L.re_debug_get_sections.restype = C.c_int; L.re_debug_get_sections.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, _u32p]
     L.re_debug_get_visible_sections.restype = C.c_int; L.re_debug_get_visible_sections.argtypes = [vp, C.c_uint32, vp, vp, _u32p]
     L.re_get_timings.restype = C.c_int; L.re_get_timings.argtypes = [vp, _fp, _fp, _fp]
+    L.re_debug_copy_to_host.restype = C.c_int; L.re_debug_copy_to_host.argtypes = [vp, vp, vp, C.c_uint64]
     L.re_get_stream.restype = vp; L.re_get_stream.argtypes = [vp]
     L.re_set_output_count.restype = C.c_int; L.re_set_output_count.argtypes = [vp, vp]
     L.re_timing_begin.restype = C.c_int; L.re_timing_begin.argtypes = [vp, C.c_uint32, C.c_uint32]

@@ -192,6 +192,7 @@ struct re_ctx {
     // waves (one crowded section, a cluster) can fill one segment while the list as a whole has room.  The pack kernels report that
     // (RESULT_SEGMENT_OVERFLOW); finish_cull then redoes the frame with the list as ONE segment -- which holds every instance of the world twice
     // (duplicates mode) by construction -- and the context stays in that mode until the next upload.
+    uint64_t shard_lo = 0, shard_hi = 0; std::vector<uint32_t> moved_rows;   // re_set_shard_range: the keys this context owns; rows re-bucketed since the last re_list_migrants
     bool single_shard = false; uint32_t n_segment_redos = 0; re_camera last_cam{}; uint32_t last_cull_flags = 0;
     // what the last frame's pack was launched with, so that it can be run again into other output buffers (the second, variable-length round of the
     // multi-GPU exchange when a rank's visible set outgrew its slab)
@@ -201,7 +202,8 @@ struct re_ctx {
     struct Comm {
         void *comm = nullptr; bool owned = false; int rank = 0, n = 1; uint32_t cap = 0, words = 0, seq = 0; int last = -1, pending = -1;
         DevBuf<uint32_t> slab[2], recv[2], big_ids; DevBuf<float> big_mats; uint32_t big_cap = 0;
-        std::vector<uint32_t> h_hdr, counts; uint32_t n_second_rounds = 0, n_regathers = 0;
+        std::vector<uint32_t> counts; uint32_t n_second_rounds = 0, n_regathers = 0;
+        uint32_t *h_hdr = nullptr, *d_hhdr = nullptr, hdr_seq = 0;          // the gathered slab headers in mapped host memory ([n ranks][4 words], then the sequence word k_gather_headers publishes)
     } comm;
     float t_cull = 0, t_pack = 0, t_tick = 0; bool timed_frame = false, timed_tick = false;
     // device-side re-bucket bookkeeping (rebucket_on_device): lookup tables, scratch, and the sections whose host mirrors are behind the device
@@ -1830,6 +1832,11 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
     if (n_movers > c->list_cap) return c->fail(RE_E_CAPACITY, "mover list overflow");
     std::vector<uint32_t> movers; bool second_batch = false;              // second_batch: the device took the movers between unique sections, these are the rest
+    if (c->shard_hi && n_movers) {                                          // a sharded world: remember who moved (re_list_migrants looks at where they went)
+        const uint32_t m0 = std::min(n_movers, c->list_cap); const size_t at = c->moved_rows.size();
+        c->moved_rows.resize(at + m0);
+        HIPCHK(c, hipMemcpy(c->moved_rows.data() + at, c->d_movers.p, (size_t)m0 * 4, hipMemcpyDeviceToHost));
+    }
     if (!pre && !ghost_touched) {
         int drc = rebucket_on_device(c, n_movers, &movers);
         if (drc < 0) return drc;
@@ -2293,7 +2300,7 @@ static int create_rows(re_ctx *c, const re_entities *E, const std::vector<NewRow
     bool grew = false;
     for (uint32_t k = 0; k < m; k++) {
         const size_t i = rows[k].src;
-        uint32_t fl = E->flags[i] & ~(F_HAS_MOVED | F_HAS_ROTATED | F_DEAD);
+        uint32_t fl = E->flags[i] & ~F_DEAD;                                 // (HasMoved / HasRotated as given: an entity that arrives from another GPU keeps the markers of its last tick)
         if (fl & F_PHANTOM) fl &= ~(F_HAS_VEL | F_HAS_ACC | F_HAS_ROTVEL | F_HAS_ROTACC | F_ALWAYS_EXEC | F_USER | F_LIGHT_ANY);
         if ((fl & F_HAS_ROT) && !E->rotation) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_ROT but rotation == NULL", (uint32_t)i);
         if ((fl & F_HAS_SCALE) && !E->scale) return c->fail(RE_E_ARG, "added entity %u has RE_F_HAS_SCALE but scale == NULL", (uint32_t)i);
@@ -2766,11 +2773,23 @@ static bool load() {
     void *h = nullptr;
     const char *env = getenv("RE_RCCL_LIBRARY");
     if (env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);           // the copy the process already uses (e.g. the one a framework brought along)
-    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    // The RCCL that belongs to the HIP runtime THIS library is bound to: the one installed next to it.  A process may hold a second ROCm stack -- a
+    // PyTorch wheel brings its own libamdhip64.so / libhsa-runtime64.so / librccl.so under other sonames --, and a communicator created by that stack's
+    // RCCL cannot take this library's streams and buffers (its HSA runtime may not even be initialised: ncclCommInitRank then fails with "no
+    // ROCm-capable device is detected").  Round 2 looked for an already loaded librccl first and found exactly that copy.
+    if (!h) {
+        Dl_info di{};
+        if (dladdr(reinterpret_cast<const void *>(&hipGetDeviceCount), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname); const size_t sl = dir.rfind('/');
+            if (sl != std::string::npos) {
+                dir.resize(sl + 1);
+                for (const char *name : { "librccl.so.1", "librccl.so" }) if (!h) h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+            }
+        }
+    }
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) { load_error = std::string("RCCL could not be loaded: ") + (dlerror() ? dlerror() : "?"); return false; }
     GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
     CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -2789,6 +2808,7 @@ static void comm_release(re_ctx *c) {
     if (m.comm && m.owned && rccl::CommDestroy) (void)rccl::CommDestroy(reinterpret_cast<rccl::ncclComm_t>(m.comm));
     for (int b = 0; b < 2; b++) { m.slab[b].release(&c->dev_bytes); m.recv[b].release(&c->dev_bytes); }
     m.big_ids.release(&c->dev_bytes); m.big_mats.release(&c->dev_bytes);
+    if (m.h_hdr) (void)hipHostFree(m.h_hdr);
     m = re_ctx::Comm{};
     c->ext_out_ids = nullptr; c->ext_out_mats = nullptr; c->ext_out_cap = 0; c->ext_out_count = nullptr;
 }
@@ -2800,7 +2820,10 @@ static int comm_setup(re_ctx *c, void *comm, bool owned, int rank, int n_ranks, 
         HIPCHK(c, m.slab[b].alloc(m.words, &c->dev_bytes)); HIPCHK(c, m.recv[b].alloc((size_t)m.words * n_ranks, &c->dev_bytes));
         HIPCHK(c, hipMemset(m.slab[b].p, 0, (size_t)m.words * 4)); HIPCHK(c, hipMemset(m.recv[b].p, 0, (size_t)m.words * n_ranks * 4));
     }
-    m.h_hdr.assign((size_t)n_ranks * 4, 0u); m.counts.assign(n_ranks, 0u); m.seq = 0; m.last = -1; m.pending = -1;
+    HIPCHK(c, hipHostMalloc(reinterpret_cast<void **>(&m.h_hdr), ((size_t)n_ranks * 4 + 32) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(m.h_hdr, 0, ((size_t)n_ranks * 4 + 32) * 4);
+    HIPCHK(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&m.d_hhdr), m.h_hdr, 0));
+    m.counts.assign(n_ranks, 0u); m.seq = 0; m.last = -1; m.pending = -1; m.hdr_seq = 0;
     return RE_OK;
 }
 extern "C" int re_comm_unique_id(uint8_t *id) try {
@@ -2863,6 +2886,9 @@ static int repack_last_frame(re_ctx *c, uint32_t *ids, float *mats, uint32_t cap
 static int gather_enqueue(re_ctx *c, int b) {
     re_ctx::Comm &m = c->comm;
     NCCLCHK(c, rccl::AllGather(m.slab[b].p, m.recv[b].p, m.words, rccl::Int32, reinterpret_cast<rccl::ncclComm_t>(m.comm), c->stream));
+    // the gathered headers follow the collective into mapped host memory (no stream synchronise, no per-rank copy)
+    hipLaunchKernelGGL(k_gather_headers, dim3(1), dim3(64), 0, c->stream, (uint32_t)m.n, (const uint32_t *)m.recv[b].p, m.words, m.d_hhdr, m.d_hhdr + (size_t)m.n * 4, ++m.hdr_seq);
+    HIPCHK(c, hipGetLastError());
     return RE_OK;
 }
 static int gather_finish(re_ctx *c, re_gathered *out) {
@@ -2870,9 +2896,14 @@ static int gather_finish(re_ctx *c, re_gathered *out) {
     const int b = m.pending >= 0 ? m.pending : m.last;
     if (b < 0) return c->fail(RE_E_STATE, "re_allgather_visible: no frame has been packed since re_comm_init");
     m.pending = -1;
-    auto read_headers = [&]() -> int {
-        HIPCHK(c, sync_stream(c->stream));
-        for (int r = 0; r < m.n; r++) HIPCHK(c, hipMemcpy(&m.h_hdr[(size_t)r * 4], m.recv[b].p + (size_t)r * m.words, 16, hipMemcpyDeviceToHost));
+    auto read_headers = [&]() -> int {                                       // poll the sequence word k_gather_headers publishes behind the collective
+        const volatile uint32_t *flag = m.h_hdr + (size_t)m.n * 4;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool done = false;
+        for (uint32_t spins = 0; !(done = (*flag == m.hdr_seq)); spins++)
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;   // a long collective: let the driver wait
+        if (!done) HIPCHK(c, sync_stream(c->stream));
+        std::atomic_thread_fence(std::memory_order_acquire);
         return RE_OK;
     };
     { int rc = read_headers(); if (rc != RE_OK) return rc; }
@@ -2933,6 +2964,67 @@ extern "C" int re_gather_wait(re_ctx *c, re_gathered *out) try {
     HIPCHK(c, hipSetDevice(c->device));
     return gather_finish(c, out);
 } RE_ABI_GUARD(c, "re_gather_wait")
+
+extern "C" int re_set_shard_range(re_ctx *c, uint64_t key_lo, uint64_t key_hi) try {
+    if (!c) return RE_E_ARG;
+    if (key_lo > key_hi) return c->fail(RE_E_ARG, "re_set_shard_range: key_lo > key_hi");
+    c->shard_lo = key_lo; c->shard_hi = key_hi; c->moved_rows.clear();
+    return RE_OK;
+} RE_ABI_GUARD(c, "re_set_shard_range")
+extern "C" int re_list_migrants(re_ctx *c, uint32_t *ids, uint32_t capacity, uint32_t *n) try {
+    if (!c || !n || (capacity && !ids)) return RE_E_ARG;
+    *n = 0;
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_list_migrants: no world uploaded");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    { int rc = resolve(c); if (rc != RE_OK) return rc; }
+    { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
+    if (!c->shard_hi) { c->moved_rows.clear(); return RE_OK; }
+    std::sort(c->moved_rows.begin(), c->moved_rows.end(), [](uint32_t a, uint32_t b) { return (a & 0x7FFFFFFFu) < (b & 0x7FFFFFFFu); });
+    uint32_t cnt = 0, prev = 0xFFFFFFFFu;
+    for (uint32_t w : c->moved_rows) {
+        const uint32_t r = w & 0x7FFFFFFFu;                                  // (bit 31 of a mover word: translation-only)
+        if (r == prev || r >= c->n) continue;
+        prev = r;
+        if ((c->h_flags[r] & (F_DEAD | F_PHANTOM)) || !c->h_row_nk[r]) continue;
+        uint64_t first = c->h_row_key[r];
+        if (c->h_row_nk[r] > 1) { const auto &ks = c->h_row_shared_keys[r]; first = ks[0]; for (uint32_t k = 1; k < c->h_row_nk[r]; k++) first = std::min(first, ks[k]); }
+        if (first >= c->shard_lo && first < c->shard_hi) continue;
+        if (cnt < capacity) ids[cnt] = c->h_id[r];
+        cnt++;
+    }
+    *n = cnt;
+    if (cnt <= capacity) c->moved_rows.clear();                              // (a list that did not fit is kept for a second call with room)
+    return RE_OK;
+} RE_ABI_GUARD(c, "re_list_migrants")
+extern "C" int re_export_entities(re_ctx *c, const uint32_t *ids, uint32_t n, re_entity_state *out) try {
+    if (!c || (n && (!ids || !out))) return RE_E_ARG;
+    if (!c->h_res) return c->fail(RE_E_STATE, "re_export_entities: no world uploaded");
+    if (!n) return RE_OK;
+    static_assert(sizeof(re_entity_state) == sizeof(ExportRec) && sizeof(ExportRec) == 140, "re_entity_state layout");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
+    { int rc = resolve(c); if (rc != RE_OK) return rc; }
+    std::vector<uint32_t> rows(n), slots(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!c->row_of(ids[i], &rows[i]) || (c->h_flags[rows[i]] & F_DEAD)) return c->fail(RE_E_ARG, "re_export_entities: unknown entity %u", ids[i]);
+        uint32_t j = 0; slots[i] = c->dyn_index(rows[i], j) ? j : 0xFFFFFFFFu;
+    }
+    DevBuf<uint32_t> d_rows, d_slots; DevBuf<ExportRec> d_out;
+    auto done = [&](int rc) { d_rows.release(nullptr); d_slots.release(nullptr); d_out.release(nullptr); return rc; };
+    if (d_rows.alloc(n, nullptr) != hipSuccess || d_slots.alloc(n, nullptr) != hipSuccess || d_out.alloc(n, nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "re_export_entities: out of device memory"));
+    hipStream_t st = c->stream;
+    (void)hipMemcpyAsync(d_rows.p, rows.data(), (size_t)n * 4, hipMemcpyHostToDevice, st); (void)hipMemcpyAsync(d_slots.p, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(k_export_rows, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows.p, d_slots.p, row_arrays(c), c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p, d_out.p);
+    (void)hipMemcpyAsync(out, d_out.p, (size_t)n * sizeof(ExportRec), hipMemcpyDeviceToHost, st);
+    if (hipGetLastError() != hipSuccess || sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "re_export_entities: kernel / copy failed"));
+    for (uint32_t i = 0; i < n; i++) {                                       // what the device rows do not hold: the group's ModelId / sortable index, and the tree's static bit
+        const GroupKey &g = c->h_gkeys[c->h_gclass[rows[i]]];
+        out[i].model_index = g.model; out[i].render_system = g.rs; out[i].sortable = g.sort;
+        out[i].flags = (out[i].flags & ~(F_STATIC | F_DEAD)) | (c->h_flags[rows[i]] & F_STATIC);
+    }
+    return done(RE_OK);
+} RE_ABI_GUARD(c, "re_export_entities")
 
 extern "C" int re_wait(re_ctx *c, re_visible *out_visible, re_tick_result *out_tick) try {
     if (!c) return RE_E_ARG;
@@ -3220,6 +3312,13 @@ extern "C" int re_get_timings(re_ctx *c, float *cull_us, float *pack_us, float *
     return RE_OK;
 } RE_ABI_GUARD(c, "re_get_timings")
 
+extern "C" int re_debug_copy_to_host(re_ctx *c, const void *d_src, void *dst, uint64_t bytes) try {
+    if (!c || (bytes && (!d_src || !dst))) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, sync_stream(c->stream));
+    return RE_OK;
+} RE_ABI_GUARD(c, "re_debug_copy_to_host")
 extern "C" void *re_get_stream(re_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
 // per-launch HIP-event timing of the dominant kernel (k_scan_cull) over a timed region, every `every`-th launch (timed dispatches

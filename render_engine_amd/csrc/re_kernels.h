@@ -291,6 +291,10 @@ __global__ void k_fold_tight_list(uint32_t m, const uint32_t *slots, const uint6
                                   const uint32_t *rows, const Aabb *ent_aabb, Aabb *cell_tight, uint32_t atomic, int too_many);
 // ECS::get_indexes_for_components over the presence column: ids of the live rows whose flag word has every bit of need_mask
 __global__ void k_query_flags(uint32_t n, const uint32_t *flags, const uint32_t *row_id, uint32_t need_mask, uint32_t *out_ids, uint32_t cap, uint32_t *count);
+struct ExportRec { uint32_t id, model_index, render_system, sortable, flags; float orig[6], pos[3], rot[4], scale[3], vel[3], acc[3], rotvel[4], rotacc[4]; };   // == re_entity_state (include/re_hip.h)
+__global__ void k_export_rows(uint32_t m, const uint32_t *rows, const uint32_t *dyn_slot, RowArrays R, const float *dyn_vel, const float *dyn_acc, const float *dyn_rotvel,
+                              const float *dyn_rotacc, ExportRec *out);
+__global__ void k_gather_headers(uint32_t n_ranks, const uint32_t *recv, uint32_t words_per_rank, uint32_t *h_hdr, uint32_t *h_seq, uint32_t seq);
 __global__ void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count);
 
 }  // namespace re

@@ -1829,6 +1829,37 @@ __global__ __launch_bounds__(256) void k_visible_lights(uint32_t n, const uint32
     if (vis) { const uint32_t o = atomicAdd(count, 1u); if (o < cap) out_ids[o] = row_id[r]; }
 }
 
+// re_export_entities: the complete state of a few entities (a migrant's record for another GPU), gathered row by row
+__global__ __launch_bounds__(256) void k_export_rows(uint32_t m, const uint32_t *__restrict__ rows, const uint32_t *__restrict__ dyn_slot, RowArrays R, const float *__restrict__ dyn_vel,
+                                                     const float *__restrict__ dyn_acc, const float *__restrict__ dyn_rotvel, const float *__restrict__ dyn_rotacc, ExportRec *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t r = rows[i], j = dyn_slot[i];
+    ExportRec e{};
+    e.id = R.id[r]; e.flags = R.flags[r];
+    const Aabb o = R.orig[r]; e.orig[0] = o.xmin; e.orig[1] = o.xmax; e.orig[2] = o.ymin; e.orig[3] = o.ymax; e.orig[4] = o.zmin; e.orig[5] = o.zmax;
+    for (int q = 0; q < 3; q++) { e.pos[q] = R.pos[(size_t)r * 3 + q]; e.scale[q] = R.scale[(size_t)r * 3 + q]; }
+    for (int q = 0; q < 4; q++) e.rot[q] = R.rot[(size_t)r * 4 + q];
+    e.rotvel[0] = e.rotacc[0] = 1.0f;
+    if (j != 0xFFFFFFFFu) {
+        for (int q = 0; q < 3; q++) { e.vel[q] = dyn_vel[(size_t)j * 3 + q]; e.acc[q] = dyn_acc[(size_t)j * 3 + q]; }
+        for (int q = 0; q < 4; q++) { e.rotvel[q] = dyn_rotvel[(size_t)j * 4 + q]; e.rotacc[q] = dyn_rotacc[(size_t)j * 4 + q]; }
+    }
+    out[i] = e;
+}
+
+// The slab headers of an all-gathered frame for the host (re_allgather_visible): one wave behind the collective copies the 4-word header of every rank's slab
+// into mapped host memory and publishes the exchange's sequence number there -- the host polls that word (one PCIe write's latency) instead of
+// synchronising the stream and issuing one blocking 16-byte copy per rank.
+__global__ __launch_bounds__(64) void k_gather_headers(uint32_t n_ranks, const uint32_t *__restrict__ recv, uint32_t words_per_rank, uint32_t *h_hdr, uint32_t *h_seq, uint32_t seq) {
+    for (uint32_t r = threadIdx.x; r < n_ranks; r += 64u) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(recv + (size_t)r * words_per_rank);
+        *reinterpret_cast<uint4 *>(h_hdr + (size_t)r * 4u) = v;
+    }
+    wait_own_stores();                                       // (one wave: every lane's host stores have left before lane 0 publishes)
+    if (threadIdx.x == 0) publish_to_host(h_seq, seq);
+}
+
 // gathers the visible sections of the last cull for re_debug_get_visible_sections
 __global__ __launch_bounds__(256) void k_collect_visible(uint32_t ncells, const uint32_t *cell_stamp, uint32_t frame, uint32_t *out_idx, uint8_t *out_mult, uint32_t cap, uint32_t *count) {
     uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;

@@ -20,6 +20,52 @@ def shard_bounds(n_units, world_size):
     return out
 
 
+def key_ranges_from_cuts(cut_keys):
+    """[(lo, hi)] per rank from the ascending first keys of ranks 1..N-1: rank r owns the world sections with cut[r-1] <= key < cut[r]"""
+    edges = [0] + [int(k) for k in cut_keys] + [1 << 63]
+    return [(edges[r], edges[r + 1]) for r in range(len(edges) - 1)]
+
+
+def route_migrants(states, ranges, tree_outline_length=16384, tree_atomic_length=64):
+    """The owner of every migrant record (ENTITY_DT array): the rank whose key range holds the smallest key of the entity's world section(s) --
+    host arithmetic (re_section_keys), the same on every rank.  Returns one index array per rank; entities out of bounds (no section) go nowhere."""
+    import numpy as np
+    from .pipeline import first_section_keys
+    if not len(states):
+        return [np.zeros(0, np.int64) for _ in ranges]
+    first = first_section_keys(states, tree_outline_length, tree_atomic_length)
+    out = []
+    for lo, hi in ranges:
+        out.append(np.nonzero((first != 0) & (first >= np.uint64(lo)) & (first < np.uint64(hi)))[0])
+    return out
+
+
+def exchange_migrants(pipeline, dist, ranges, group=None, tree_outline_length=16384, tree_atomic_length=64):
+    """The frame's second, sparse exchange: every rank hands over the entities whose section left its key range (take_migrants: list,
+    export, remove), the records travel over the host channel (a few per frame: all_gather_object), and every rank registers the ones whose new
+    section it owns (register_model_instances appends).  Call between frames, after the tick.  Returns (sent, received)."""
+    import numpy as np
+    from .pipeline import ENTITY_DT
+    mine = pipeline.take_migrants()
+    world = dist.get_world_size(group)
+    box = [None] * world
+    dist.all_gather_object(box, mine.tobytes(), group=group)
+    rank = dist.get_rank(group)
+    got = []
+    for r, blob in enumerate(box):
+        if r == rank or not blob:
+            continue
+        st = np.frombuffer(blob, ENTITY_DT)
+        sel = route_migrants(st, ranges, tree_outline_length, tree_atomic_length)[rank]
+        if len(sel):
+            got.append(st[sel])
+    if got:
+        new = np.concatenate(got)
+        pipeline.register_model_instances(new)
+        return len(mine), len(new)
+    return len(mine), 0
+
+
 def allgather_packed(ids, mats, n_local, dist, group=None):
     """Variable-length all-gather of {entity id, 4x4 matrix} slabs.
 

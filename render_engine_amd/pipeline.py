@@ -370,11 +370,44 @@ class Pipeline:
         if copy:                                           # rank-ordered concatenation on the host
             ids, mats = [], []
             for r, n in enumerate(counts):
-                ids.append(_capi.device_to_host(g.d_entity_ids + 4 * r * g.ids_rank_stride, 4 * n).view(np.uint32))
-                mats.append(_capi.device_to_host(g.d_matrices + 4 * r * g.matrices_rank_stride, 64 * n).view(np.float32).reshape(n, 16))
+                ids.append(_capi.device_to_host(self._h, g.d_entity_ids + 4 * r * g.ids_rank_stride, 4 * n).view(np.uint32))
+                mats.append(_capi.device_to_host(self._h, g.d_matrices + 4 * r * g.matrices_rank_stride, 64 * n).view(np.float32).reshape(n, 16))
             out["ids"] = np.concatenate(ids) if ids else np.zeros(0, np.uint32)
             out["mats"] = np.concatenate(mats) if mats else np.zeros((0, 16), np.float32)
         return out
+
+    # -- entities that change GPU (the second, sparse exchange) -----------------------------
+    def set_shard_range(self, key_lo, key_hi):
+        """this pipeline owns the world sections with key_lo <= key < key_hi (the smallest key of an entity's sections decides)"""
+        self._check(self._L.re_set_shard_range(self._h, int(key_lo), int(key_hi)), "re_set_shard_range")
+
+    def list_migrants(self, capacity=65536):
+        """ids of the entities re-bucketed since the last call whose section now belongs to another pipeline's key range"""
+        ids = np.zeros(max(capacity, 1), np.uint32); n = C.c_uint32()
+        self._check(self._L.re_list_migrants(self._h, ids.ctypes.data, capacity, C.byref(n)), "re_list_migrants")
+        if n.value > capacity:
+            return self.list_migrants(n.value)
+        return ids[:n.value].copy()
+
+    def export_entities(self, ids):
+        """the complete current state of these entities as an ENTITY_DT array (re_entity_state has the same 140-byte layout): what register_model_instances
+        of another pipeline needs to take them over"""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        out = np.zeros(len(ids), ENTITY_DT)
+        assert ENTITY_DT.itemsize == 140
+        if len(ids):
+            self._check(self._L.re_export_entities(self._h, ids.ctypes.data, len(ids), out.ctypes.data), "re_export_entities")
+        return out
+
+    def take_migrants(self):
+        """list + export + remove: the entities this pipeline hands over, as ENTITY_DT records"""
+        ids = self.list_migrants()
+        if not len(ids):
+            return np.zeros(0, ENTITY_DT)
+        states = self.export_entities(ids)
+        ch = np.zeros(len(ids), CHANGE_DT); ch["kind"] = _capi.CHANGE_DELETE; ch["entity_id"] = ids
+        self.apply_changes(ch)
+        return states
 
     def wait(self, copy=False):
         vis = _capi.Visible(); tr = _capi.TickResult()

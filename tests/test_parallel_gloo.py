@@ -120,3 +120,105 @@ def test_two_rank_allgather_matches_single_process():
     np.testing.assert_array_equal(mats_all[o1], full["mats"][o2])
     half = DIMS[0] * DIMS[1] * DIMS[2] // 2
     assert np.all(ids_all[:counts[0]] < half) and np.all(ids_all[counts[0]:] >= half)      # rank order
+
+
+# ---- the frame's second, sparse exchange: movers that cross the shard boundary -----------------------------------------------------
+class OracleShard:
+    """one rank's share of the world with the interface parallel.exchange_migrants drives (take_migrants / register_model_instances): the CPU oracle as
+    the per-shard stand-in, as everywhere in this file -- the exchange code is device-agnostic"""
+
+    def __init__(self, ents, key_range):
+        import oracle as ro
+        from helpers import to_oracle
+        self.ro, self.to_oracle = ro, to_oracle
+        self.w = ro.World(16384, 64); self.w.register(to_oracle(ents))
+        self.rec = {int(e["id"]): e.copy() for e in ents}
+        self.lo, self.hi = key_range
+
+    def take_migrants(self):
+        from render_engine_amd import ENTITY_DT
+        import render_engine_amd as R
+        out = []
+        for eid in sorted(self.rec):
+            kind, ks = self.w.lookup(eid)
+            if not kind or self.lo <= min(ks) < self.hi:
+                continue
+            st = self.w.entity(eid); e = self.rec.pop(eid)
+            e["pos"] = st["pos"]; e["vel"] = st["vel"]; e["flags"] = (st["flags"] & ~np.uint32(R.F_STATIC))      # the components as they are now
+            out.append(e)
+        if out:
+            ch = np.zeros(len(out), self.ro.CHANGE_DT); ch["kind"] = 1; ch["entity_id"] = [int(e["id"]) for e in out]      # DeleteRequest
+            self.w.apply_changes(ch, end_of_frame=False)
+        return np.array(out, ENTITY_DT) if out else np.zeros(0, ENTITY_DT)
+
+    def register_model_instances(self, ents):
+        for e in ents:
+            self.rec[int(e["id"])] = e.copy()
+        return self.w.register(self.to_oracle(ents))
+
+
+def _migration_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import render_engine_amd as R
+    from render_engine_amd import synthetic, parallel
+    from helpers import oracle_camera
+    ents = synthetic.hopping_lattice(dims=(10, 10, 10), first_cell=123, every=2)
+    keys = R.first_section_keys(ents)
+    cut = np.sort(keys)[len(keys) // 2]
+    ranges = parallel.key_ranges_from_cuts([cut])
+    lo, hi = ranges[rank]
+    sh = OracleShard(ents[(keys >= np.uint64(lo)) & (keys < np.uint64(hi))], (lo, hi))
+    c = (123 + 5) * 64.0
+    cam = oracle_camera(R.Camera((c, c, c + 450), (0, 0, -1), 1400.0))
+    frames = []
+    for f in range(5):
+        sh.w.cull(cam); r = sh.w.render(cam)
+        n, _ = sh.w.tick(cam, 1.0)
+        sent, got = parallel.exchange_migrants(sh, dist, ranges)
+        cells = sh.w.cells()
+        frames.append((np.sort(r["ids"]).copy(), n, sent, got, cells["keys"].copy(), cells["n_local"].copy()))
+    q.put((rank, frames))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_migration_of_shard_crossing_movers():
+    """two gloo ranks, each with half of the key space of a lattice whose movers hop one or two world sections per tick: after every tick
+    parallel.exchange_migrants hands the entities whose section left a rank's range to the rank that owns it.  Frame by frame the two ranks' visible
+    ids, ticked counts and section tables add up to the single-process oracle world."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as ro
+    import render_engine_amd as R
+    from render_engine_amd import synthetic
+    from helpers import to_oracle, oracle_camera
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_migration_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=150) for _ in range(world))
+    for p in procs:
+        p.join(30); assert p.exitcode == 0
+    ents = synthetic.hopping_lattice(dims=(10, 10, 10), first_cell=123, every=2)
+    w = ro.World(16384, 64); w.register(to_oracle(ents))
+    c = (123 + 5) * 64.0
+    cam = oracle_camera(R.Camera((c, c, c + 450), (0, 0, -1), 1400.0))
+    moved = 0
+    for f in range(5):
+        w.cull(cam); r = w.render(cam); n, _ = w.tick(cam, 1.0)
+        a, b = res[0][f], res[1][f]
+        np.testing.assert_array_equal(np.sort(np.concatenate([a[0], b[0]])), np.sort(r["ids"]))
+        assert a[1] + b[1] == n
+        assert a[2] == b[3] and b[2] == a[3]                       # what one rank sent, the other received
+        moved += a[2] + b[2]
+        cells = w.cells()
+        k = np.concatenate([a[4], b[4]]); o = np.argsort(k)
+        np.testing.assert_array_equal(k[o], cells["keys"])
+        np.testing.assert_array_equal(np.concatenate([a[5], b[5]])[o], cells["n_local"])
+    assert moved > 20
+    w.close()

@@ -81,3 +81,67 @@ def test_union_of_shards_equals_the_single_pipeline_frame():
         st = p.stats(); assert st["n_seal_waits"] == 0 and st["n_sync_fallbacks"] == 0
         p.close()
     w.close()
+
+
+def _keyed(r):
+    out = []
+    for grp in r["groups"]:
+        b, c = int(grp["begin"]), int(grp["count"])
+        for k in range(b, b + c):
+            out.append((int(grp["model_index"]), int(grp["render_system"]), int(grp["sortable"]), int(r["ids"][k]), r["mats"][k].view(np.uint32).tobytes()))
+    return out
+
+
+@pytest.mark.gpu
+def test_movers_that_cross_the_shard_boundary_migrate():
+    """SURVEY 8e's second, sparse exchange: two pipelines own the two halves of the key space of a lattice in which every second entity hops one or two
+    world sections per tick.  After every tick each pipeline hands over the entities whose section left its key range (re_list_migrants /
+    re_export_entities / RE_CHANGE_DELETE) and registers the ones that arrived (re_add_entities).  Frame by frame the union of the two pipelines'
+    visible instances -- and of their section tables -- equals the CPU oracle's single world."""
+    import render_engine_amd as R
+    from render_engine_amd import parallel
+    ents = R.synthetic.hopping_lattice(dims=(12, 12, 12), first_cell=122, every=2)
+    keys = R.first_section_keys(ents)
+    cut = np.sort(keys)[len(keys) // 2]
+    ranges = parallel.key_ranges_from_cuts([cut])
+    w = ro.World(16384, 64); w.register(to_oracle(ents))
+    parts = []
+    for lo, hi in ranges:
+        p = R.Pipeline(16384, 64)
+        assert p.register_model_instances(ents[(keys >= np.uint64(lo)) & (keys < np.uint64(hi))]) == 0
+        p.set_shard_range(lo, hi); parts.append(p)
+    c = (122 + 6) * 64.0
+    cams = [R.Camera((c + 20 * i, c, c + 500 - 30 * i), (0, 0, -1), 1500.0) for i in range(6)]
+    moved_total = 0
+    for f, cam in enumerate(cams):
+        dups = f % 2 == 1
+        oc = oracle_camera(cam); w.cull(oc); o = w.render(oc, emit_duplicates=dups)
+        res = [p.cull_and_pack(cam, emit_duplicates=dups) for p in parts]
+        assert sum(r["total"] for r in res) == o["total"], f
+        assert sorted(x for r in res for x in _keyed(r)) == sorted(_keyed(o)), f
+        n_o, _ = w.tick(oc, 1.0)
+        assert sum(p.tick(1.0)["n_changed"] for p in parts) == n_o
+        # the sparse exchange, between frames
+        states = [p.take_migrants() for p in parts]
+        for r, p in enumerate(parts):
+            inc = [states[q][parallel.route_migrants(states[q], ranges)[r]] for q in range(len(parts)) if q != r]
+            inc = np.concatenate(inc) if inc else np.zeros(0, R.ENTITY_DT)
+            if len(inc):
+                assert p.register_model_instances(inc) == 0
+        moved_total += sum(len(s) for s in states)
+        # the two section tables together are the oracle's tree: keys, member counts, tight AABBs
+        secs = [p.sections() for p in parts]
+        cells = w.cells()
+        k_all = np.concatenate([s["keys"] for s in secs]); order = np.argsort(k_all, kind="stable")
+        np.testing.assert_array_equal(k_all[order], cells["keys"])
+        np.testing.assert_array_equal(np.concatenate([s["n_local"] for s in secs])[order], cells["n_local"])
+        np.testing.assert_array_equal(np.concatenate([s["n_static"] for s in secs])[order], cells["n_static"])
+        tight = np.stack([cells["tight"][k] for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")], axis=1)
+        np.testing.assert_array_equal(np.concatenate([s["tight"] for s in secs])[order], tight)
+        for (lo, hi), s in zip(ranges, secs):                      # and every section sits on the pipeline that owns its key
+            assert np.all((s["keys"] >= np.uint64(lo)) & (s["keys"] < np.uint64(hi)))
+    assert moved_total > 50
+    for p in parts:
+        st = p.stats(); assert st["n_seal_waits"] == 0 and st["n_sync_fallbacks"] == 0
+        p.close()
+    w.close()
