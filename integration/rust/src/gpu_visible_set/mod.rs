@@ -27,7 +27,22 @@ pub struct EntityColumns {
     pub velocity: Vec<[f32; 3]>, pub acceleration: Vec<[f32; 3]>, pub rotation_velocity: Vec<[f32; 4]>, pub rotation_acceleration: Vec<[f32; 4]>,
 }
 
-pub struct Frame { pub visible_sections: u32, pub instances: u32, pub written: u32, pub groups: Vec<ReInstanceRange> }
+pub struct Frame { pub visible_sections: u32, pub visible_sections_vec: u32, pub instances: u32, pub written: u32, pub groups: Vec<ReInstanceRange> }
+
+/// What replaces `CullResult` (flows/visible_world_flow.rs:17-36) at the call sites of this path: the render and logic flows of the GPU path never look
+/// at the section ids themselves -- the gather (render_flow.rs:401-410), the tick gate (logic_flow.rs:216-223) and the collision phase read the visible
+/// set on the device --, so the adapter carries its SIZES (what the reference prints / asserts on) and the handle.
+pub struct GpuCullResult { pub visible_sections_map_len: u32, pub visible_sections_vec_len: u32 }
+
+/// ECS::create_entity's id allocator (objects/ecs.rs:384-402): the last freed id, else the next one.  The library takes entity ids from its host
+/// (RE_CHANGE_ADD_ENTITY / re_add_entities); the shim keeps the counter and the free list exactly as the reference's ECS does.
+#[derive(Default)]
+pub struct EntityIds { next: u32, free: Vec<u32> }
+impl EntityIds {
+    pub fn with_existing(n_entities: u32) -> EntityIds { EntityIds { next: n_entities, free: Vec::new() } }
+    pub fn create_entity(&mut self) -> u32 { match self.free.pop() { Some(i) => i, None => { let i = self.next; self.next += 1; i } } }
+    pub fn remove_entity(&mut self, id: u32) { self.free.push(id); }
+}
 
 impl GpuVisibleSet {
     /// `outline_length` / `atomic_length`: the arguments of `BoundingBoxTree::new` (render_thread.rs:127).
@@ -70,7 +85,126 @@ impl GpuVisibleSet {
         self.check(unsafe { re_cull_pack(self.ctx, &cam, if emit_duplicates { RE_CULL_EMIT_DUPLICATES } else { 0 }, vis.as_mut_ptr()) })?;
         let vis = unsafe { vis.assume_init() };
         let groups = if vis.n_groups == 0 { Vec::new() } else { unsafe { std::slice::from_raw_parts(vis.groups, vis.n_groups as usize) }.to_vec() };
-        Ok(Frame { visible_sections: vis.n_visible_sections, instances: vis.n_instances, written: vis.n_written, groups })
+        Ok(Frame { visible_sections: vis.n_visible_sections, visible_sections_vec: vis.n_visible_vec, instances: vis.n_instances, written: vis.n_written, groups })
+    }
+
+    /// `CullResult` adapter of flows/pipeline.rs:222-229 (the union of the two visibility queries, duplicates kept in the vec)
+    pub fn cull_result(frame: &Frame) -> GpuCullResult { GpuCullResult { visible_sections_map_len: frame.visible_sections, visible_sections_vec_len: frame.visible_sections_vec } }
+
+    /// flows/render_flow.rs:401-410 + upload_instance_data_to_render_system (:939-992) for one render system: the frame's (ModelId, sortable) groups become
+    /// `ModelRenderingInformation::instance_location` entries (`InstanceRange { begin_instance, count }`), every other entry's count is zeroed first (:952-962),
+    /// the TransformationMatrix bytes go into the persistent-mapped instance buffer (truncated at its capacity like MappedBuffer::write_data_serialized,
+    /// render_components/mapped_buffer.rs:166-189), and the buffer is flushed for the bytes written.
+    ///
+    /// `set_range(model_index_with_lod, render_system_index, sortable_index, begin_instance, count)` is the crate-side closure that does
+    ///     `render_system.model_rendering_information.entry(ModelId { model_index, render_system_index }).or_insert_with(ModelRenderingInformation::new)
+    ///          .instance_location.insert(sortable_index, InstanceRange { begin_instance, count })`
+    /// and `zero_counts()` the loop of :952-962; they are closures because `ModelRenderingInformation::new` and `BufferWriteInfo`'s fields are private to the crate's modules.
+    pub fn upload_instance_data_to_render_system(&mut self, frame: &Frame, render_system_index: u32, mapped_matrix_buffer: *mut f32, buffer_bytes: isize,
+                                                 mut zero_counts: impl FnMut(), mut set_range: impl FnMut(u32, u32, usize, u32, u32)) -> Result<isize, GpuError> {
+        zero_counts();
+        for g in frame.groups.iter().filter(|g| g.render_system == render_system_index) { set_range(g.model_index, g.render_system, g.sortable as usize, g.begin_instance, g.count); }
+        let capacity = (buffer_bytes.max(0) as usize / 64) as u32;             // 64 bytes per instance: one column-major Matrix4<f32>
+        let mut ids = vec![0u32; frame.written.min(capacity) as usize];
+        let n = self.copy_instances(&mut ids, mapped_matrix_buffer, capacity)?;
+        Ok(n as isize * 64)                                                    // bytes to hand to RenderSystem::flush_per_instance_buffers
+    }
+
+    /// Pipeline::register_model_instances after the first frame (flows/pipeline.rs:186-208): the new instances are APPENDED (`upload` replaces the world)
+    pub fn add_entities(&mut self, c: &EntityColumns) -> Result<u32, GpuError> {
+        let e = Self::columns(c);
+        let mut rejected = 0u32;
+        self.check(unsafe { re_add_entities(self.ctx, &e, &mut rejected) })?;
+        Ok(rejected)
+    }
+
+    /// apply_change with AddEntity arms (helper_things/entity_change_helpers.rs:48-107): `changes` in list order, `added` the entities the
+    /// RE_CHANGE_ADD_ENTITY changes refer to (`reserved` = index; `entity_id` from `EntityIds::create_entity`)
+    pub fn apply_changes_with_added(&mut self, changes: &[ReChange], added: &EntityColumns) -> Result<ReTickResult, GpuError> {
+        let e = Self::columns(added);
+        let mut t = MaybeUninit::<ReTickResult>::zeroed();
+        self.check(unsafe { re_apply_changes_ex(self.ctx, changes.as_ptr(), changes.len() as u32, &e, 0, t.as_mut_ptr()) })?;
+        Ok(unsafe { t.assume_init() })
+    }
+
+    /// level_views.custom of one model (register_model_with_render_system(.., custom_level_of_view, ..), flows/render_flow.rs:1069-1076)
+    pub fn set_model_lod(&mut self, model_index: u32, render_system: u32, bands: &[(f32, f32)]) -> Result<(), GpuError> {
+        let lo: Vec<f32> = bands.iter().map(|b| b.0).collect(); let hi: Vec<f32> = bands.iter().map(|b| b.1).collect();
+        self.check(unsafe { re_set_model_lod(self.ctx, model_index, render_system, bands.len().min(8) as u32, lo.as_ptr(), hi.as_ptr()) })
+    }
+
+    /// ECS::check_component_written / the entity's bitset (objects/ecs.rs:61-72, 348-367) in the reference's registration order
+    pub fn ecs_bitset(&mut self, entity_id: u32) -> Result<u32, GpuError> { let mut b = 0u32; self.check(unsafe { re_ecs_bitset(self.ctx, entity_id, &mut b) })?; Ok(b) }
+
+    /// ECS::get_indexes_for_components (objects/ecs.rs:238-285): ascending ids of the entities that carry all of `components` (RE_C_*)
+    pub fn get_indexes_for_components(&mut self, components: &[i32]) -> Result<Vec<u32>, GpuError> {
+        let mut n = 0u32;
+        self.check(unsafe { re_ecs_query(self.ctx, components.as_ptr(), components.len() as u32, std::ptr::null_mut(), 0, &mut n) })?;
+        let mut ids = vec![0u32; n as usize];
+        self.check(unsafe { re_ecs_query(self.ctx, components.as_ptr(), components.len() as u32, ids.as_mut_ptr(), n, &mut n) })?;
+        ids.truncate(n as usize);
+        Ok(ids)
+    }
+
+    /// find_nearby_lights (flows/shadow_flow.rs:455-513) for one FindLightType (RE_F_LIGHT_*): ascending entity ids
+    pub fn visible_lights(&mut self, projection_view: &[f32; 16], position: [f32; 3], direction: [f32; 3], far_draw: f32, light_type: u32) -> Result<Vec<u32>, GpuError> {
+        let cam = ReCamera { projection_view: *projection_view, position, direction, far_draw, n_lod: 0, lod_min: [0.0; 8], lod_max: [0.0; 8] };
+        let mut n = 0u32; let mut ids = vec![0u32; 4096];
+        loop {
+            self.check(unsafe { re_visible_lights(self.ctx, &cam, light_type, ids.as_mut_ptr(), ids.len() as u32, &mut n) })?;
+            if n as usize <= ids.len() { ids.truncate(n as usize); return Ok(ids); }
+            ids = vec![0u32; n as usize];
+        }
+    }
+
+    // ---- several GPUs (one GpuVisibleSet per GPU, one process per GPU): the frame's exchange steps -------------------------------------------------
+    /// rank 0 creates the id and hands it to the other ranks over the host's own channel
+    pub fn comm_unique_id() -> Result<[u8; RE_COMM_ID_BYTES], GpuError> {
+        let mut id = [0u8; RE_COMM_ID_BYTES];
+        let rc = unsafe { re_comm_unique_id(id.as_mut_ptr()) };
+        if rc != RE_OK { return Err(GpuError { code: rc, message: last_error(std::ptr::null()) }); }
+        Ok(id)
+    }
+    pub fn comm_init(&mut self, id: &[u8; RE_COMM_ID_BYTES], rank: i32, n_ranks: i32, slab_instances: u32) -> Result<(), GpuError> {
+        self.check(unsafe { re_comm_init(self.ctx, id.as_ptr(), rank, n_ranks, slab_instances) })
+    }
+    /// between cull_pack and tick: every GPU ends with every GPU's packed visible instances, in rank order; returns the per-rank counts
+    pub fn allgather_visible(&mut self) -> Result<Vec<u32>, GpuError> {
+        let mut g = MaybeUninit::<ReGathered>::zeroed();
+        self.check(unsafe { re_allgather_visible(self.ctx, 0, g.as_mut_ptr()) })?;
+        let g = unsafe { g.assume_init() };
+        Ok(unsafe { std::slice::from_raw_parts(g.counts, g.n_ranks as usize) }.to_vec())
+    }
+    /// the world sections this GPU owns (the smallest key of an entity's sections decides): switches the migrant bookkeeping on
+    pub fn set_shard_range(&mut self, key_lo: u64, key_hi: u64) -> Result<(), GpuError> { self.check(unsafe { re_set_shard_range(self.ctx, key_lo, key_hi) }) }
+    /// after the tick: the entities whose section left this GPU's key range, with their complete state, removed here; the host routes each record to the
+    /// GPU that owns its new section (re_section_keys is the same host arithmetic on every rank) and calls `add_entities` there
+    pub fn take_migrants(&mut self) -> Result<Vec<ReEntityState>, GpuError> {
+        let mut n = 0u32; let mut ids = vec![0u32; 4096];
+        loop {
+            self.check(unsafe { re_list_migrants(self.ctx, ids.as_mut_ptr(), ids.len() as u32, &mut n) })?;
+            if n as usize <= ids.len() { ids.truncate(n as usize); break; }
+            ids = vec![0u32; n as usize];
+        }
+        let mut out = vec![ReEntityState::default(); ids.len()];
+        if ids.is_empty() { return Ok(out); }
+        self.check(unsafe { re_export_entities(self.ctx, ids.as_ptr(), ids.len() as u32, out.as_mut_ptr()) })?;
+        let del: Vec<ReChange> = ids.iter().map(|&i| delete(i)).collect();
+        self.apply_changes(&del)?;
+        Ok(out)
+    }
+
+    fn columns(c: &EntityColumns) -> ReEntities {
+        let n = c.entity_id.len();
+        assert!([c.model_index.len(), c.render_system.len(), c.sortable.len(), c.flags.len(), c.original_aabb.len(), c.position.len(), c.rotation.len(), c.scale.len(),
+                 c.velocity.len(), c.acceleration.len(), c.rotation_velocity.len(), c.rotation_acceleration.len()].iter().all(|&l| l == n));
+        ReEntities {
+            n: n as u32, entity_id: c.entity_id.as_ptr(), model_index: c.model_index.as_ptr(), render_system: c.render_system.as_ptr(), sortable: c.sortable.as_ptr(),
+            flags: c.flags.as_ptr(), original_aabb: c.original_aabb.as_ptr() as *const f32, position: c.position.as_ptr() as *const f32,
+            rotation: c.rotation.as_ptr() as *const f32, scale: c.scale.as_ptr() as *const f32, velocity: c.velocity.as_ptr() as *const f32,
+            acceleration: c.acceleration.as_ptr() as *const f32, rotation_velocity: c.rotation_velocity.as_ptr() as *const f32,
+            rotation_acceleration: c.rotation_acceleration.as_ptr() as *const f32,
+        }
     }
 
     /// flows/render_flow.rs:939-992: the instance bytes into the persistent-mapped GL buffer of render system 0
@@ -137,3 +271,19 @@ pub fn modify(entity_id: u32, component: u32, value: [f32; 4]) -> ReChange { ReC
 pub fn delete(entity_id: u32) -> ReChange { ReChange { kind: RE_CHANGE_DELETE, entity_id, component: 0, reserved: 0, value: [0.0; 4] } }
 pub fn make_static(entity_id: u32) -> ReChange { ReChange { kind: RE_CHANGE_MAKE_STATIC, entity_id, component: 0, reserved: 0, value: [0.0; 4] } }
 pub fn wake_up(entity_id: u32) -> ReChange { ReChange { kind: RE_CHANGE_WAKE_UP, entity_id, component: 0, reserved: 0, value: [0.0; 4] } }
+pub fn remove_component(entity_id: u32, component: u32) -> ReChange { ReChange { kind: RE_CHANGE_REMOVE_COMPONENT, entity_id, component, reserved: 0, value: [0.0; 4] } }
+/// EntityChangeInformation::AddEntity: `index` into the `added` columns handed to apply_changes_with_added; `entity_id` from EntityIds::create_entity
+pub fn add_entity(entity_id: u32, index: u32) -> ReChange { ReChange { kind: RE_CHANGE_ADD_ENTITY, entity_id, component: 0, reserved: index, value: [0.0; 4] } }
+/// EntityChangeInformation::AddSortableComponent / RemoveSortableComponent: `sortable_index` = position of the sortable component in registration order
+pub fn add_sortable(entity_id: u32, sortable_index: u32) -> ReChange { ReChange { kind: RE_CHANGE_ADD_SORTABLE, entity_id, component: sortable_index, reserved: 0, value: [0.0; 4] } }
+pub fn remove_sortable(entity_id: u32) -> ReChange { ReChange { kind: RE_CHANGE_REMOVE_SORTABLE, entity_id, component: 0, reserved: 0, value: [0.0; 4] } }
+/// ReEntityState records (migrants) as the columns add_entities takes
+pub fn columns_of(states: &[ReEntityState]) -> EntityColumns {
+    let mut c = EntityColumns::default();
+    for s in states {
+        c.entity_id.push(s.entity_id); c.model_index.push(s.model_index); c.render_system.push(s.render_system); c.sortable.push(s.sortable); c.flags.push(s.flags);
+        c.original_aabb.push(s.original_aabb); c.position.push(s.position); c.rotation.push(s.rotation); c.scale.push(s.scale); c.velocity.push(s.velocity);
+        c.acceleration.push(s.acceleration); c.rotation_velocity.push(s.rotation_velocity); c.rotation_acceleration.push(s.rotation_acceleration);
+    }
+    c
+}

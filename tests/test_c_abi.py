@@ -119,3 +119,19 @@ def test_every_entry_point_is_guarded():
             else:
                 assert not re.search(r"\b(new|vector|push_back|resize|assign|std::string\()", ln), (f, i + 1, ln[:120])
     assert n >= 45
+
+
+def test_rust_shim_declares_every_symbol_of_the_header():
+    """integration/rust (the extern "C" block a maintainer adds to the reference crate) is source only -- no Rust toolchain in this image --, so what
+    can be checked here is that it names every function include/re_hip.h declares, that its ABI-version comment is current, and that the record sizes it relies on
+    are the library's (the #[repr(C)] structs are field-for-field transcriptions of the header's)"""
+    import render_engine_amd as R
+    from render_engine_amd import _capi
+    ffi = open(os.path.join(ROOT, "integration", "rust", "src", "gpu_visible_set", "ffi.rs")).read()
+    declared = set(re.findall(r"pub fn (re_[a-z_0-9]+)", ffi))
+    assert set(header_functions()) <= declared, sorted(set(header_functions()) - declared)
+    assert "re_abi_version() -> u32;" in ffi and "// %d" % _capi.load().re_abi_version() in ffi.split("re_abi_version() -> u32;")[1].split("\n")[0]
+    assert R.ENTITY_DT.itemsize == 140 and "// 140 bytes" in ffi                 # re_entity_state == ENTITY_DT == ReEntityState
+    mod = open(os.path.join(ROOT, "integration", "rust", "src", "gpu_visible_set", "mod.rs")).read()
+    for wrapper in ("upload_instance_data_to_render_system", "cull_result", "add_entities", "apply_changes_with_added", "take_migrants", "allgather_visible", "EntityIds"):
+        assert wrapper in mod, wrapper
