@@ -364,7 +364,7 @@ def main():
 
 def committed_traffic(which):
     """HBM traffic per launch from the committed PMC profile (separate --pmc passes, gfx950 FETCH_SIZE correction applied); not measured in this run"""
-    for name in ("r02_pmc.json", "r01_pmc_k_scan_cull.json"):
+    for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_k_scan_cull.json"):
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
             try:
@@ -495,7 +495,10 @@ def lighting_leg(headline, steps=20, warmup=3):
     flops = pairs * 150 + 20 * npix                  # ~75 flop per evaluated (pixel, light) term, the spot term is evaluated twice, + 20 per pixel epilogue
     bytes_ = npix * (16 + 16 + 4 + 16)               # gPosition + gNormal RGBA32F, gAlbedoSpec RGBA8 read; FragColor RGBA32F written (gLightPosition is not needed)
     tf, gb = flops / (t * 1e-6) / 1e12, bytes_ / (t * 1e-6) / 1e9
-    binds = "fp32 VALU" if tf / VALU_PEAK_TFLOPS > gb / HBM_PEAK_GBS else "HBM"
+    # What binds the kernel is decided by the SQ counters, not by which of the two model ratios below is larger: SQ_INSTS_VALU = 92.8 M wave-instructions per
+    # launch fill 75-85 % of the VALU issue slots of the launch (tools/pmc_sq.sh); valu_frac prices only the 150-flop model of the in-radius
+    # (pixel, light) pairs, about a quarter of what a wave executes (it evaluates a listed light for all 64 lanes when any lane is inside the radius).
+    binds = "fp32 VALU issue (SQ_INSTS_VALU: 75-85 % of the issue slots; hbm_frac and valu_frac are model ratios, not utilisations)"
     res = {"workload": "configs[4]: deferred lighting, %dx%d synthetic G-buffer, %d radius-40 'spot' lights (second_pass_frag.glsl:20-139)" % (W, H, NL),
            "kernel": "k_deferred_lighting", "kernel_us": t, "pixels_per_s": npix / (t * 1e-6),
            "pixel_light_pairs_in_radius": pairs, "pairs_per_pixel": pairs / npix, "flop_model": "150 flop per pair (75 per evaluated term, spot term twice) + 20 per pixel",
@@ -507,7 +510,7 @@ def lighting_leg(headline, steps=20, warmup=3):
     return {"metric": "deferred-lighting pixels/sec (configs[4])", "value": res["pixels_per_s"], "unit": "pixels/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
             "ms_per_step": t * 1e-3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": res["workload"]},
-            "roofline": {"bound": "hbm", "note": "the kernel is fp32-VALU bound (no MFMA: per-light branchy shading), so this HBM fraction is low by construction; the VALU fraction is in `lighting`",
+            "roofline": {"bound": "hbm", "note": "the kernel is fp32-VALU-issue bound (no MFMA: per-light branchy shading), so this HBM fraction is low by construction; the VALU figures are in `lighting`",
                          "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS,
                          "traffic": committed_traffic("lighting")[0], "traffic_source": committed_traffic("lighting")[1]},
             "lighting": res}

@@ -6,14 +6,14 @@ args=${@:---config visible --no-extras}
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --output-format csv -d $root/gpurun_out/pmc_${tag}_$ctr -- python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline $args > $root/gpurun_out/pmc_${tag}_$ctr.log 2>&1
+  rm -rf /tmp/pmc_${tag}_$ctr; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_${tag}_$ctr -- python $root/bench.py --steps 60 --warmup 10 --no-cpu-baseline $args > $root/gpurun_out/pmc_${tag}_$ctr.log 2>&1
 done
 cd $root
 python - <<PY
 import csv, glob, json, collections
 out = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("gpurun_out/pmc_${tag}_%s/*/*counter_collection.csv" % ctr)
+    f = glob.glob("/tmp/pmc_${tag}_%s/*/*counter_collection.csv" % ctr)
     if not f:
         print("no counter file for", ctr); continue
     acc = collections.defaultdict(list)
