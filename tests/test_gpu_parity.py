@@ -377,6 +377,8 @@ def test_add_entities_between_frames(R):
             new["id"] = np.arange(next_id, next_id + len(new), dtype=np.uint32); next_id += len(new)
             new["flags"] &= ~np.uint32(C.F_STATIC)
             new["model_index"] += np.uint32(3 * f)                       # model ids the upload did not know: new group classes
+            if f == 3:
+                new["model_index"] = 100 + np.arange(len(new), dtype=np.uint32) % 170      # 170 more models: the group table outgrows the result block's InstanceRange capacity (regrow_groups) and the one-launch packs' 512 slots
             if f == 2:
                 new["pos"][5] = (-900.0, 100.0, 100.0)                   # out of bounds: created, not inserted
             assert p.register_model_instances(new) == w.register(to_oracle(new)) == (1 if f == 2 else 0)
@@ -419,10 +421,11 @@ def test_add_entities_static_recache_and_in_frame(R):
     frame(); frame(True)
     static_ids = [int(e["id"]) for e in ents if e["flags"] & C.F_STATIC]
     # a change batch that leaves ghosts and hidden rows behind: wake a cached static entity, move another, make an active one static
-    ch = np.zeros(3, R.CHANGE_DT)
+    ch = np.zeros(4, R.CHANGE_DT)
     ch[0] = (C.CHANGE_WAKE_UP, static_ids[700], 0, 0, (0, 0, 0, 0))
     ch[1] = (C.CHANGE_MODIFY, static_ids[701], C.C_POSITION, 0, tuple(ents[ents["id"] == static_ids[701]]["pos"][0] + np.float32(3.0)) + (0,))
     ch[2] = (C.CHANGE_MAKE_STATIC, int(ents["id"][0]), 0, 0, (0, 0, 0, 0))
+    ch[3] = (C.CHANGE_WAKE_UP, static_ids[702], 0, 0, (0, 0, 0, 0))                    # a ghost nobody re-caches: it stays through the growth of the row columns below
     w.apply_changes(ch.view(ro.CHANGE_DT)); p.apply_changes(ch)
     frame(); check_sections(p, w)
     # between frames: static and active instances; two of the static ones land in the sections that hold the ghost / the hidden row
