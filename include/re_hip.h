@@ -395,13 +395,19 @@ typedef struct {
     uint32_t n_device_rebuckets; /* re-bucket batches (movers of a tick that changed world section) whose bookkeeping ran on the device; the others took the host path */
     uint32_t n_segment_redos;    /* frames issued a second time because clustered world sections overflowed one cursor segment of the instance list: the frame is redone
                                   * with the list as one segment (which holds every instance of the world twice), and the context keeps that layout until the next upload */
-    uint32_t reserved2;
+    uint32_t n_host_rebuckets;  /* batches of section changes (or the rest of one the device took in part) whose bookkeeping ran on the host: change-request batches, static movers,
+                                 * worlds with ghost instances of the frozen render cache, a table without slack */
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,
  * bounding_box_tree_v2.rs:21-26); tight = UniqueWorldSectionEntities.aabb (6 floats each).  Any pointer may be NULL. */
 int re_debug_get_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, float *tight_aabb6,
                           uint32_t *n_local, uint32_t *n_static, uint8_t *is_static_section, uint32_t *n);
+/* The shared world sections in canonical id order (keys lexicographic, then count): the 2..8 section keys of each, its AABB (end_of_changes, shared branch:
+ * world/bounding_box_tree_v2.rs:1104-1125), the number of active / static members and their EntityIds (member_offsets[i] .. member_offsets[i + 1]; active first,
+ * each part in ascending EntityId).  Read from the device table; RE_E_STATE when the host mirrors of the library are out of step with it. */
+int re_debug_get_shared_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys /* [capacity * 8] */, uint8_t *n_keys, float *aabb6, uint32_t *n_active, uint32_t *n_static,
+                                 uint32_t member_capacity, uint32_t *member_ids, uint32_t *member_offsets /* [capacity + 1] */, uint32_t *n);
 /* visible_sections_map of the last cull, ascending; multiplicity[i] = 2 when the section is in both
  * the logic and the render result (appears twice in visible_sections_vec). */
 int re_debug_get_visible_sections(re_ctx *ctx, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n);

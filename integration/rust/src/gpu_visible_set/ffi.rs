@@ -27,7 +27,7 @@ use std::os::raw::{c_char, c_int, c_void};
     pub rotation_velocity: [f32; 4], pub rotation_acceleration: [f32; 4] }                                   // 140 bytes
 #[repr(C)] #[derive(Copy, Clone, Default)] pub struct ReStats { pub n_entities: u32, pub n_dynamic: u32, pub n_sections: u32, pub n_shared_sections: u32, pub max_level: u32,
     pub device_bytes: u64, pub n_probe_frames: u32, pub n_table_rebuilds: u32, pub n_fused_frames: u32, pub reserved: u32, pub n_seal_waits: u32, pub n_sync_fallbacks: u32,
-    pub n_section_slots: u32, pub n_device_rebuckets: u32, pub n_segment_redos: u32, pub reserved2: u32 }
+    pub n_section_slots: u32, pub n_device_rebuckets: u32, pub n_segment_redos: u32, pub n_host_rebuckets: u32 }
 #[repr(C)] pub struct ReLighting { _private: [u8; 0] }
 #[repr(C)] pub struct ReLightingConfig { pub device: i32, pub width: u32, pub height: u32, pub max_spot_lights: u32, pub max_point_lights: u32 }
 #[repr(C)] pub struct ReLights { pub n_spot: u32, pub n_point: u32,
@@ -80,6 +80,8 @@ extern "C" {
     pub fn re_debug_copy_to_host(ctx: *mut ReCtx, d_src: *const c_void, dst: *mut c_void, bytes: u64) -> c_int;
     // introspection / profiling
     pub fn re_debug_get_sections(ctx: *mut ReCtx, capacity: u32, keys: *mut u64, tight_aabb6: *mut f32, n_local: *mut u32, n_static: *mut u32, is_static_section: *mut u8, n: *mut u32) -> c_int;
+    pub fn re_debug_get_shared_sections(ctx: *mut ReCtx, capacity: u32, keys: *mut u64, n_keys: *mut u8, aabb6: *mut f32, n_active: *mut u32, n_static: *mut u32,
+                                        member_capacity: u32, member_ids: *mut u32, member_offsets: *mut u32, n: *mut u32) -> c_int;
     pub fn re_debug_get_visible_sections(ctx: *mut ReCtx, capacity: u32, keys: *mut u64, multiplicity: *mut u8, n: *mut u32) -> c_int;
     pub fn re_get_timings(ctx: *mut ReCtx, cull_us: *mut f32, pack_us: *mut f32, tick_us: *mut f32) -> c_int;
     pub fn re_timing_begin(ctx: *mut ReCtx, max_launches: u32, every: u32) -> c_int;

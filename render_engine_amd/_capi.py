@@ -80,7 +80,7 @@ class Stats(C.Structure):
                 ("n_shared_sections", C.c_uint32), ("max_level", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("n_probe_frames", C.c_uint32), ("n_table_rebuilds", C.c_uint32), ("n_fused_frames", C.c_uint32), ("reserved", C.c_uint32),
                 ("n_seal_waits", C.c_uint32), ("n_sync_fallbacks", C.c_uint32), ("n_section_slots", C.c_uint32), ("n_device_rebuckets", C.c_uint32),
-                ("n_segment_redos", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("n_segment_redos", C.c_uint32), ("n_host_rebuckets", C.c_uint32)]
 
 
 class Gathered(C.Structure):
@@ -106,7 +106,7 @@ class Lights(C.Structure):
 # every symbol include/re_hip.h declares
 EXPORTS = ["re_create", "re_destroy", "re_last_error", "re_abi_version", "re_upload_entities", "re_set_model_lod", "re_cull_pack", "re_tick",
            "re_apply_changes", "re_apply_changes_ex", "re_add_entities", "re_set_shard_range", "re_list_migrants", "re_export_entities", "re_collide", "re_wait", "re_run_frames", "re_comm_unique_id", "re_comm_init", "re_comm_adopt", "re_comm_destroy", "re_allgather_visible", "re_gather_wait", "re_copy_visible", "re_set_output_buffers", "re_set_output_count", "re_read_component", "re_ecs_bitset", "re_ecs_query", "re_visible_lights", "re_section_keys", "re_get_out_of_bounds", "re_get_stats",
-           "re_debug_get_sections", "re_debug_get_visible_sections", "re_debug_copy_to_host", "re_get_timings", "re_get_stream",
+           "re_debug_get_sections", "re_debug_get_shared_sections", "re_debug_get_visible_sections", "re_debug_copy_to_host", "re_get_timings", "re_get_stream",
            "re_timing_begin", "re_timing_collect", "re_get_last_candidates",
            "re_lighting_create", "re_lighting_destroy", "re_lighting_last_error", "re_lighting_upload_gbuffer", "re_lighting_set_lights",
            "re_lighting_run", "re_lighting_read", "re_lighting_read_pixels",
@@ -175,6 +175,7 @@ def load():
     L.re_get_out_of_bounds.restype = C.c_int; L.re_get_out_of_bounds.argtypes = [vp, vp, C.c_uint32, _u32p]
     L.re_get_stats.restype = C.c_int; L.re_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.re_debug_get_sections.restype = C.c_int; L.re_debug_get_sections.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, _u32p]
+    L.re_debug_get_shared_sections.restype = C.c_int; L.re_debug_get_shared_sections.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, _u32p]
     L.re_debug_get_visible_sections.restype = C.c_int; L.re_debug_get_visible_sections.argtypes = [vp, C.c_uint32, vp, vp, _u32p]
     L.re_get_timings.restype = C.c_int; L.re_get_timings.argtypes = [vp, _fp, _fp, _fp]
     L.re_debug_copy_to_host.restype = C.c_int; L.re_debug_copy_to_host.argtypes = [vp, vp, vp, C.c_uint64]

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librender_engine_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
-SOURCES = ["re_kernels.hip", "re_api.hip", "re_lighting.hip", "re_collide.hip", "re_sort.hip", "re_history.cpp"]
+SOURCES = ["re_kernels.hip", "re_rebucket.hip", "re_api.hip", "re_lighting.hip", "re_collide.hip", "re_sort.hip", "re_history.cpp"]
 HEADERS = ["re_kernels.h", "re_math.h", "re_guard.h", os.path.join(INCLUDE, "re_hip.h")]
 # -ffp-contract=off: the visible set must be bit-exact with the reference's Rust arithmetic (no FMA contraction)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",

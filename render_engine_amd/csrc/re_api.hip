@@ -214,8 +214,18 @@ struct re_ctx {
     DevBuf<uint64_t> d_rb_key, d_rb_ord, d_rb_key2, d_rb_ksorted; DevBuf<uint32_t> d_rb_row, d_rb_idx, d_rb_perm1, d_rb_perm, d_rb_tmprow, d_rb_refold, d_rb_free, d_rb_freeoff;
     DevBuf<uint32_t> d_hrb_list; DevBuf<uint8_t> d_hrb_nk; DevBuf<uint64_t> d_hrb_keys;   // scratch of the host-path re-bucket (the movers' new section decisions)
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
+    // shared world sections on the device path: the table has sh_cap entries with STABLE indices (a retired entry is a hole until a host path rebuilds the
+    // table compactly); ids, row capacities and the id -> index hash are device-only, rebuilt from the host mirrors whenever a host path has touched the table
+    uint32_t sh_cap = 0, sh_hmask = 0, sh_hash_used = 0; bool rb_sh_dirty = true;   // (sh_hash_used: entries of the id -> index hash, retired ones included)
+    DevBuf<uint64_t> d_sh_keys; DevBuf<uint8_t> d_sh_nk, d_cell_inact; DevBuf<uint32_t> d_sh_rowcap, d_sh_hidx; DevBuf<unsigned long long> d_sh_hkeys;
+    std::vector<uint32_t> sh_free, stale_shared;        // holes of the table (indices a new shared section may take); entries the device changed since the host mirrors were brought up to date
+    struct Rb2Scratch {
+        uint32_t cap = 0;                                 // movers the buffers are sized for
+        DevBuf<uint64_t> key, key2, ord, ord_s, kgath, ksorted1, ksorted2, mk, pair_key, pair_key_s; DevBuf<uint32_t> row, idx, perm_a, perm1, perm2, host_list, refold, tmp_u, tmp_s, free_u, free_off, free_s, pair_seg, pair_seg_s;
+        DevBuf<uint8_t> mnk, tmp; DevBuf<Rb2Seg> segs_u; DevBuf<Rb2ShSeg> segs_s; DevBuf<Rb2Status> status;
+    } rb2;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
-    uint32_t n_device_rebuckets = 0, n_phantom = 0;
+    uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0;
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -299,6 +309,12 @@ extern "C" int re_create(const re_config *cfg, re_ctx **out) try {
     return RE_OK;
 } RE_ABI_GUARD_NOCTX(g_create_error, "re_create")
 
+static void release_rb2(re_ctx *c) {
+    re_ctx::Rb2Scratch &B = c->rb2;
+    for (DevBuf<uint64_t> *b : { &B.key, &B.key2, &B.ord, &B.ord_s, &B.kgath, &B.ksorted1, &B.ksorted2, &B.mk, &B.pair_key, &B.pair_key_s }) b->release(nullptr);
+    for (DevBuf<uint32_t> *b : { &B.row, &B.idx, &B.perm_a, &B.perm1, &B.perm2, &B.host_list, &B.refold, &B.tmp_u, &B.tmp_s, &B.free_u, &B.free_off, &B.free_s, &B.pair_seg, &B.pair_seg_s }) b->release(nullptr);
+    B.mnk.release(nullptr); B.tmp.release(nullptr); B.segs_u.release(nullptr); B.segs_s.release(nullptr); B.status.release(nullptr); B.cap = 0;
+}
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
     c->d_light_rows.release(nullptr); c->d_light_out.release(nullptr); c->light_rows_dirty = true;
@@ -307,6 +323,8 @@ static void free_world(re_ctx *c) {
     c->d_rb_perm1.release(nullptr); c->d_rb_perm.release(nullptr); c->d_rb_tmprow.release(nullptr); c->d_rb_refold.release(nullptr); c->d_rb_free.release(nullptr); c->d_rb_freeoff.release(nullptr);
     c->d_rb_tmp.release(nullptr); c->d_rb_segs.release(nullptr); c->d_rb_status.release(nullptr); c->rb_cap = 0;
     c->d_hrb_list.release(nullptr); c->d_hrb_nk.release(nullptr); c->d_hrb_keys.release(nullptr);
+    c->d_sh_keys.release(nullptr); c->d_sh_nk.release(nullptr); c->d_cell_inact.release(nullptr); c->d_sh_rowcap.release(nullptr); c->d_sh_hidx.release(nullptr); c->d_sh_hkeys.release(nullptr);
+    c->sh_cap = 0; c->rb_sh_dirty = true; c->sh_free.clear(); c->stale_shared.clear(); release_rb2(c);
     c->d_id.release(a); c->d_gclass.release(a); c->d_flags.release(a); c->d_row_cell.release(a); c->d_mat.release(a); c->d_pos.release(a); c->d_rot.release(a);
     c->d_scale.release(a); c->d_aabb.release(a); c->d_orig.release(a); c->d_dyn_row.release(a); c->d_dyn_cell.release(a); c->d_dyn_vel.release(a); c->d_dyn_acc.release(a);
     c->d_dyn_rotvel.release(a); c->d_dyn_rotacc.release(a); c->d_row_key.release(a); c->d_row_nk.release(a); c->d_shrec.release(a); c->d_counter.release(a);
@@ -385,6 +403,21 @@ struct SortRec { uint64_t key; uint64_t sub; uint32_t row; };   // sub = static 
 using SharedId = SharedIdPub;
 }
 
+// The shared-section arrays hold sh_cap entries (the table itself [0, nsh), holes included); grown, never shrunk.  Callers re-upload the table afterwards.
+static int ensure_shared_capacity(re_ctx *c, uint32_t need) {
+    if (need <= c->sh_cap && c->d_sh_cells.p) return RE_OK;
+    uint64_t *acct = &c->dev_bytes;
+    const uint32_t cap = std::max(std::max(need * 2u + 1024u, c->sh_cap), std::min(c->ndyn, 1u << 20));      // (every dynamic entity may come to straddle a section border: room for the device path to create its shared section, ~200 bytes an entry)
+    HIPCHK(c, sync_stream(c->stream));
+    HIPCHK(c, c->d_sh_cells.alloc((size_t)cap * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(cap, acct)); HIPCHK(c, c->d_sh_aabb.alloc(cap, acct));
+    HIPCHK(c, c->d_sh_begin.alloc(cap, acct)); HIPCHK(c, c->d_sh_nact.alloc(cap, acct)); HIPCHK(c, c->d_sh_nstat.alloc(cap, acct));
+    HIPCHK(c, c->d_sh_cached.alloc(cap, acct)); HIPCHK(c, c->d_sh_dirty.alloc(cap, acct));
+    HIPCHK(c, c->d_sh_keys.alloc((size_t)cap * 8, nullptr)); HIPCHK(c, c->d_sh_nk.alloc(cap, nullptr)); HIPCHK(c, c->d_sh_rowcap.alloc(cap, nullptr));
+    uint32_t hs = 1024; while (hs < 4u * cap) hs <<= 1;
+    HIPCHK(c, c->d_sh_hkeys.alloc(hs, nullptr)); HIPCHK(c, c->d_sh_hidx.alloc(hs, nullptr)); c->sh_hmask = hs - 1u;
+    c->sh_cap = cap; c->rb_sh_dirty = true;
+    return RE_OK;
+}
 static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const std::vector<uint8_t> &row_nk, std::vector<SharedRec> &shrec,
                           const std::vector<uint32_t> &flags, const Carry *carry = nullptr) {
     const uint32_t n = c->n;
@@ -533,9 +566,8 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
     if (c->park_ready) { HIPCHK(c, c->park.d_cell_stamp.alloc(ncells, acct)); HIPCHK(c, hipMemset(c->park.d_cell_stamp.p, 0, (size_t)std::max(ncells, 1u) * 4)); }   // the parked lane's stamps follow a rebuilt table (it is idle: rebuilds happen behind drain_other_lane)
     c->pool_used = (uint32_t)rows.size(); c->pool_cap = c->pool_used + ((c->cfg.flags & RE_CFG_TIGHT_SLACK) ? 96u : c->pool_used / 4u + 65536u);      // slack: re-bucket patches append relocated segments
     HIPCHK(c, c->d_rows.alloc(c->pool_cap, acct)); HIPCHK(c, c->d_row_cell.alloc(std::max(n, c->row_cap), acct));
-    HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
-    HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));
-    HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
+    { int rcs = ensure_shared_capacity(c, nsh); if (rcs != RE_OK) return rcs; }
+    c->rb_sh_dirty = true; c->sh_free.clear(); c->stale_shared.clear();
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->d_cell_key.p, keys_padded.data(), keys_padded.size() * 8, hipMemcpyHostToDevice, st));
     {   // compact stream keys + the level of every 512-key chunk, when every section index fits 9 bits
@@ -1584,7 +1616,6 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
     }
     lap("C-F");
     // ---- G. upload + kernels
-    uint64_t *acct = &c->dev_bytes;
     {
         std::vector<FlagOp> vf; vf.reserve(fops.size()); for (auto &kv : fops) vf.push_back(kv.second);
         std::vector<Pair32> p_rowsgc; p_rowsgc.reserve(p_rows.size());         // the group class travels with every pool entry written
@@ -1625,11 +1656,8 @@ static int patch_sections(re_ctx *c, const Carry &carry, const std::map<uint64_t
         HIPCHK(c, sync_stream(st));                                 // `host` goes out of scope
     }
     lap("G upload");
-    if (nsh || old_nsh) {
-        HIPCHK(c, c->d_sh_cells.alloc((size_t)nsh * 8, acct)); HIPCHK(c, c->d_sh_owner.alloc(nsh, acct)); HIPCHK(c, c->d_sh_aabb.alloc(nsh, acct));
-        HIPCHK(c, c->d_sh_begin.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nact.alloc(nsh, acct)); HIPCHK(c, c->d_sh_nstat.alloc(nsh, acct));
-        HIPCHK(c, c->d_sh_cached.alloc(nsh, acct)); HIPCHK(c, c->d_sh_dirty.alloc(nsh, acct));
-    }
+    { int rcs = ensure_shared_capacity(c, nsh); if (rcs != RE_OK) return rcs; }      // (the table is rebuilt compactly below: no holes, the device-only parts follow at their next use)
+    c->rb_sh_dirty = true; c->sh_free.clear(); c->stale_shared.clear();
     if (nsh) {
         HIPCHK(c, hipMemcpyAsync(c->d_sh_cells.p, sh_cells.data(), (size_t)nsh * 8 * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(c->d_sh_begin.p, sh_begin.data(), (size_t)nsh * 4, hipMemcpyHostToDevice, st));
@@ -1681,7 +1709,10 @@ static RbCells rb_cells(re_ctx *c) {
 static RbTables rb_tables(re_ctx *c) { RbTables T; T.base_keys = c->d_base_keys.p; T.nbase = (uint32_t)c->base_keys.size(); T.ovl_keys = c->d_ovl_keys.p; T.ovl_slots = c->d_ovl_slots.p; T.ovl_mask = c->ovl_cap - 1u; return T; }
 
 // host mirrors of the sections the device patched, fetched when a host path needs them
+static ShTable sh_table(re_ctx *c);
+static int sync_shared_mirrors(re_ctx *c);
 static int sync_mirrors(re_ctx *c) {
+    { int rc = sync_shared_mirrors(c); if (rc != RE_OK) return rc; }          // (first: a row that moved from a shared to a unique section ends as the unique part below leaves it)
     if (c->stale_slots.empty()) return RE_OK;
     hipStream_t st = c->stream;
     std::sort(c->stale_slots.begin(), c->stale_slots.end()); c->stale_slots.erase(std::unique(c->stale_slots.begin(), c->stale_slots.end()), c->stale_slots.end());
@@ -1712,14 +1743,67 @@ static int sync_mirrors(re_ctx *c) {
             if (!is_pad(kn) && !(slot < c->base_keys.size() && c->base_keys[slot] == kn)) c->extra_slots[kn] = slot;
         }
         c->h_cell_key[slot] = kn; c->h_cell_begin[slot] = begin; c->h_cell_cap[slot] = cap; c->h_cell_nl[slot] = nl; c->h_cell_ns[slot] = ns; c->h_cell_ng[slot] = 0;
-        if (c->h_rows.size() < (size_t)begin + nl + ns) c->h_rows.resize((size_t)begin + nl + ns, 0);
+        if (c->h_rows.size() < (size_t)begin + std::max(cap, nl + ns)) c->h_rows.resize((size_t)begin + std::max(cap, nl + ns), 0);
+        // the rest of the segment holds whatever the device's compaction left there: never "already in place" for the host path, which uploads only the
+        // pool entries that differ from this mirror (patch_sections)
+        for (uint32_t k = nl + ns; k < cap; k++) c->h_rows[begin + k] = 0xFFFFFFFFu;
         for (uint32_t k = 0; k < nl + ns; k++) {
             const uint32_t r = rows[offs[i] + k];
             c->h_rows[begin + k] = r;
-            if (r < c->ghost_base) { c->h_row_cell[r] = slot; c->h_row_key[r] = kn; c->h_row_nk[r] = 1; }
+            if (r < c->ghost_base) { c->h_row_cell[r] = slot; c->h_row_key[r] = kn; if (c->h_row_nk[r] > 1) c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 1; }
         }
     }
     c->stale_slots.clear();
+    return done(RE_OK);
+}
+// the shared world sections the device created, changed or retired (rebucket_on_device2): ids, counts, linked slots, members
+static int sync_shared_mirrors(re_ctx *c) {
+    const uint32_t nsh = c->nsh;
+    if (c->h_shids.size() < nsh) { c->h_shids.resize(nsh, SharedIdPub{}); c->h_sh_nact.resize(nsh, 0); c->h_sh_nstat.resize(nsh, 0); c->h_sh_begin.resize(nsh, 0); c->h_sh_cells.resize((size_t)nsh * 8, -1); }
+    if (c->stale_shared.empty()) return RE_OK;
+    hipStream_t st = c->stream;
+    std::sort(c->stale_shared.begin(), c->stale_shared.end()); c->stale_shared.erase(std::unique(c->stale_shared.begin(), c->stale_shared.end()), c->stale_shared.end());
+    const uint32_t n = (uint32_t)c->stale_shared.size();
+    DevBuf<uint32_t> d_idx, d_hdr, d_offs, d_rows; DevBuf<uint64_t> d_keys; DevBuf<int32_t> d_cells;
+    auto done = [&](int rc) { d_idx.release(nullptr); d_hdr.release(nullptr); d_offs.release(nullptr); d_rows.release(nullptr); d_keys.release(nullptr); d_cells.release(nullptr); return rc; };
+    if (d_idx.alloc(n, nullptr) != hipSuccess || d_hdr.alloc((size_t)n * 5, nullptr) != hipSuccess || d_offs.alloc((size_t)n + 1, nullptr) != hipSuccess || d_keys.alloc((size_t)n * 8, nullptr) != hipSuccess
+        || d_cells.alloc((size_t)n * 8, nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: out of device memory"));
+    std::vector<uint64_t> keys((size_t)n * 8); std::vector<uint32_t> hdr((size_t)n * 5), offs((size_t)n + 1, 0); std::vector<int32_t> cells((size_t)n * 8);
+    if (hipMemcpyAsync(d_idx.p, c->stale_shared.data(), (size_t)n * 4, hipMemcpyHostToDevice, st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: copy"));
+    hipLaunchKernelGGL(k_rb2_gather_shared, dim3((n + 255) / 256), dim3(256), 0, st, n, (const uint32_t *)d_idx.p, sh_table(c), d_keys.p, d_hdr.p, d_cells.p);
+    (void)hipMemcpyAsync(keys.data(), d_keys.p, (size_t)n * 64, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(hdr.data(), d_hdr.p, (size_t)n * 20, hipMemcpyDeviceToHost, st);
+    (void)hipMemcpyAsync(cells.data(), d_cells.p, (size_t)n * 32, hipMemcpyDeviceToHost, st);
+    if (sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: shared section headers"));
+    for (uint32_t i = 0; i < n; i++) offs[i + 1] = offs[i] + hdr[(size_t)i * 5 + 2] + hdr[(size_t)i * 5 + 3];
+    std::vector<uint32_t> rows(std::max<uint32_t>(offs[n], 1u));
+    if (offs[n]) {
+        if (d_rows.alloc(offs[n], nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: out of device memory"));
+        (void)hipMemcpyAsync(d_offs.p, offs.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st);
+        hipLaunchKernelGGL(k_rb2_gather_shared_rows, dim3((n + 255) / 256), dim3(256), 0, st, n, (const uint32_t *)d_idx.p, (const uint32_t *)d_offs.p, sh_table(c), (const uint32_t *)c->d_rows.p, d_rows.p);
+        (void)hipMemcpyAsync(rows.data(), d_rows.p, (size_t)offs[n] * 4, hipMemcpyDeviceToHost, st);
+        if (sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "sync_mirrors: shared section rows"));
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s2 = c->stale_shared[i];
+        if (s2 >= nsh) continue;
+        const uint32_t begin = hdr[(size_t)i * 5], na = hdr[(size_t)i * 5 + 2], nst = hdr[(size_t)i * 5 + 3], nk = hdr[(size_t)i * 5 + 4];
+        SharedIdPub id{}; id.nk = nk; for (uint32_t k = 0; k < nk && k < 8; k++) id.keys[k] = keys[(size_t)i * 8 + k];
+        c->h_shids[s2] = id; c->h_sh_nact[s2] = na; c->h_sh_nstat[s2] = nst; c->h_sh_begin[s2] = begin;
+        for (uint32_t k = 0; k < 8; k++) {                                   // (the link counts a host patch resets: every slot linked before or now)
+            const int32_t was = c->h_sh_cells[(size_t)s2 * 8 + k], now = cells[(size_t)i * 8 + k];
+            if (was >= 0) c->h_linked_slots.push_back((uint32_t)was);
+            if (now >= 0) c->h_linked_slots.push_back((uint32_t)now);
+            c->h_sh_cells[(size_t)s2 * 8 + k] = now;
+        }
+        if (c->h_rows.size() < (size_t)begin + na + nst) c->h_rows.resize((size_t)begin + na + nst, 0);
+        std::array<uint64_t, 8> a; memcpy(a.data(), id.keys, sizeof id.keys);
+        for (uint32_t k = 0; k < na + nst; k++) {
+            const uint32_t r = rows[offs[i] + k];
+            c->h_rows[begin + k] = r;
+            if (r < c->ghost_base) { c->h_row_cell[r] = ROW_CELL_SHARED | s2; c->h_row_key[r] = id.keys[0]; c->h_row_nk[r] = (uint8_t)nk; c->h_row_shared_keys[r] = a; }
+        }
+    }
+    c->stale_shared.clear();
     return done(RE_OK);
 }
 
@@ -1836,6 +1920,199 @@ static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host
 }
 
 // ------------------------------------------------------------------------------------------------
+// rebucket_on_device, round 3: the whole batch of a tick's movers on the device, shared world sections included (re_rebucket.hip).  Returns RE_OK (the
+// movers listed in host_list -- static rows -- are left for the host path as a second batch), 1 when the batch is left to the host path whole (nothing
+// has been touched then), or an error.
+// ------------------------------------------------------------------------------------------------
+static ShTable sh_table(re_ctx *c) {
+    ShTable S; S.cells = c->d_sh_cells.p; S.aabb = c->d_sh_aabb.p; S.begin = c->d_sh_begin.p; S.nact = c->d_sh_nact.p; S.nstat = c->d_sh_nstat.p; S.rowcap = c->d_sh_rowcap.p;
+    S.owner = c->d_sh_owner.p; S.cached = c->d_sh_cached.p; S.dirty = c->d_sh_dirty.p; S.keys = c->d_sh_keys.p; S.nk = c->d_sh_nk.p;
+    S.hkeys = c->d_sh_hkeys.p; S.hidx = c->d_sh_hidx.p; S.hmask = c->sh_hmask; S.cap = c->sh_cap;
+    return S;
+}
+// the device-only parts of the shared table (ids, row capacities, id -> index hash, free indices) from the host mirrors, after a host path rebuilt the table
+static int ensure_device_shared(re_ctx *c) {
+    if (!c->rb_sh_dirty) return RE_OK;
+    { int rc = ensure_shared_capacity(c, c->nsh); if (rc != RE_OK) return rc; }
+    hipStream_t st = c->stream;
+    const uint32_t n = c->nsh;
+    std::vector<uint64_t> keys((size_t)std::max(n, 1u) * 8, 0ull); std::vector<uint8_t> nk(std::max(n, 1u), 0); std::vector<uint32_t> rowcap(std::max(n, 1u), 0);
+    c->sh_free.clear();
+    for (uint32_t s2 = 0; s2 < n; s2++) {
+        const SharedIdPub &id = c->h_shids[s2];
+        nk[s2] = (uint8_t)id.nk; for (uint32_t k = 0; k < id.nk && k < 8; k++) keys[(size_t)s2 * 8 + k] = id.keys[k];
+        rowcap[s2] = c->h_sh_nact[s2] + c->h_sh_nstat[s2];                   // (a host path packs the members without slack)
+        if (!id.nk) c->sh_free.push_back(s2);
+    }
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_keys.p, keys.data(), (size_t)n * 64, hipMemcpyHostToDevice, st)); HIPCHK(c, hipMemcpyAsync(c->d_sh_nk.p, nk.data(), n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(c->d_sh_rowcap.p, rowcap.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_sh_hkeys.p, 0xFF, ((size_t)c->sh_hmask + 1u) * 8, st));
+    if (n) hipLaunchKernelGGL(k_rb2_hash_insert, dim3((n + 255) / 256), dim3(256), 0, st, n, sh_table(c));
+    HIPCHK(c, hipGetLastError()); HIPCHK(c, sync_stream(st));                // (the staging vectors go out of scope)
+    c->rb_sh_dirty = false; c->sh_hash_used = n - (uint32_t)c->sh_free.size();
+    return RE_OK;
+}
+static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *host_list) {
+    host_list->clear();
+    if (!M || !device_rebucket_applicable(c)) return 1;
+    hipStream_t st = c->stream;
+    static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
+    auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  device rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
+    // ---- lookup tables: sorted keys of the last full build + overlay of the sections created since; the shared table's device-only parts
+    if (c->rb_base_dirty) {
+        HIPCHK(c, c->d_base_keys.alloc(c->base_keys.size(), &c->dev_bytes));
+        HIPCHK(c, hipMemcpyAsync(c->d_base_keys.p, c->base_keys.data(), c->base_keys.size() * 8, hipMemcpyHostToDevice, st));
+        c->rb_base_dirty = false;
+    }
+    if (!c->ovl_cap) { c->ovl_cap = 1u << 17; HIPCHK(c, c->d_ovl_keys.alloc(c->ovl_cap, nullptr)); HIPCHK(c, c->d_ovl_slots.alloc(c->ovl_cap, nullptr)); c->rb_ovl_dirty = true; }
+    if (((uint64_t)c->sh_hash_used + std::min(2u * M, c->sh_cap)) * 2u > (uint64_t)c->sh_hmask + 1u) c->rb_sh_dirty = true;      // retired ids keep their hash entry: rebuild before the probes get long
+    if (c->rb_ovl_dirty || c->rb_sh_dirty) { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
+    if (c->rb_ovl_dirty) {
+        if (c->extra_slots.size() * 4u > c->ovl_cap) return 1;
+        HIPCHK(c, hipMemsetAsync(c->d_ovl_keys.p, 0xFF, (size_t)c->ovl_cap * 8, st));
+        std::vector<Pair64> pr; pr.reserve(c->extra_slots.size());
+        for (auto &kv : c->extra_slots) pr.push_back(Pair64{ kv.second, 0u, kv.first });
+        if (!pr.empty()) {
+            if (c->d_stage.n < pr.size() * sizeof(Pair64)) HIPCHK(c, c->d_stage.alloc(pr.size() * sizeof(Pair64) * 2, nullptr));
+            HIPCHK(c, hipMemcpyAsync(c->d_stage.p, pr.data(), pr.size() * sizeof(Pair64), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_rb_ovl_insert, dim3(((uint32_t)pr.size() + 255) / 256), dim3(256), 0, st, (uint32_t)pr.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p), rb_tables(c));
+            HIPCHK(c, sync_stream(st));
+        }
+        c->ovl_count = (uint32_t)c->extra_slots.size(); c->rb_ovl_dirty = false;
+    }
+    { int rc = ensure_device_shared(c); if (rc != RE_OK) return rc; }
+    if (((uint64_t)c->sh_hash_used + std::min(2u * M, c->sh_cap)) * 2u > (uint64_t)c->sh_hmask + 1u) return 1;      // (cannot happen: the hash has 4 entries per table entry and a batch creates at most as many sections as the table has free entries)
+    // ---- scratch: 2 member ops per mover + up to 8 link ops per op of a shared placement
+    re_ctx::Rb2Scratch &B = c->rb2;
+    const uint32_t n1 = 2u * M, link_cap = 16u * M;
+    if (B.cap < M) {
+        const uint32_t mc = std::max(2u * M, 2048u), oc = 18u * mc;
+        for (DevBuf<uint64_t> *b : { &B.key, &B.key2, &B.ord, &B.ord_s, &B.kgath, &B.ksorted1, &B.ksorted2 }) HIPCHK(c, b->alloc(oc, nullptr));
+        for (DevBuf<uint32_t> *b : { &B.row, &B.idx, &B.perm_a, &B.perm1, &B.perm2, &B.refold, &B.tmp_u, &B.tmp_s }) HIPCHK(c, b->alloc(oc, nullptr));
+        HIPCHK(c, B.mk.alloc((size_t)mc * 8, nullptr)); HIPCHK(c, B.mnk.alloc(mc, nullptr)); HIPCHK(c, B.host_list.alloc(mc, nullptr));
+        HIPCHK(c, B.segs_u.alloc(oc, nullptr)); HIPCHK(c, B.segs_s.alloc(2u * mc, nullptr));
+        HIPCHK(c, B.free_u.alloc(oc, nullptr)); HIPCHK(c, B.free_off.alloc(MAX_LEVELS, nullptr)); HIPCHK(c, B.free_s.alloc(2u * mc, nullptr));
+        HIPCHK(c, B.pair_key.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_key_s.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_seg.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_seg_s.alloc(16u * mc, nullptr));
+        if (!B.status.p) HIPCHK(c, B.status.alloc(1, nullptr));
+        size_t t1 = 0, t2 = 0;
+        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, oc, 0, 34, st));
+        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t2, B.kgath.p, B.ksorted1.p, B.perm_a.p, B.perm1.p, oc, 0, 64, st));
+        HIPCHK(c, B.tmp.alloc(std::max(t1, t2) + 256, nullptr));
+        B.cap = mc;
+    }
+    if (!c->d_cell_inact.p || c->d_cell_inact.n < c->ncells) HIPCHK(c, c->d_cell_inact.alloc(std::max(c->ncells, 1u), nullptr));
+    Rb2Status hs{}; hs.pool_used = c->pool_used;
+    HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    const RbTables T = rb_tables(c); const RbCells C = rb_cells(c); const ShTable S = sh_table(c);
+    auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm) -> int {      // by (placement key, reference order): two stable radix sorts
+        size_t tb = B.tmp.n;
+        HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, n, 0, 34, st));
+        hipLaunchKernelGGL(k_rb_gather_keys, dim3((n + 255) / 256), dim3(256), 0, st, n, (const uint32_t *)B.perm_a.p, key_src, B.kgath.p);
+        tb = B.tmp.n;
+        HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.kgath.p, ksorted, B.perm_a.p, perm, n, 0, 64, st));
+        return RE_OK;
+    };
+    // ---- phase 1 + 2: ops, the shared placements
+    hipLaunchKernelGGL(k_rb2_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), C, S, c->cfg.outline_length, c->cfg.atomic_length,
+                       B.key.p, B.key2.p, B.ord.p, B.row.p, B.idx.p, B.mk.p, B.mnk.p, B.host_list.p, B.status.p);
+    { int rc = sort_ops(n1, B.key.p, B.ksorted1.p, B.perm1.p); if (rc != RE_OK) return rc; }
+    hipLaunchKernelGGL(k_rb2_shared_segments, dim3((n1 + 255) / 256), dim3(256), 0, st, n1, M, (const uint32_t *)B.perm1.p, (const uint64_t *)B.ksorted1.p, (const uint32_t *)B.row.p, B.ord.p,
+                       (const uint64_t *)B.mk.p, (const uint8_t *)B.mnk.p, S, C, B.key2.p, B.row.p, B.idx.p, link_cap, B.segs_s.p, B.status.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, sync_stream(st));
+    lap("shared");
+    if (hs.fallback || hs.n_link > link_cap) return 1;
+    // ---- phase 3: the unique placements with the link ops merged in
+    const uint32_t n2 = n1 + hs.n_link;
+    { int rc = sort_ops(n2, B.key2.p, B.ksorted2.p, B.perm2.p); if (rc != RE_OK) return rc; }
+    hipLaunchKernelGGL(k_rb2_unique_segments, dim3((n2 + 255) / 256), dim3(256), 0, st, n2, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, sync_stream(st));
+    lap("unique");
+    if (hs.fallback) return 1;
+    // movers the host path keeps (static rows): as a second batch behind this one, only where the threshold of total_world_aabb_combining cannot depend on the split
+    if (hs.n_host >= M || (hs.n_host && hs.total <= 500u)) return 1;
+    std::vector<uint32_t> keep(hs.n_host);
+    if (hs.n_host) HIPCHK(c, hipMemcpy(keep.data(), B.host_list.p, (size_t)hs.n_host * 4, hipMemcpyDeviceToHost));
+    uint32_t need_total = 0;
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { if (hs.need_slots[l] > c->free_slots[l].size()) return 1; need_total += hs.need_slots[l]; }
+    if ((uint64_t)c->pool_used + hs.need_pool > c->pool_cap) return 1;
+    if (((uint64_t)c->ovl_count + need_total) * 2u > c->ovl_cap) return 1;
+    if (hs.need_sh > c->sh_free.size() + (c->sh_cap - c->nsh)) return 1;      // (the host path rebuilds the table compactly and with more room)
+    // ---- phase 4: free slots / free shared indices for what is created, then the patch itself
+    std::vector<uint32_t> fl, off(MAX_LEVELS, 0), fs;
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { off[l] = (uint32_t)fl.size(); for (uint32_t j = 0; j < hs.need_slots[l]; j++) fl.push_back(c->free_slots[l][c->free_slots[l].size() - 1u - j]); }
+    { uint32_t bump = c->nsh; for (uint32_t j = 0; j < hs.need_sh; j++) fs.push_back(j < c->sh_free.size() ? c->sh_free[c->sh_free.size() - 1u - j] : bump++); }
+    if (!fl.empty()) HIPCHK(c, hipMemcpyAsync(B.free_u.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, st));
+    if (!fs.empty()) HIPCHK(c, hipMemcpyAsync(B.free_s.p, fs.data(), fs.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(B.free_off.p, off.data(), MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
+    const uint32_t nu = hs.nseg_u, ns = hs.nseg_s;
+    uint32_t nsh_after = c->nsh; for (uint32_t x : fs) nsh_after = std::max(nsh_after, x + 1u);
+    if (nu) hipLaunchKernelGGL(k_rb2_apply_unique, dim3((nu + 63) / 64), dim3(64), 0, st, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), c->d_cell_links.p, B.segs_u.p, B.status.p,
+                               (const uint32_t *)B.free_u.p, (const uint32_t *)B.free_off.p, B.tmp_u.p, B.refold.p);
+    if (ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3((ns + 63) / 64), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p,
+                               (const uint32_t *)B.free_s.p, B.tmp_s.p);
+    // update_static_world_sections: first loop (changed / new unique sections), second loop (changed shared sections in canonical order)
+    HIPCHK(c, hipMemsetAsync(c->d_cell_inact.p, 0, std::max(c->ncells, 1u), st));
+    if (nsh_after) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p);
+    if (nu) hipLaunchKernelGGL(k_rb2_static_first, dim3((nu + 255) / 256), dim3(256), 0, st, C, (const uint8_t *)c->d_cell_links.p, (const uint8_t *)c->d_cell_inact.p, (const Rb2Seg *)B.segs_u.p, (const Rb2Status *)B.status.p);
+    if (ns) {
+        hipLaunchKernelGGL(k_rb2_static_pairs, dim3((ns + 255) / 256), dim3(256), 0, st, (const Rb2ShSeg *)B.segs_s.p, (const Rb2Status *)B.status.p, S, B.pair_key.p, B.pair_seg.p, B.status.p);
+        const uint32_t np_max = 8u * ns;                                      // (pairs beyond n_pairs carry stale keys: sort only what was written -- the count comes back with the status below, so sort the bound and let the kernel stop at n_pairs)
+        HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, sync_stream(st));
+        const uint32_t np = std::min(hs.n_pairs, np_max);
+        if (np) {
+            size_t tb = B.tmp.n;
+            HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.pair_key.p, B.pair_key_s.p, B.pair_seg.p, B.pair_seg_s.p, np, 0, 32, st));
+            hipLaunchKernelGGL(k_rb2_static_second, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint64_t *)B.pair_key_s.p, (const uint32_t *)B.pair_seg_s.p, (const Rb2ShSeg *)B.segs_s.p, C);
+        }
+    }
+    // end_of_changes: tight AABBs of the changed sections (bounding_box_tree_v2.rs:1055-1130)
+    if (nu) hipLaunchKernelGGL(k_fold_tight_list, dim3((nu + 255) / 256), dim3(256), 0, st, nu, (const uint32_t *)B.refold.p, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p,
+                               c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    std::vector<Rb2Seg> su(nu); std::vector<Rb2ShSeg> ss(ns); Rb2Status h2{};
+    HIPCHK(c, hipMemcpyAsync(&h2, B.status.p, sizeof h2, hipMemcpyDeviceToHost, st));
+    if (nu) HIPCHK(c, hipMemcpyAsync(su.data(), B.segs_u.p, (size_t)nu * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st));
+    if (ns) HIPCHK(c, hipMemcpyAsync(ss.data(), B.segs_s.p, (size_t)ns * sizeof(Rb2ShSeg), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, sync_stream(st));
+    lap("apply");
+    // ---- what the host keeps in step at once: free slots / indices, pool fill, counts; everything else waits for sync_mirrors
+    if (h2.err) return c->fail(RE_E_STATE, "device re-bucket: accounting error %u in the apply phase", h2.err);
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
+        if (h2.popped[l] != hs.need_slots[l]) return c->fail(RE_E_STATE, "device re-bucket: free-slot accounting (level %u: %u taken, %u planned)", l, h2.popped[l], hs.need_slots[l]);
+        c->free_slots[l].resize(c->free_slots[l].size() - hs.need_slots[l]);
+    }
+    if (h2.popped_sh != hs.need_sh) return c->fail(RE_E_STATE, "device re-bucket: shared-index accounting (%u taken, %u planned)", h2.popped_sh, hs.need_sh);
+    { const uint32_t from_holes = std::min<uint32_t>(hs.need_sh, (uint32_t)c->sh_free.size()); c->sh_free.resize(c->sh_free.size() - from_holes); }
+    int32_t delta = 0;
+    for (const Rb2Seg &G : su) {
+        if (G.slot < 0) continue;
+        c->stale_slots.push_back((uint32_t)G.slot);
+        if (G.freed) { c->free_slots[key_level(G.key) & (MAX_LEVELS - 1)].push_back((uint32_t)G.slot); delta--; }
+        if (G.created) delta++;
+    }
+    for (const Rb2ShSeg &G : ss) {
+        if (G.idx < 0) continue;
+        c->stale_shared.push_back((uint32_t)G.idx);
+        if (G.freed) c->sh_free.push_back((uint32_t)G.idx);
+    }
+    if (h2.pool_used > c->pool_cap) return c->fail(RE_E_STATE, "device re-bucket: row-pool accounting");
+    c->nsh = nsh_after; c->sh_hash_used += h2.n_sh_created;
+    c->pool_used = h2.pool_used; c->nrows_csr = c->pool_used; c->ovl_count += h2.n_created;
+    c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + delta);
+    c->n_patches++; c->n_device_rebuckets++;
+    host_list->swap(keep);
+    lap("bookkeeping");
+    return RE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Incremental re-bucket after a tick: update_entity_in_tree -> BoundingBoxTree::add_entity (which removes the entity from
 // its previous section) for every mover whose section changed, then end_of_changes (helper_things/entity_change_helpers.rs:
 // 217-262, 325-351; world/bounding_box_tree_v2.rs:563-942, 1055-1213).  Order of the reference: translation-only movers, then
@@ -1859,10 +2136,12 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         HIPCHK(c, hipMemcpy(c->moved_rows.data() + at, c->d_movers.p, (size_t)m0 * 4, hipMemcpyDeviceToHost));
     }
     if (!pre && !ghost_touched) {
-        int drc = rebucket_on_device(c, n_movers, &movers);
+        static const bool v1 = getenv("RE_EXP_RB_V1") != nullptr;          // A/B switch: round 2's device path (unique, unlinked sections only)
+        int drc = v1 ? rebucket_on_device(c, n_movers, &movers) : rebucket_on_device2(c, n_movers, &movers);
         if (drc < 0) return drc;
         if (drc == 0) { if (movers.empty()) return RE_OK; second_batch = true; }
     }
+    c->n_host_rebuckets++;
     { int src = sync_mirrors(c); if (src != RE_OK) return src; }
     const uint32_t M = second_batch ? (uint32_t)movers.size() : std::min(n_movers, c->list_cap);
     if (!second_batch) { movers.resize(M); HIPCHK(c, hipMemcpy(movers.data(), c->d_movers.p, (size_t)M * 4, hipMemcpyDeviceToHost)); }
@@ -3265,7 +3544,7 @@ extern "C" int re_get_out_of_bounds(re_ctx *c, uint32_t *ids, uint32_t capacity,
 
 extern "C" int re_get_stats(re_ctx *c, re_stats *out) try {
     if (!c || !out) return RE_E_ARG;
-    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh; out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->n_device_rebuckets = c->n_device_rebuckets; out->n_segment_redos = c->n_segment_redos; out->reserved2 = 0;
+    out->n_entities = c->n; out->n_dynamic = c->ndyn; out->n_sections = c->n_real_sections; out->n_shared_sections = c->nsh - (uint32_t)c->sh_free.size();   /* (retired entries of the table are holes until a host path rebuilds it) */ out->max_level = c->maxlevel; out->device_bytes = c->dev_bytes; out->n_probe_frames = c->probe_frames; out->n_table_rebuilds = c->n_rebuilds; out->n_fused_frames = c->n_fused_frames; out->reserved = c->n_lane_switches; out->n_seal_waits = c->n_seal_waits; out->n_sync_fallbacks = c->n_sync_fallbacks; out->n_section_slots = c->ncells; out->n_device_rebuckets = c->n_device_rebuckets; out->n_segment_redos = c->n_segment_redos; out->n_host_rebuckets = c->n_host_rebuckets;
     return RE_OK;
 } RE_ABI_GUARD(c, "re_get_stats")
 
@@ -3295,6 +3574,53 @@ extern "C" int re_debug_get_sections(re_ctx *c, uint32_t capacity, uint64_t *key
     }
     return RE_OK;
 } RE_ABI_GUARD(c, "re_debug_get_sections")
+
+// the shared world sections in canonical id order (keys lexicographic, then count): ids, AABB, members (active, then static; each in ascending EntityId).
+// Read from the DEVICE table; the host mirrors are checked against it on the way (RE_E_STATE when they are out of step).
+extern "C" int re_debug_get_shared_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, uint8_t *n_keys, float *aabb, uint32_t *n_active, uint32_t *n_static,
+                                            uint32_t member_capacity, uint32_t *member_ids, uint32_t *member_offsets, uint32_t *n) try {
+    if (!c) return RE_E_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    { int rc_ = resolve(c); if (rc_ != RE_OK) return rc_; }
+    { int rc_ = sync_mirrors(c); if (rc_ != RE_OK) return rc_; }
+    const uint32_t m = c->nsh;
+    std::vector<uint32_t> order; order.reserve(m);
+    for (uint32_t i = 0; i < m; i++) if (c->h_shids[i].nk) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return c->h_shids[a] < c->h_shids[b]; });
+    if (n) *n = (uint32_t)order.size();
+    if (!m || !capacity) return RE_OK;
+    std::vector<Aabb> box(m); std::vector<uint32_t> na(m), ns(m), bg(m), rows(std::max(c->pool_used, 1u)); std::vector<int32_t> cells((size_t)m * 8);
+    HIPCHK(c, hipMemcpy(box.data(), c->d_sh_aabb.p, (size_t)m * 24, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(na.data(), c->d_sh_nact.p, (size_t)m * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(ns.data(), c->d_sh_nstat.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(bg.data(), c->d_sh_begin.p, (size_t)m * 4, hipMemcpyDeviceToHost)); HIPCHK(c, hipMemcpy(cells.data(), c->d_sh_cells.p, (size_t)m * 32, hipMemcpyDeviceToHost));
+    if (c->pool_used) HIPCHK(c, hipMemcpy(rows.data(), c->d_rows.p, (size_t)c->pool_used * 4, hipMemcpyDeviceToHost));
+    uint32_t off = 0;
+    for (uint32_t o = 0; o < order.size(); o++) {
+        const uint32_t i = order[o];
+        if (na[i] != c->h_sh_nact[i] || ns[i] != c->h_sh_nstat[i] || bg[i] != c->h_sh_begin[i]) return c->fail(RE_E_STATE, "shared section %u: host mirror out of step (%u+%u members at %u on the device, %u+%u at %u on the host)", i, na[i], ns[i], bg[i], c->h_sh_nact[i], c->h_sh_nstat[i], c->h_sh_begin[i]);
+        if ((uint64_t)bg[i] + na[i] + ns[i] > c->pool_used) return c->fail(RE_E_STATE, "shared section %u: members outside the row pool", i);
+        for (uint32_t k = 0; k < 8; k++) {
+            const int32_t ci = cells[(size_t)i * 8 + k];
+            if (k < c->h_shids[i].nk ? (ci < 0 || (uint32_t)ci >= c->ncells || c->h_cell_key[ci] != c->h_shids[i].keys[k]) : ci >= 0) return c->fail(RE_E_STATE, "shared section %u: link %u does not lead to its section (slot %d)", i, k, ci);
+            if (ci != c->h_sh_cells[(size_t)i * 8 + k]) return c->fail(RE_E_STATE, "shared section %u: host mirror of link %u out of step", i, k);
+        }
+        for (uint32_t k = 0; k < na[i] + ns[i]; k++) {
+            const uint32_t r = rows[bg[i] + k];
+            if (r >= c->ghost_base) continue;
+            if (c->h_row_cell[r] != (ROW_CELL_SHARED | i) || c->h_rows[bg[i] + k] != r) return c->fail(RE_E_STATE, "shared section %u: host mirror of member %u out of step", i, k);
+        }
+        if (o >= capacity) continue;
+        if (keys) memcpy(keys + (size_t)o * 8, c->h_shids[i].keys, 64);
+        if (n_keys) n_keys[o] = (uint8_t)c->h_shids[i].nk;
+        if (aabb) memcpy(aabb + (size_t)o * 6, &box[i], 24);
+        if (n_active) n_active[o] = na[i];
+        if (n_static) n_static[o] = ns[i];
+        if (member_offsets) member_offsets[o] = off;
+        for (uint32_t k = 0; k < na[i] + ns[i]; k++, off++) if (member_ids && off < member_capacity) { const uint32_t r = rows[bg[i] + k]; member_ids[off] = r < c->n ? c->h_id[r] : 0xFFFFFFFFu; }
+        if (member_offsets) member_offsets[o + 1] = off;
+    }
+    return RE_OK;
+} RE_ABI_GUARD(c, "re_debug_get_shared_sections")
 
 extern "C" int re_debug_get_visible_sections(re_ctx *c, uint32_t capacity, uint64_t *keys, uint8_t *multiplicity, uint32_t *n) try {
     if (!c || !c->have_cull) return RE_E_ARG;

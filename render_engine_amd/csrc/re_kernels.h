@@ -269,6 +269,61 @@ struct RbCells {
     uint32_t *rows, *rows_gc, *row_cell; uint64_t *row_key; uint32_t pool_cap;
     const uint8_t *cell_links;                               // shared sections linking each unique section (maintained by the host paths)
 };
+// ---- the device-side re-bucket with shared sections (re_rebucket.hip; re_api.hip: rebucket_on_device) ----
+constexpr uint64_t RB2_SHARED_BIT = 0x8000000000000000ull;   // placement key of a shared section: this bit + 63 bits of the hash of its id (a unique section's key has a level < 16 up there)
+constexpr uint32_t RB2_LINK_INC = 0x40000000u, RB2_LINK_DEC = 0x20000000u;   // op words of the link ops a shared section's creation / emptying sends to the sections it links
+struct ShTable {                                             // shared world sections with STABLE indices: cap entries, a retired one is a hole (nk == 0, no members, no links)
+    int32_t *cells; Aabb *aabb; uint32_t *begin, *nact, *nstat, *rowcap; int32_t *owner; uint8_t *cached, *dirty;
+    uint64_t *keys; uint8_t *nk;                             // the id (SharedWorldSectionId): nk linked section keys
+    unsigned long long *hkeys; uint32_t *hidx; uint32_t hmask;   // placement key -> index (open addressing; a retired entry keeps its key with index ~0)
+    uint32_t cap;
+};
+struct Rb2Status {                                           // one block the host reads between the phases
+    uint32_t fallback, err;                                  // fallback: a mover / a collision of placement keys the device path does not handle (nothing has been touched); err: accounting broke in the apply phase
+    uint32_t total;                                          // total_world_aabb_combining of the batch
+    uint32_t nseg_u, nseg_s, n_link, n_pairs, n_host;
+    uint32_t need_pool, need_sh, need_slots[MAX_LEVELS];
+    uint32_t popped[MAX_LEVELS], popped_sh, pool_used;
+    uint32_t n_created, n_freed, n_sh_created, n_sh_freed;
+};
+struct Rb2Seg { uint64_t key; int32_t slot; uint32_t op_begin, op_count, nl1, ns, links1; uint8_t exists0, exists1, created, freed, changed, pad[3]; };
+struct Rb2ShSeg { uint64_t pkey; uint64_t keys[8]; int32_t idx; uint32_t op_begin, op_count, na1, nst, nk; uint8_t exists0, exists1, created, freed, relink, pad[3]; };
+__global__ void k_rb2_hash_insert(uint32_t n, ShTable S);
+__global__ void k_rb2_ops(uint32_t m, const uint32_t *movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic, uint64_t *op_key, uint64_t *op_key2, uint64_t *op_ord,
+                          uint32_t *op_row, uint32_t *op_idx, uint64_t *mk, uint8_t *mnk, uint32_t *host_list, Rb2Status *st);
+__global__ void k_rb2_shared_segments(uint32_t n, uint32_t m, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, uint64_t *op_ord, const uint64_t *mk, const uint8_t *mnk,
+                                      ShTable S, RbCells C, uint64_t *op_key2, uint32_t *op_row_w, uint32_t *op_idx, uint32_t link_cap, Rb2ShSeg *segs, Rb2Status *st);
+__global__ void k_rb2_unique_segments(uint32_t n, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, RbTables T, RbCells C, uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st);
+__global__ void k_rb2_apply_unique(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st,
+                                   const uint32_t *free_slots, const uint32_t *free_off, uint32_t *tmp_row, uint32_t *refold);
+__global__ void k_rb2_apply_shared(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, ShTable S, Rb2ShSeg *segs, Rb2Status *st, const uint32_t *free_sh, uint32_t *tmp_row);
+__global__ void k_rb2_mark_inactive(uint32_t nsh, ShTable S, uint8_t *cell_inact);
+__global__ void k_rb2_static_first(RbCells C, const uint8_t *cell_links, const uint8_t *cell_inact, const Rb2Seg *segs, const Rb2Status *st);
+__global__ void k_rb2_static_pairs(const Rb2ShSeg *segs, const Rb2Status *st, ShTable S, uint64_t *pair_key, uint32_t *pair_seg, Rb2Status *stw);
+__global__ void k_rb2_static_second(uint32_t n, const uint64_t *slot_sorted, const uint32_t *seg_sorted, const Rb2ShSeg *segs, RbCells C);
+__global__ void k_rb2_gather_shared(uint32_t n, const uint32_t *idxs, ShTable S, uint64_t *out_keys, uint32_t *out_hdr, int32_t *out_cells);
+__global__ void k_rb2_gather_shared_rows(uint32_t n, const uint32_t *idxs, const uint32_t *offs, ShTable S, const uint32_t *rows, uint32_t *out_rows);
+__global__ void k_rb2_gather_links(uint32_t n, const uint32_t *slots, const uint8_t *cell_links, uint8_t *out);
+#if defined(__HIPCC__)
+// key -> slot of the resident section table (shared by the re-bucket kernels of re_kernels.hip and re_rebucket.hip)
+__device__ __forceinline__ uint32_t rb_hash(uint64_t k) { k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29; return (uint32_t)k; }
+__device__ __forceinline__ int32_t rb_find(const RbTables &T, const uint64_t *cell_key, uint64_t key) {
+    for (uint32_t h = rb_hash(key) & T.ovl_mask;; h = (h + 1u) & T.ovl_mask) {          // sections created since the last full build (authoritative for the keys they hold)
+        const unsigned long long k = T.ovl_keys[h];
+        if (k == ~0ull) break;
+        if (k == key) { const uint32_t sl = T.ovl_slots[h]; return cell_key[sl] == key ? (int32_t)sl : -1; }
+    }
+    uint32_t lo = 0, hi = T.nbase;                                                     // lower_bound in the immutable sorted keys of the last full build
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (T.base_keys[mid] < key) lo = mid + 1u; else hi = mid; }
+    return (lo < T.nbase && T.base_keys[lo] == key && cell_key[lo] == key) ? (int32_t)lo : -1;
+}
+__device__ __forceinline__ void rb_ovl_put(const RbTables &T, uint64_t key, uint32_t slot) {
+    for (uint32_t h = rb_hash(key) & T.ovl_mask;; h = (h + 1u) & T.ovl_mask) {
+        const unsigned long long prev = atomicCAS(&T.ovl_keys[h], ~0ull, (unsigned long long)key);
+        if (prev == ~0ull || prev == key) { T.ovl_slots[h] = slot; return; }
+    }
+}
+#endif
 hipError_t sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                               uint32_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream);      // re_sort.hip (rocPRIM radix sort)
 __global__ void k_rb_ops(uint32_t m, const uint32_t *movers, RowArrays R, RbTables T, RbCells C, uint32_t outline, uint32_t atomic,

@@ -1640,23 +1640,6 @@ __global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t 
 // rows are listed for the host path (re_api.hip: rebucket), which takes them as a second batch behind this one; worlds with ghosts of the frozen
 // static cache or hidden rows stay on the host path altogether.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rb_hash(uint64_t k) { k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 29; return (uint32_t)k; }
-__device__ __forceinline__ int32_t rb_find(const RbTables &T, const uint64_t *cell_key, uint64_t key) {
-    for (uint32_t h = rb_hash(key) & T.ovl_mask;; h = (h + 1u) & T.ovl_mask) {          // sections created since the last full build (authoritative for the keys they hold)
-        const unsigned long long k = T.ovl_keys[h];
-        if (k == ~0ull) break;
-        if (k == key) { const uint32_t sl = T.ovl_slots[h]; return cell_key[sl] == key ? (int32_t)sl : -1; }
-    }
-    uint32_t lo = 0, hi = T.nbase;                                                     // lower_bound in the immutable sorted keys of the last full build
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (T.base_keys[mid] < key) lo = mid + 1u; else hi = mid; }
-    return (lo < T.nbase && T.base_keys[lo] == key && cell_key[lo] == key) ? (int32_t)lo : -1;
-}
-__device__ __forceinline__ void rb_ovl_put(const RbTables &T, uint64_t key, uint32_t slot) {
-    for (uint32_t h = rb_hash(key) & T.ovl_mask;; h = (h + 1u) & T.ovl_mask) {
-        const unsigned long long prev = atomicCAS(&T.ovl_keys[h], ~0ull, (unsigned long long)key);
-        if (prev == ~0ull || prev == key) { T.ovl_slots[h] = slot; return; }
-    }
-}
 __global__ __launch_bounds__(256) void k_rb_ovl_insert(uint32_t n, const Pair64 *__restrict__ pairs, RbTables T) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rb_ovl_put(T, pairs[i].val, pairs[i].idx);

@@ -1,0 +1,372 @@
+// re_rebucket.hip -- the re-bucket bookkeeping of a tick's movers on the device, shared world sections included.
+//
+// update_entity_in_tree -> BoundingBoxTree::add_entity (which first removes the entity from its previous section) for every mover whose section
+// changed, then end_of_changes and update_static_world_sections (helper_things/entity_change_helpers.rs:217-262, 325-351;
+// world/bounding_box_tree_v2.rs:563-942, 1055-1213).  Round 2 (re_kernels.hip: k_rb_*) took the movers between UNIQUE sections that no shared section
+// links and left the rest -- about half of the placement changes of a scene whose boxes straddle section borders for a tick -- to the host.  Here a
+// placement is either kind:
+//   * two ops per mover, remove from the old placement and add to the new one, keyed by the placement -- a unique section's key, or the hash of a
+//     shared section's id (its 2..8 linked keys) with the top bit set -- and by the reference's order (translation-only movers first, then ascending
+//     EntityId, remove before add); sorted, one thread replays a placement's ops in order;
+//   * the SHARED placements first: what the section ends as, and every time it is created or emptied on the way it emits a link op (+1 / -1) for each
+//     unique section it links, stamped with the order of the op that caused it;
+//   * then the unique placements with those link ops merged in by order, so that a section's existence (members or links) and its share of
+//     total_world_aabb_combining evolve exactly as in the reference's one sequential pass;
+//   * the host reads one status block (is the batch eligible, is there slack: free slots per level, free shared entries, row pool), hands the free
+//     slots over, and the apply kernels rewrite the segments of the row pool, create / retire sections and shared entries (stable indices, holes
+//     allowed), recompute the links' slots, the shared AABBs (last member), the static-section flags (both loops of update_static_world_sections) and
+//     the tight AABBs of the changed sections.
+// The host only notes what changed; its mirrors follow on demand (re_api.hip: sync_mirrors).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "re_kernels.h"
+#include "re_math.h"
+
+namespace re {
+
+__device__ __forceinline__ uint64_t sh_id_pkey(const uint64_t *keys, uint32_t nk) {      // placement key of a shared section: top bit set, never ~0
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ nk;
+    for (uint32_t k = 0; k < nk; k++) { h ^= keys[k]; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; }
+    uint64_t p = RB2_SHARED_BIT | (h >> 1);
+    if (p == ~0ull) p ^= 1ull;
+    return p;
+}
+__device__ __forceinline__ bool sh_same_id(const uint64_t *a, uint32_t na, const uint64_t *b, uint32_t nb) {
+    if (na != nb) return false;
+    for (uint32_t k = 0; k < na; k++) if (a[k] != b[k]) return false;
+    return true;
+}
+// SharedIdPub::operator< (re_api.hip): keys lexicographic, then the count -- the order update_static_world_sections visits changed shared sections in
+__device__ __forceinline__ bool sh_id_less(const uint64_t *a, uint32_t na, const uint64_t *b, uint32_t nb) {
+    const uint32_t m = na < nb ? na : nb;
+    for (uint32_t i = 0; i < m; i++) if (a[i] != b[i]) return a[i] < b[i];
+    return na < nb;
+}
+// index of a shared section by id: -1 absent, -2 another id with the same placement key (the batch goes to the host path)
+__device__ __forceinline__ int32_t sh_lookup(const ShTable &S, uint64_t pkey, const uint64_t *keys, uint32_t nk) {
+    for (uint32_t h = rb_hash(pkey) & S.hmask;; h = (h + 1u) & S.hmask) {
+        const unsigned long long k = S.hkeys[h];
+        if (k == ~0ull) return -1;
+        if (k == pkey) {
+            const uint32_t idx = S.hidx[h];
+            if (idx == 0xFFFFFFFFu) return -1;                              // retired
+            return sh_same_id(S.keys + (size_t)idx * 8, S.nk[idx], keys, nk) ? (int32_t)idx : -2;
+        }
+    }
+}
+__device__ __forceinline__ void sh_hash_put(const ShTable &S, uint64_t pkey, uint32_t idx) {
+    for (uint32_t h = rb_hash(pkey) & S.hmask;; h = (h + 1u) & S.hmask) {
+        const unsigned long long prev = atomicCAS(&S.hkeys[h], ~0ull, (unsigned long long)pkey);
+        if (prev == ~0ull || prev == pkey) { S.hidx[h] = idx; return; }
+    }
+}
+__global__ __launch_bounds__(256) void k_rb2_hash_insert(uint32_t n, ShTable S) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n || !S.nk[s]) return;
+    sh_hash_put(S, sh_id_pkey(S.keys + (size_t)s * 8, S.nk[s]), s);
+}
+
+// ---- phase 1: two ops per mover --------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic,
+                                                 uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_key2, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
+                                                 uint32_t *__restrict__ op_idx, uint64_t *__restrict__ mk, uint8_t *__restrict__ mnk, uint32_t *__restrict__ host_list, Rb2Status *st) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t w = movers[i], r = w & 0x7FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
+    Aabb bv = R.aabb[r];
+    normalize_aabb(&bv, (float)outline);
+    uint64_t keys[8];
+    const int nk = assign_sections(bv, atomic, keys);                      // add_entity with add_if_out_bounds = true: the box is clamped
+    if (rc == ROW_CELL_NONE || (fl & F_DEAD) || nk < 1) st->fallback = 1u;  // (not a mover the tick can have listed)
+    const bool host = (fl & F_STATIC) || rc == ROW_CELL_NONE || nk < 1;     // static rows (an always-execute entity of a static set) keep the host path: their removal touches the changed-static set
+    if (host) host_list[atomicAdd(&st->n_host, 1u)] = w;
+    uint64_t pold = ~0ull, pnew = ~0ull;
+    if (!host) {
+        if (rc & ROW_CELL_SHARED) { const uint32_t s = rc & ~ROW_CELL_SHARED; pold = s < S.cap ? sh_id_pkey(S.keys + (size_t)s * 8, S.nk[s]) : ~0ull; if (s >= S.cap || !S.nk[s]) st->fallback = 1u; }
+        else pold = C.cell_key[rc];
+        pnew = nk == 1 ? keys[0] : sh_id_pkey(keys, (uint32_t)nk);
+    }
+    for (int k = 0; k < 8; k++) mk[(size_t)i * 8 + k] = k < nk ? keys[k] : 0ull;
+    mnk[i] = (uint8_t)(nk < 0 ? 0 : nk);
+    const uint64_t ord = ((uint64_t)((w >> 31) ? 0u : 1u) << 33) | ((uint64_t)R.id[r] << 1);   // translation-only movers first, then ascending EntityId; remove before add
+    op_key[2 * i] = pold; op_ord[2 * i] = ord; op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
+    op_key[2 * i + 1] = pnew; op_ord[2 * i + 1] = ord | 1ull; op_row[2 * i + 1] = r; op_idx[2 * i + 1] = 2 * i + 1;
+    // the second sort (unique placements + the link ops of the shared ones) leaves the shared placements' member ops behind every section
+    op_key2[2 * i] = (pold & RB2_SHARED_BIT) ? ~0ull : pold;
+    op_key2[2 * i + 1] = (pnew & RB2_SHARED_BIT) ? ~0ull : pnew;
+}
+
+// ---- phase 2: the shared placements.  One thread per placement (segment head of the first sort) replays remove_entity / add_entity on the shared section's
+// counts (re_api.hip: rebucket, `replay`); every creation / emptying on the way becomes link ops for the sections it links ------------------------------------
+__global__ __launch_bounds__(256) void k_rb2_shared_segments(uint32_t n, uint32_t m, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
+                                                             uint64_t *__restrict__ op_ord, const uint64_t *__restrict__ mk, const uint8_t *__restrict__ mnk, ShTable S, RbCells C,
+                                                             uint64_t *__restrict__ op_key2, uint32_t *__restrict__ op_row_w, uint32_t *__restrict__ op_idx, uint32_t link_cap,
+                                                             Rb2ShSeg *__restrict__ segs, Rb2Status *st) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t pkey = key_sorted[t];
+    if (!(pkey & RB2_SHARED_BIT) || pkey == ~0ull) return;                 // unique placements: phase 3; ~0: the movers left to the host path
+    if (t > 0 && key_sorted[t - 1] == pkey) return;                         // segment heads only
+    uint32_t e = t + 1u; while (e < n && key_sorted[e] == pkey) e++;
+    // the id of the placement, from its first op: the section a leaving row is still registered in, or the new keys of an arriving one
+    Rb2ShSeg G{}; G.pkey = pkey; G.op_begin = t; G.op_count = e - t;
+    {
+        const uint32_t o = perm[t], w = op_row[o];
+        if (w & RB_REMOVE) { const uint32_t s = C.row_cell[w & 0x7FFFFFFFu] & ~ROW_CELL_SHARED; G.nk = S.nk[s]; for (uint32_t k = 0; k < 8; k++) G.keys[k] = k < G.nk ? S.keys[(size_t)s * 8 + k] : 0ull; }
+        else { const uint32_t i = o >> 1; G.nk = mnk[i]; for (uint32_t k = 0; k < 8; k++) G.keys[k] = mk[(size_t)i * 8 + k]; }
+    }
+    const int32_t idx0 = sh_lookup(S, pkey, G.keys, G.nk);
+    if (idx0 == -2) { st->fallback = 1u; return; }
+    G.idx = idx0; G.exists0 = idx0 >= 0;
+    uint32_t na = G.exists0 ? S.nact[idx0] : 0u, nst = G.exists0 ? S.nstat[idx0] : 0u;
+    bool exists = G.exists0, relink = false;
+    for (uint32_t q = t; q < e; q++) {
+        const uint32_t o = perm[q], w = op_row[o];
+        const uint64_t ord = op_ord[o];
+        int dir = 0;
+        if (w & RB_REMOVE) {
+            const uint32_t s = C.row_cell[w & 0x7FFFFFFFu] & ~ROW_CELL_SHARED;
+            if (!sh_same_id(S.keys + (size_t)s * 8, S.nk[s], G.keys, G.nk)) { st->fallback = 1u; return; }      // two ids, one placement key
+            if (na) na--;
+            if (exists && na == 0 && nst == 0) { exists = false; dir = -1; }
+        } else {
+            const uint32_t i = o >> 1;
+            if (!sh_same_id(mk + (size_t)i * 8, mnk[i], G.keys, G.nk)) { st->fallback = 1u; return; }
+            if (!exists) { exists = true; na = 0; nst = 0; dir = 1; relink = true; }
+            na++;
+        }
+        if (dir) {                                                          // the shared section appears / disappears: its linked sections gain / lose a link, at this point of the sequence
+            const uint32_t at = atomicAdd(&st->n_link, G.nk);
+            if (at + G.nk > link_cap) { st->fallback = 1u; return; }
+            for (uint32_t k = 0; k < G.nk; k++) {
+                const uint32_t j = 2u * m + at + k;
+                op_key2[j] = G.keys[k]; op_ord[j] = ord; op_row_w[j] = dir > 0 ? RB2_LINK_INC : RB2_LINK_DEC; op_idx[j] = j;
+            }
+        }
+    }
+    G.na1 = na; G.nst = nst; G.exists1 = exists; G.relink = relink;
+    segs[atomicAdd(&st->nseg_s, 1u)] = G;
+    if (exists) {
+        const uint32_t size = na + nst;
+        if (idx0 < 0) atomicAdd(&st->need_sh, 1u);
+        if (idx0 < 0 || size > S.rowcap[idx0]) { const uint32_t cap = size * 2u > 4u ? size * 2u : 4u; atomicAdd(&st->need_pool, cap); }
+    }
+}
+
+// ---- phase 3: the unique placements, member ops and link ops merged by the reference's order -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rb2_unique_segments(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
+                                                             RbTables T, RbCells C, uint8_t *__restrict__ cell_links, Rb2Seg *__restrict__ segs, Rb2Status *st) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t key = key_sorted[t];
+    if (key == ~0ull) return;
+    if (t > 0 && key_sorted[t - 1] == key) return;                           // segment heads only
+    uint32_t e = t + 1u; while (e < n && key_sorted[e] == key) e++;
+    const int32_t slot = rb_find(T, C.cell_key, key);
+    const bool exists0 = slot >= 0;
+    uint32_t nl = exists0 ? C.cell_nl[slot] : 0u, ns = exists0 ? C.cell_ns[slot] : 0u, links = exists0 ? cell_links[slot] : 0u, total = 0;
+    if (links >= 255u) st->fallback = 1u;                                    // (a saturated link count: the host path counts exactly)
+    bool exists = exists0, changed = false;
+    for (uint32_t q = t; q < e; q++) {
+        const uint32_t w = op_row[perm[q]];
+        if (w == RB2_LINK_INC) { if (!exists) { nl = 0; ns = 0; links = 0; exists = true; } links++; }
+        else if (w == RB2_LINK_DEC) { if (links) links--; if (nl == 0 && ns == 0 && links == 0) exists = false; }
+        else if (w & RB_REMOVE) {
+            if (nl) nl--;
+            if (nl == 0 && ns == 0 && links == 0) exists = false; else total += changed ? 1u : nl + ns;
+            changed = true;
+        } else {
+            if (exists) { nl++; total += changed ? 1u : nl + ns; }
+            else { nl = 1u; ns = 0u; links = 0u; exists = true; total += 1u; }
+            changed = true;
+        }
+    }
+    Rb2Seg S{}; S.key = key; S.slot = slot; S.op_begin = t; S.op_count = e - t; S.nl1 = nl; S.ns = ns; S.links1 = links; S.exists0 = exists0; S.exists1 = exists; S.changed = changed;
+    segs[atomicAdd(&st->nseg_u, 1u)] = S;
+    if (total) atomicAdd(&st->total, total);
+    if (links > 254u) st->fallback = 1u;
+    if (exists) {
+        const uint32_t size = nl + ns;
+        if (slot < 0) atomicAdd(&st->need_slots[key_level(key) & (MAX_LEVELS - 1)], 1u);
+        if (changed && (slot < 0 || size > C.cell_cap[slot])) { const uint32_t cap = size * 2u > 4u ? size * 2u : 4u; atomicAdd(&st->need_pool, cap); }
+    }
+}
+
+// members of one placement rewritten in place: the active rows that stay (compacted), the arrivals merged in ascending EntityId from the back, the static
+// rows behind them; relocated to the end of the pool when the segment outgrew its capacity (the host checked the room).  Returns the new active count.
+__device__ __forceinline__ uint32_t rb2_rewrite_members(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, uint32_t op_begin, uint32_t op_count, const RbCells &C, const RowArrays &R,
+                                                        uint32_t *begin_io, uint32_t *cap_io, uint32_t na0, uint32_t nst, uint32_t *__restrict__ tmp_row, Rb2Status *st, uint32_t place_word) {
+    uint32_t begin = *begin_io, cap = *cap_io;
+    uint32_t a = 0;                                                           // the rows that arrive, in ascending EntityId (insertion sort into this placement's share of the scratch array)
+    for (uint32_t q = op_begin; q < op_begin + op_count; q++) {
+        const uint32_t w = op_row[perm[q]];
+        if ((w & RB_REMOVE) || w == RB2_LINK_INC || w == RB2_LINK_DEC) continue;
+        const uint32_t id = R.id[w];
+        uint32_t k = a;
+        while (k > 0 && R.id[tmp_row[op_begin + k - 1u]] > id) { tmp_row[op_begin + k] = tmp_row[op_begin + k - 1u]; k--; }
+        tmp_row[op_begin + k] = w; a++;
+    }
+    auto leaves = [&](uint32_t r) { for (uint32_t q = op_begin; q < op_begin + op_count; q++) if (op_row[perm[q]] == (r | RB_REMOVE)) return true; return false; };
+    uint32_t kept = 0; for (uint32_t i = 0; i < na0; i++) if (!leaves(C.rows[begin + i])) kept++;
+    const uint32_t na1 = kept + a, size = na1 + nst;
+    if (size > cap) {
+        const uint32_t ncap = size * 2u > 4u ? size * 2u : 4u, nb = atomicAdd(&st->pool_used, ncap);
+        if ((uint64_t)nb + ncap > C.pool_cap) { st->err = 1u; return na0; }      // (cannot happen: the host checked need_pool)
+        for (uint32_t i = 0; i < na0 + nst; i++) { C.rows[nb + i] = C.rows[begin + i]; C.rows_gc[nb + i] = C.rows_gc[begin + i]; }
+        begin = nb; cap = ncap;
+    }
+    uint32_t mm = 0;
+    for (uint32_t i = 0; i < na0; i++) { const uint32_t r = C.rows[begin + i]; if (!leaves(r)) { C.rows[begin + mm] = r; C.rows_gc[begin + mm] = C.rows_gc[begin + i]; mm++; } }
+    if (na1 > na0) for (uint32_t i = nst; i-- > 0;) { C.rows[begin + na1 + i] = C.rows[begin + na0 + i]; C.rows_gc[begin + na1 + i] = C.rows_gc[begin + na0 + i]; }
+    else if (na1 < na0) for (uint32_t i = 0; i < nst; i++) { C.rows[begin + na1 + i] = C.rows[begin + na0 + i]; C.rows_gc[begin + na1 + i] = C.rows_gc[begin + na0 + i]; }
+    for (int32_t i = (int32_t)mm - 1, j = (int32_t)a - 1, k = (int32_t)na1 - 1; j >= 0; k--) {
+        if (i >= 0 && R.id[C.rows[begin + i]] > R.id[tmp_row[op_begin + j]]) { C.rows[begin + k] = C.rows[begin + i]; C.rows_gc[begin + k] = C.rows_gc[begin + i]; i--; }
+        else { const uint32_t r = tmp_row[op_begin + j]; C.rows[begin + k] = r; C.rows_gc[begin + k] = R.gclass[r]; C.row_cell[r] = place_word; j--; }
+    }
+    *begin_io = begin; *cap_io = cap;
+    return na1;
+}
+
+// ---- phase 4a: the unique sections ----------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rb2_apply_unique(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, uint8_t *__restrict__ cell_links,
+                                                         Rb2Seg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_slots, const uint32_t *__restrict__ free_off,
+                                                         uint32_t *__restrict__ tmp_row, uint32_t *__restrict__ refold) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= st->nseg_u) return;
+    Rb2Seg S = segs[s];
+    const uint32_t lv = key_level(S.key) & (MAX_LEVELS - 1);
+    refold[s] = 0xFFFFFFFFu;
+    if (!S.exists1) {
+        if (S.slot >= 0) {                                                    // no member and no link left: a padding slot from now on
+            const uint32_t sl = (uint32_t)S.slot;
+            C.cell_key[sl] = pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu); C.cell_key32[sl] = KEY32_PAD | 0x1FF7FDFFu;
+            C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = (uint8_t)(CF_PAD | CF_STATIC_SECTION); cell_links[sl] = 0;
+            S.freed = 1; atomicAdd(&st->n_freed, 1u); segs[s] = S;
+        }
+        return;
+    }
+    uint32_t sl;
+    if (S.slot < 0) {
+        sl = free_slots[free_off[lv] + atomicAdd(&st->popped[lv], 1u)];
+        S.slot = (int32_t)sl; S.created = 1; atomicAdd(&st->n_created, 1u);
+        C.cell_key[sl] = S.key; C.cell_key32[sl] = (key_x(S.key) << 20) | (key_z(S.key) << 10) | key_y(S.key);
+        C.cell_stamp[sl] = 0; C.cell_cap[sl] = 0; C.cell_begin[sl] = 0; C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = 0;
+        rb_ovl_put(T, S.key, sl);
+    } else sl = (uint32_t)S.slot;
+    cell_links[sl] = (uint8_t)(S.links1 > 255u ? 255u : S.links1);
+    if (S.changed) {
+        uint32_t begin = C.cell_begin[sl], cap = C.cell_cap[sl];
+        const uint32_t nl1 = rb2_rewrite_members(perm, op_row, S.op_begin, S.op_count, C, R, &begin, &cap, C.cell_nl[sl], C.cell_ns[sl], tmp_row, st, sl);
+        C.cell_begin[sl] = begin; C.cell_cap[sl] = cap; C.cell_nl[sl] = nl1;
+        // (the rows that arrived: the key of their own section, streamed by the tick)
+        for (uint32_t q = S.op_begin; q < S.op_begin + S.op_count; q++) { const uint32_t w = op_row[perm[q]]; if (!(w & RB_REMOVE) && w != RB2_LINK_INC && w != RB2_LINK_DEC) C.row_key[w] = S.key; }
+        S.nl1 = nl1;
+    }
+    segs[s] = S;
+    if (S.changed || S.created) refold[s] = sl;                              // end_of_changes / update_static_world_sections touch the changed (and the new) sections
+}
+
+// ---- phase 4b: the shared sections (stable indices: a retired entry is a hole, a new one takes a free index the host handed over) ---------------------------
+__global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, ShTable S,
+                                                         Rb2ShSeg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_sh, uint32_t *__restrict__ tmp_row) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= st->nseg_s) return;
+    Rb2ShSeg G = segs[s];
+    if (!G.exists1) {
+        if (G.idx >= 0) {
+            const uint32_t idx = (uint32_t)G.idx;
+            for (uint32_t h = rb_hash(G.pkey) & S.hmask;; h = (h + 1u) & S.hmask) { const unsigned long long k = S.hkeys[h]; if (k == ~0ull) break; if (k == G.pkey) { S.hidx[h] = 0xFFFFFFFFu; break; } }
+            S.nact[idx] = 0; S.nstat[idx] = 0; S.nk[idx] = 0; S.owner[idx] = -1; S.cached[idx] = 0; S.dirty[idx] = 0;
+            for (uint32_t k = 0; k < 8; k++) { S.cells[(size_t)idx * 8 + k] = -1; S.keys[(size_t)idx * 8 + k] = 0ull; }
+            G.freed = 1; atomicAdd(&st->n_sh_freed, 1u); segs[s] = G;
+        }
+        return;
+    }
+    uint32_t idx;
+    if (G.idx < 0) {
+        idx = free_sh[atomicAdd(&st->popped_sh, 1u)];
+        G.idx = (int32_t)idx; G.created = 1; atomicAdd(&st->n_sh_created, 1u);
+        S.nk[idx] = (uint8_t)G.nk; for (uint32_t k = 0; k < 8; k++) S.keys[(size_t)idx * 8 + k] = G.keys[k];
+        S.begin[idx] = 0; S.rowcap[idx] = 0; S.nact[idx] = 0; S.nstat[idx] = 0; S.owner[idx] = -1; S.cached[idx] = 0; S.dirty[idx] = 0;
+        sh_hash_put(S, G.pkey, idx);
+    } else idx = (uint32_t)G.idx;
+    if (G.relink || G.created)                                               // (a section emptied and refilled within the batch may find a linked section in another slot)
+        for (uint32_t k = 0; k < 8; k++) { int32_t c = -1; if (k < G.nk) { c = rb_find(T, C.cell_key, G.keys[k]); if (c < 0) st->err = 2u; } S.cells[(size_t)idx * 8 + k] = c; }
+    uint32_t begin = S.begin[idx], cap = S.rowcap[idx];
+    const uint32_t na1 = rb2_rewrite_members(perm, op_row, G.op_begin, G.op_count, C, R, &begin, &cap, S.nact[idx], S.nstat[idx], tmp_row, st, ROW_CELL_SHARED | idx);
+    S.begin[idx] = begin; S.rowcap[idx] = cap; S.nact[idx] = na1;
+    const uint32_t nm = na1 + S.nstat[idx];                                   // end_of_changes, shared branch (:1104-1125): the AABB of the last entity iterated (entities, then static_entities)
+    Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    if (nm) u = R.aabb[C.rows[begin + nm - 1u]];
+    S.aabb[idx] = u;
+    G.na1 = na1; segs[s] = G;
+}
+
+// ---- phase 4c: update_static_world_sections (bounding_box_tree_v2.rs:1133-1213) --------------------------------------------------------------------------
+// which sections a shared section WITHOUT active entities links (first loop: an empty section is a static section when nothing links it, or when one of
+// the shared sections linking it has no active entity)
+__global__ __launch_bounds__(256) void k_rb2_mark_inactive(uint32_t nsh, ShTable S, uint8_t *__restrict__ cell_inact) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nsh || !S.nk[s] || S.nact[s] != 0u) return;
+    for (uint32_t k = 0; k < 8; k++) { const int32_t c = S.cells[(size_t)s * 8 + k]; if (c >= 0) cell_inact[c] = 1; }
+}
+__global__ __launch_bounds__(256) void k_rb2_static_first(RbCells C, const uint8_t *__restrict__ cell_links, const uint8_t *__restrict__ cell_inact, const Rb2Seg *__restrict__ segs, const Rb2Status *st) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= st->nseg_u) return;
+    const Rb2Seg S = segs[s];
+    if (!S.exists1 || S.slot < 0 || !(S.changed || S.created)) return;
+    const uint32_t sl = (uint32_t)S.slot;
+    const bool stat = C.cell_nl[sl] == 0u && (cell_links[sl] == 0u || cell_inact[sl] != 0u);
+    C.cell_flags[sl] = (uint8_t)((C.cell_flags[sl] & ~CF_STATIC_SECTION) | (stat ? CF_STATIC_SECTION : 0));
+}
+// second loop: the changed shared sections in canonical id order; for each linked section: no active entity -> a static section if it holds no active
+// entity itself, else not a static section.  (slot, shared segment) pairs sorted by slot; one thread folds a slot's rules in that order: with active
+// entities of its own only "not static" can apply (any rule with active entities), without them the LAST rule decides.
+__global__ __launch_bounds__(256) void k_rb2_static_pairs(const Rb2ShSeg *__restrict__ segs, const Rb2Status *st, ShTable S, uint64_t *__restrict__ pair_key, uint32_t *__restrict__ pair_seg, Rb2Status *stw) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= st->nseg_s) return;
+    const Rb2ShSeg G = segs[s];
+    if (!G.exists1 || G.idx < 0) return;
+    const uint32_t at = atomicAdd(&stw->n_pairs, G.nk);
+    for (uint32_t k = 0; k < G.nk; k++) { pair_key[at + k] = (uint64_t)(uint32_t)S.cells[(size_t)G.idx * 8 + k]; pair_seg[at + k] = s; }
+}
+__global__ __launch_bounds__(256) void k_rb2_static_second(uint32_t n, const uint64_t *__restrict__ slot_sorted, const uint32_t *__restrict__ seg_sorted, const Rb2ShSeg *__restrict__ segs, RbCells C) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t sl64 = slot_sorted[t];
+    if (t > 0 && slot_sorted[t - 1] == sl64) return;
+    if (sl64 >= 0x80000000ull) return;                                       // (a link that could not be resolved: reported by the apply kernel)
+    const uint32_t sl = (uint32_t)sl64;
+    bool any_active = false; uint32_t last = seg_sorted[t];
+    for (uint32_t q = t; q < n && slot_sorted[q] == sl64; q++) {
+        const Rb2ShSeg &G = segs[seg_sorted[q]];
+        if (G.na1 != 0u) any_active = true;
+        const Rb2ShSeg &L = segs[last];
+        if (sh_id_less(L.keys, L.nk, G.keys, G.nk)) last = seg_sorted[q];
+    }
+    uint8_t f = C.cell_flags[sl];
+    if (C.cell_nl[sl] != 0u) { if (any_active) f &= (uint8_t)~CF_STATIC_SECTION; }
+    else f = (uint8_t)((f & ~CF_STATIC_SECTION) | (segs[last].na1 == 0u ? CF_STATIC_SECTION : 0));
+    C.cell_flags[sl] = f;
+}
+
+// ---- host mirrors on demand: the state of the shared entries the device changed (re_api.hip: sync_mirrors) ----------------------------------------------------
+__global__ __launch_bounds__(256) void k_rb2_gather_shared(uint32_t n, const uint32_t *__restrict__ idxs, ShTable S, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_hdr, int32_t *__restrict__ out_cells) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = idxs[i];
+    for (uint32_t k = 0; k < 8; k++) { out_keys[(size_t)i * 8 + k] = S.keys[(size_t)s * 8 + k]; out_cells[(size_t)i * 8 + k] = S.cells[(size_t)s * 8 + k]; }
+    out_hdr[i * 5 + 0] = S.begin[s]; out_hdr[i * 5 + 1] = S.rowcap[s]; out_hdr[i * 5 + 2] = S.nact[s]; out_hdr[i * 5 + 3] = S.nstat[s]; out_hdr[i * 5 + 4] = S.nk[s];
+}
+__global__ __launch_bounds__(256) void k_rb2_gather_shared_rows(uint32_t n, const uint32_t *__restrict__ idxs, const uint32_t *__restrict__ offs, ShTable S, const uint32_t *__restrict__ rows, uint32_t *__restrict__ out_rows) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = idxs[i], b = S.begin[s], cnt = offs[i + 1] - offs[i];
+    for (uint32_t k = 0; k < cnt; k++) out_rows[offs[i] + k] = rows[b + k];
+}
+__global__ __launch_bounds__(256) void k_rb2_gather_links(uint32_t n, const uint32_t *__restrict__ slots, const uint8_t *__restrict__ cell_links, uint8_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cell_links[slots[i]];
+}
+
+}  // namespace re

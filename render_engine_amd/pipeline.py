@@ -475,6 +475,19 @@ class Pipeline:
         self._check(self._L.re_debug_get_sections(self._h, n, keys.ctypes.data, tight.ctypes.data, nl.ctypes.data, ns.ctypes.data, st.ctypes.data, C.byref(cnt)), "re_debug_get_sections")
         return dict(keys=keys, tight=tight, n_local=nl, n_static=ns, is_static_section=st)
 
+    def shared_sections(self):
+        """the shared world sections in canonical id order: [dict(keys, aabb, active, static)] (EntityIds)"""
+        n = self.stats()["n_shared_sections"]; cap = max(n, 1); mcap = max(self.stats()["n_entities"], 1)
+        keys = np.zeros((cap, 8), np.uint64); nk = np.zeros(cap, np.uint8); box = np.zeros((cap, 6), np.float32); na = np.zeros(cap, np.uint32); ns = np.zeros(cap, np.uint32)
+        ids = np.zeros(mcap, np.uint32); offs = np.zeros(cap + 1, np.uint32); cnt = C.c_uint32()
+        self._check(self._L.re_debug_get_shared_sections(self._h, cap, keys.ctypes.data, nk.ctypes.data, box.ctypes.data, na.ctypes.data, ns.ctypes.data, mcap, ids.ctypes.data,
+                                                         offs.ctypes.data, C.byref(cnt)), "re_debug_get_shared_sections")
+        out = []
+        for i in range(min(cnt.value, cap)):
+            o = int(offs[i])
+            out.append(dict(keys=[int(k) for k in keys[i, :nk[i]]], aabb=tuple(float(v) for v in box[i]), active=ids[o:o + int(na[i])].copy(), static=ids[o + int(na[i]):o + int(na[i]) + int(ns[i])].copy()))
+        return out
+
     def visible_sections(self):
         n = self.stats()["n_sections"]
         keys = np.zeros(n, np.uint64); mult = np.zeros(n, np.uint8); cnt = C.c_uint32()

@@ -40,6 +40,12 @@ def check_sections(p, w):
     np.testing.assert_array_equal(s["is_static_section"] != 0, c["is_static_section"] != 0)
     tight = np.stack([c["tight"][k] for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")], axis=1)
     np.testing.assert_array_equal(s["tight"], tight)
+    gs, cs = p.shared_sections(), w.shared_sections()                  # shared world sections: ids, AABB of the last member, members (re_debug_get_shared_sections also
+    assert [g["keys"] for g in gs] == [o["keys"] for o in cs]          # checks the library's host mirrors against its device table)
+    for g, o in zip(gs, cs):
+        np.testing.assert_array_equal(g["active"], np.sort(o["active"]), err_msg=f"active members of shared section {o['keys']}")
+        np.testing.assert_array_equal(g["static"], np.sort(o["static"]), err_msg=f"static members of shared section {o['keys']}")
+        assert g["aabb"] == tuple(np.float32(v) for v in o["aabb"]), (o["keys"], g["aabb"], o["aabb"])
 
 
 def check_frame(R, p, w, cam, dups, force_large_pack=False):
@@ -889,11 +895,12 @@ def hopping_world(R, dims=(14, 14, 14), first=121, atomic=64, every=2):
 
 @pytest.mark.parametrize("straddlers", [False, True])
 def test_rebucket_on_the_device(R, straddlers):
-    """batches of movers between unique world sections: the bookkeeping runs on the device (k_rb_*), the host only notes which sections changed.
-    Sections are emptied (-> padding slots), created (free slots of the level run), outgrow their segment (relocated); the host mirrors are
+    """batches of movers between world sections: the bookkeeping runs on the device (re_rebucket.hip: k_rb2_*), the host only notes which sections
+    changed.  Sections are emptied (-> padding slots), created (free slots of the level run), outgrow their segment (relocated); the host mirrors are
     fetched on demand (a change-request batch, the debug getters) and the device path resumes afterwards.
-    straddlers: some movers are wider than a world section (shared sections, higher levels): every batch is split -- the device takes the movers
-    between unique, unlinked sections, the host path the rest as a second batch -- and must still equal the reference's single pass"""
+    straddlers: some movers are wider than a world section (shared sections, higher levels): shared sections are created, emptied and re-created,
+    the unique sections they link gain and lose links (and with the last one their existence), in the order of the reference's single pass -- on the
+    device too: no part of a tick's batch is left to the host"""
     ents = hopping_world(R)
     if straddlers:
         mv = np.nonzero((ents["flags"] & R.F_HAS_VEL) != 0)[0][::23]
@@ -911,6 +918,7 @@ def test_rebucket_on_the_device(R, straddlers):
         t = p.tick(1.0)
         assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o) == 0, (f, t, n_o)
         moved += t["n_rebucket"]
+        if f < 3: assert p.stats()["n_host_rebuckets"] == 0 and p.stats()["n_device_rebuckets"] == f + 1, p.stats()      # shared sections included
         if f % 2 == 1:                                           # looks at the table: host mirrors fetched from the device
             check_sections(p, w)
         if f == 3:                                               # a host-path batch in between (overlay and capacities change on the host)
@@ -922,7 +930,7 @@ def test_rebucket_on_the_device(R, straddlers):
             assert g["n_changed"] == n_a
             check_sections(p, w)
     st = p.stats()
-    assert moved > 2000 and st["n_device_rebuckets"] >= (4 if straddlers else 5) and st["n_table_rebuilds"] <= 1, (moved, st)      # (the small lattice has few spare slots per level: one batch may find no room and rebuild)
+    assert moved > 2000 and st["n_device_rebuckets"] >= 5 and st["n_table_rebuilds"] <= 1, (moved, st)      # (the small lattice has few spare slots per level: one batch may find no room and rebuild)
     check_sections(p, w)
     check_entities(R, p, w, ents[::7])
     check_frame(R, p, w, cams[0], False)

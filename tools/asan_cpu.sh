@@ -10,7 +10,7 @@ ASAN_LIB=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.s
 C=$ROOT/render_engine_amd/csrc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -fgpu-rdc -Wno-unused-result -mllvm -amdgpu-kernarg-preload-count=14 \
     -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -shared-libsan -I "$ROOT/include" -I "$C" \
-    "$C/re_kernels.hip" "$C/re_api.hip" "$C/re_lighting.hip" "$C/re_collide.hip" "$C/re_sort.hip" "$C/re_history.cpp" -o "$OUT/librender_engine_hip_asan.so"
+    "$C/re_kernels.hip" "$C/re_rebucket.hip" "$C/re_api.hip" "$C/re_lighting.hip" "$C/re_collide.hip" "$C/re_sort.hip" "$C/re_history.cpp" -o "$OUT/librender_engine_hip_asan.so"
 cd "$ROOT"
 # (test_no_exception_crosses_the_abi asks for a 2^62-byte vector to see the guard turn std::bad_alloc into a status code: ASan's allocator ends the process for
 # that request instead of returning, so the witness runs with the normal build only)
