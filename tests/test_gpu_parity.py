@@ -937,6 +937,39 @@ def test_rebucket_on_the_device(R, straddlers):
     p.close(); w.close()
 
 
+@pytest.mark.parametrize("seed,tight", [(5, False), (6, True), (7, False)])
+def test_device_rebucket_soak(R, seed, tight):
+    """40 ticks of a world whose movers drift across section borders (about half of the placement changes involve a shared section): batch after batch
+    on the device without the host looking at the table in between (holes of the shared table reused, retired ids looked up again, sections
+    that exist through links only), interleaved with asynchronous frames (cancelled and replayed) and -- tight: hardly any slack -- with batches that
+    find no room and fall back to the host path, which rebuilds the shared table compactly.  Compared with the oracle every 8 ticks and at the end."""
+    rng = np.random.default_rng(seed)
+    ents = R.synthetic.mixed_world(3000, seed=seed, spread=500.0)
+    mv = (ents["flags"] & R.F_HAS_VEL) != 0
+    ents["flags"][mv] &= ~np.uint32(R.F_STATIC)
+    ents["vel"] *= 6.0
+    p, w = build_pair(R, ents, flags=R._capi.CFG_TIGHT_SLACK if tight else 0)
+    for f in range(40):
+        cam = R.Camera((8192 + rng.uniform(-200, 200), 8192 + rng.uniform(-200, 200), 8800), (0, 0, -1), 2500.0)
+        oc = oracle_camera(cam)
+        if f % 4 == 3:
+            check_frame(R, p, w, cam, False)
+            n_o, oob_o = w.tick(oc, 0.05); t = p.tick(0.05)
+            assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+        else:
+            p.cull_and_pack(cam, asynchronous=True, copy=False); p.tick(0.05, asynchronous=True)
+            w.cull(oc); w.render(oc); w.tick(oc, 0.05)
+        if f % 8 == 7:
+            p.wait(); check_sections(p, w)
+    p.wait()
+    st = p.stats()
+    assert st["n_device_rebuckets"] >= (10 if tight else 30), st
+    check_sections(p, w)
+    check_entities(R, p, w, ents[::9])
+    check_frame(R, p, w, cam, True)
+    p.close(); w.close()
+
+
 @pytest.mark.parametrize("straddlers", [False, True])
 def test_async_frames_with_the_device_rebucket(R, straddlers):
     """frames enqueued without waiting while every tick moves entities between world sections: each such tick cancels the frames behind it, the
