@@ -346,6 +346,15 @@ def main():
             per = pipelined_frames(p, camc, 64, a.tick_all); per = pipelined_frames(p, camc, max(a.steps, 200), a.tick_all)
             out["pipelined"] = {"ms_per_frame": per * 1e3, "entities_per_s": n_total / per,
                                 "note": "asynchronous frames, no result read by the host per frame; static worlds defer each pack to the next launch and alternate two frame lanes (round 1's headline figure)"}
+            # opt-in variant (RE_CULL_ONE_LAUNCH): the scan's last workgroup publishes the frame itself -- one launch between the call and its answer.  Reported beside the default;
+            # its scan launch contains the publication chain, so its duration is not comparable with roofline.achieved above
+            F = R._capi
+            p.run_frames(camc, 64, 0.016, F.CULL_ONE_LAUNCH, F.TICK_ALL_DYNAMIC if a.tick_all else 0)
+            us1, _, _ = p.run_frames(camc, max(a.steps, 200), 0.016, F.CULL_ONE_LAUNCH, F.TICK_ALL_DYNAMIC if a.tick_all else 0)
+            p.wait(); p.timing_begin(64, 1, kernel="scan"); p.run_frames(camc, 64, 0.016, F.CULL_ONE_LAUNCH, F.TICK_ALL_DYNAMIC if a.tick_all else 0); k1 = p.timing_collect()
+            out["one_launch_sync"] = {"frame_ms_median": float(np.median(us1)) * 1e-3, "entities_per_s": n_total / (float(np.median(us1)) * 1e-6),
+                                      "scan_launch_us_incl_publication": float(np.mean(k1)) if len(k1) else None,
+                                      "note": "RE_CULL_ONE_LAUNCH: k_scan_cull_sync + k_pack_small(move only); opt-in, not the default (DESIGN.md section 4)"}
         if not a.no_cpu_baseline and world == 1:
             gpu_frame = p.cull_and_pack(camc, copy=True) if not a.spinner_every else None
             out["cpu_baseline"], out["cpu_optimised"], out["full_size_check"] = cpu_baseline(a, atomic, n_total, dims, first, gpu_frame)

@@ -128,6 +128,10 @@ typedef struct {
                                        * f + 2).  Needs a second copy of the per-frame buffers (~70 B per entity).  re_get_stream returns the stream of the
                                        * frame issued last. */
 #define RE_CULL_FORCE_STREAM    0x8u  /* with RE_CFG_PROBE: take the key stream for this frame anyway */
+#define RE_CULL_ONE_LAUNCH      0x40u /* opt-in, synchronous frames with a small visible set and at most 256 group slots: ONE launch between the call and its answer -- the
+                                      * scan's last workgroup to finish publishes the InstanceRange table and the counts itself (k_scan_cull_sync), the pack launch behind it only
+                                      * moves the instances.  About 1 us less per frame than the two dependent launches; the scan launch then contains the publication chain
+                                      * (DESIGN.md section 4), which is why it is not the default */
 #define RE_CULL_FORCE_LARGE_PACK 0x4u /* always use the multi-kernel pack (count/scan/scatter) instead of k_pack_small */
 
 /* One (ModelId, sortable) group of the packed buffer == ModelRenderingInformation.instance_location

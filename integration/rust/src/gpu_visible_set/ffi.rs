@@ -114,7 +114,7 @@ pub const RE_OK: c_int = 0;
 pub const RE_F_STATIC: u32 = 0x001; pub const RE_F_HAS_VEL: u32 = 0x002; pub const RE_F_HAS_ACC: u32 = 0x004; pub const RE_F_HAS_ROT: u32 = 0x008;
 pub const RE_F_HAS_ROTVEL: u32 = 0x010; pub const RE_F_HAS_ROTACC: u32 = 0x020; pub const RE_F_HAS_SCALE: u32 = 0x040; pub const RE_F_ALWAYS_EXEC: u32 = 0x080;
 pub const RE_F_OOB_LOGIC: u32 = 0x100; pub const RE_F_USER: u32 = 0x800; pub const RE_F_CAN_COLLIDE: u32 = 0x1000;
-pub const RE_CULL_EMIT_DUPLICATES: u32 = 0x1; pub const RE_CULL_ASYNC: u32 = 0x2; pub const RE_CULL_DEFER_PACK: u32 = 0x10; pub const RE_CULL_TWO_LANES: u32 = 0x20;
+pub const RE_CULL_EMIT_DUPLICATES: u32 = 0x1; pub const RE_CULL_ASYNC: u32 = 0x2; pub const RE_CULL_DEFER_PACK: u32 = 0x10; pub const RE_CULL_TWO_LANES: u32 = 0x20; pub const RE_CULL_ONE_LAUNCH: u32 = 0x40;
 pub const RE_CHANGE_MODIFY: u32 = 0; pub const RE_CHANGE_DELETE: u32 = 1; pub const RE_CHANGE_MAKE_STATIC: u32 = 2; pub const RE_CHANGE_WAKE_UP: u32 = 3;
 pub const RE_C_POSITION: u32 = 0; pub const RE_C_ROTATION: u32 = 1; pub const RE_C_SCALE: u32 = 2; pub const RE_C_VELOCITY: u32 = 3; pub const RE_C_ACCELERATION: u32 = 4;
 pub const RE_C_ROTATION_VEL: u32 = 5; pub const RE_C_ROTATION_ACC: u32 = 6;

@@ -12,7 +12,7 @@ F_OOB_LOGIC, F_HAS_MOVED, F_HAS_ROTATED, F_USER = 0x100, 0x200, 0x400, 0x800
 F_CAN_COLLIDE = 0x1000
 F_PHANTOM = 0x10000            # halo replica of an entity another shard owns: in the tree, never drawn or ticked
 F_LIGHT_DIRECTIONAL, F_LIGHT_POINT, F_LIGHT_SPOT = 0x2000, 0x4000, 0x8000      # FindLightType of the entity (light sets of its world section)
-CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK, CULL_FORCE_STREAM, CULL_DEFER_PACK, CULL_TWO_LANES = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+CULL_EMIT_DUPLICATES, CULL_ASYNC, CULL_FORCE_LARGE_PACK, CULL_FORCE_STREAM, CULL_DEFER_PACK, CULL_TWO_LANES, CULL_ONE_LAUNCH = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 TICK_ALL_DYNAMIC, TICK_ASYNC = 0x1, 0x2
 (C_POSITION, C_ROTATION, C_SCALE, C_VELOCITY, C_ACCELERATION, C_ROTATION_VEL, C_ROTATION_ACC,
  C_TRANSFORMATION, C_STATIC_AABB, C_ORIGINAL_AABB, C_FLAGS) = range(11)

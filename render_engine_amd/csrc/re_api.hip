@@ -1019,7 +1019,7 @@ static FrameHeader *frame_header(re_ctx *c, uint32_t frame) { return c->d_hdr.p 
 static ItemSink item_sink(re_ctx *c, uint32_t frame) {
     const size_t half = (size_t)(frame & 1u) * c->item_cap;
     ItemSink K; K.item_row = c->d_item_row.p + half; K.item_slot = c->d_item_slot.p + half; K.item_cap = c->item_cap; K.rows = c->d_rows.p; K.rows_gc = c->d_rows_gc.p;
-    K.nshards = c->single_shard ? 1u : CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0;
+    K.nshards = c->single_shard ? 1u : CURSOR_SHARDS; K.seg_cap = c->item_cap / K.nshards; K.group_count = nullptr; K.count_nslots = 0; K.slot_write_through = 0;
     K.gc_lodtab = c->lod_tables_on ? c->d_gc_lodtab.p : nullptr; K.lod_n = c->d_lod_n.p; K.lod_min = c->d_lod_min.p; K.lod_max = c->d_lod_max.p;
     return K;
 }
@@ -1313,7 +1313,17 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     const bool fuse = c->deferred_pack && !probed && c->deferred_grid < (1u << 20);
     if (c->deferred_pack && !fuse) { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     const size_t fused_lds = (size_t)std::max(c->nslots, 1u) * 8;
+    // a synchronous frame with a small visible set: the scan's last workgroup publishes the result itself (k_scan_cull_sync), the pack launch behind it only moves the instances
+    static const bool always_one = getenv("RE_EXP_ONE_LAUNCH_SYNC") != nullptr;       // (testing: every eligible synchronous frame of the process)
+    const bool one_launch = ((flags & RE_CULL_ONE_LAUNCH) || always_one) && small && !(flags & RE_CULL_ASYNC) && !probed && !fuse && !count_in_scan && c->nslots <= SYNC_TAIL_SLOTS;
+    if (one_launch) SA.K.slot_write_through = 1u;
     if (probed) {}
+    else if (one_launch && c->key32)
+        hipExtLaunchKernelGGL(k_scan_cull_sync<true>, dim3(scan_grid), dim3(CULL_THREADS), (size_t)std::max(c->nslots, 1u) * 4, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+                              SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, A);
+    else if (one_launch)
+        hipExtLaunchKernelGGL(k_scan_cull_sync<false>, dim3(scan_grid), dim3(CULL_THREADS), (size_t)std::max(c->nslots, 1u) * 4, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+                              SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, A);
     else if (fuse && c->key32)
         hipExtLaunchKernelGGL(k_scan_cull_fused<true>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n | (c->deferred_grid << 8),
                               SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
@@ -1342,7 +1352,8 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
             FusedPack F{}; F.hdr = hdr; F.hdr_next = hdr_next; F.th = c->d_th.p; F.A = A; F.K = item_sink(c, c->lane_seq); F.nrows = c->ghost_base + c->ghost_cap;
             c->deferred = F; c->deferred_grid = pgrid; c->deferred_pack = true;
         } else {
-            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, A, item_sink(c, c->lane_seq), c->ghost_base + c->ghost_cap);
+            PackArgs Am = A; if (one_launch) Am.flags |= PACK_NO_PUBLISH;
+            hipLaunchKernelGGL(k_pack_small, dim3(pgrid), dim3(256), (size_t)std::max(c->nslots, 1u) * 8, st, hdr, hdr_next, c->d_th.p, Am, item_sink(c, c->lane_seq), c->ghost_base + c->ghost_cap);
             c->last_pack.kind = 1; c->last_pack.hdr = hdr; c->last_pack.hdr_next = hdr_next; c->last_pack.A = A; c->last_pack.K = item_sink(c, c->lane_seq); c->last_pack.grid = pgrid; c->last_pack.nrows = c->ghost_base + c->ghost_cap;
         }
     } else {

@@ -125,6 +125,7 @@ struct ItemSink {
     const uint32_t *rows, *rows_gc;         // the row pool and, entry for entry, the row's group class (0xFFFFFFFF: not drawn -- removed or hidden)
     const uint32_t *gc_lodtab; const uint32_t *lod_n; const float *lod_min, *lod_max;   // per-model level-of-view bands (level_views.custom, render_flow.rs:889-893): band table of each
                                             // group class (0: the camera's default bands), tables of 8 bands each; nullptr while no model has custom bands
+    uint32_t slot_write_through;            // the one-launch synchronous frame (k_scan_cull_sync): the last workgroup of the SAME launch reads item_slot, so its stores go through to memory (sc1)
     uint32_t *group_count; uint32_t count_nslots;   // large visible sets: the expansion also counts the instances per (cursor shard, group slot) -- [nshards][count_nslots],
                                             // through a per-wave LDS histogram flushed once per wave -- so that the pack needs no counting pass (nullptr / 0: off)
 };
@@ -149,7 +150,10 @@ struct PackArgs {                           // what k_pack_small needs besides t
     const uint32_t *gc_model, *gc_rs, *gc_sort; InstanceRange *ranges; HostResult *hres; const SpecState *spec;
     uint32_t frame;                         // this frame's number (HostResult::done_frame)
     uint32_t *out_count;                    // optional device word: instances written to the output buffers (the all-gather slab header)
+    uint32_t flags;                         // PACK_NO_PUBLISH: the frame's result block has been published by the scan's own last workgroup (k_scan_cull_sync); this launch only moves the instances
 };
+constexpr uint32_t PACK_NO_PUBLISH = 1u;
+constexpr uint32_t SYNC_TAIL_SLOTS = 256;      // group slots the tail of k_scan_cull_sync takes (its histogram is dynamic LDS of every workgroup of the scan: 1 KB)
 struct ScanCullArgs {                       // the kernel-argument segment of k_scan_cull after its two leading scalars (the kernel addresses it explicitly)
     PBoxTable B; PBox32Table B32;           // read by every wave (one of the two); everything below by candidate waves only
     const uint64_t *cell_key64;             // the full keys (candidate waves; the stream may run over the compact 32-bit keys)
@@ -170,6 +174,12 @@ template <bool K32> __global__ void k_scan_cull(const void *keys, uint32_t ncell
 extern template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 extern template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows);
+// One launch between the call and the host's answer for a SYNCHRONOUS frame with a small visible set: the scan, whose last workgroup to finish publishes the
+// InstanceRange table and the counts (k_pack_small then only moves the instances, stream-ordered behind it, while the host is already back).
+template <bool K32> __global__ void k_scan_cull_sync(const void *keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
+                                                     uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A, PackArgs T);
+extern template __global__ void k_scan_cull_sync<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, PackArgs);
+extern template __global__ void k_scan_cull_sync<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, PackArgs);
 struct FusedPack { FrameHeader *hdr, *hdr_next; TickHeader *th; PackArgs A; ItemSink K; uint32_t nrows, pad; };   // the previous frame's pack, carried by the next frame's launch
 template <bool K32> __global__ void k_scan_cull_fused(const void *keys, uint32_t ncells, uint32_t nsp_npack, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
                                                       uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A, FusedPack F);

@@ -181,7 +181,9 @@ __device__ __forceinline__ void expand_rows(uint32_t rb, uint32_t cnt, uint32_t 
             uint32_t lod_e = lod;
             if (K.gc_lodtab && gc != 0xFFFFFFFFu) { const uint32_t tb = K.gc_lodtab[gc]; if (tb) lod_e = lod_index(dist, K.lod_n[tb], K.lod_min + tb * 8u, K.lod_max + tb * 8u); }   // level_views.custom
             const uint32_t slot = gc == 0xFFFFFFFFu ? 0xFFFFFFFFu : gc * 8u + lod_e;
-            K.item_row[seg_base + t] = row; K.item_slot[seg_base + t] = slot;
+            K.item_row[seg_base + t] = row;
+            if (K.slot_write_through) __hip_atomic_store(&K.item_slot[seg_base + t], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (wave-uniform: a kernel argument)
+            else K.item_slot[seg_base + t] = slot;
             if (K.group_count && slot < K.count_nslots) { if (hist) atomicAdd(&hist[slot], 1u); else atomicAdd(&K.group_count[shard * K.count_nslots + slot], 1u); }
         }
     }
@@ -1050,8 +1052,9 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     __shared__ uint32_t s_pos[64], s_row[64];
     uint32_t direct_hash = 0;                                 // hash of the table words this thread stores straight to the host (a table too large to stage)
     const uint32_t NT = 256, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const bool reporter = bid == 0 && !(A.flags & PACK_NO_PUBLISH);       // (k_scan_cull_sync: the scan's last workgroup has reported the frame already)
     if (A.spec->stale) {                                    // cancelled frame (SpecState): report it, touch nothing
-        if (bid == 0 && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
+        if (reporter && tid == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
         return;
     }
     const uint32_t nslots = A.nslots;
@@ -1073,7 +1076,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
     __shared__ InstanceRange s_rng[PACK_STAGED_GROUPS];
     const bool staged = nslots <= PACK_STAGED_GROUPS;         // at most nslots groups
     uint32_t fc_a = 0, fc_b = 0, fc_c = 0;
-    if (bid == 0 && wid == 0 && lane < COUNTER_SHARDS) { const uint32_t *cnt = hdr->counters + lane * 16u; fc_a = cnt[0]; fc_b = cnt[1]; fc_c = cnt[2]; }
+    if (reporter && wid == 0 && lane < COUNTER_SHARDS) { const uint32_t *cnt = hdr->counters + lane * 16u; fc_a = cnt[0]; fc_b = cnt[1]; fc_c = cnt[2]; }
     for (uint32_t i = tid; i < 2u * nslots && nslots <= LDS_HIST_SLOTS; i += NT) s_dyn[i] = 0;
     if (tid == 0) { s_carry = 0; s_gcarry = 0; }
     if (tid < 64u) s_row[tid] = my_row;
@@ -1120,7 +1123,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
             uint32_t gidx = s_gcarry + wcn + incn - nz;
             if (i < nslots) {
                 s_tot[i] = begin;
-                if (v && bid == 0) {
+                if (v && reporter) {
                     uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
                     if (staged) s_rng[gidx] = r;
                     else {
@@ -1144,7 +1147,7 @@ __device__ __forceinline__ void pack_small_body(const uint32_t bid, const uint32
             wait_own_stores();
         }
         __syncthreads();
-        if (wid == 0) {
+        if (wid == 0 && reporter) {
             for (int d = 32; d >= 1; d >>= 1) { fc_a += __shfl_xor(fc_a, d, 64); fc_b += __shfl_xor(fc_b, d, 64); fc_c += __shfl_xor(fc_c, d, 64); }
             FrameCounts fc; fc.n_candidates = fc_a; fc.n_vis_map = fc_b; fc.n_vis_vec = fc_c;
             uint32_t table_hash = 0;
@@ -1231,6 +1234,112 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull_fused(const void *__
 }
 template __global__ void k_scan_cull_fused<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
 template __global__ void k_scan_cull_fused<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, FusedPack);
+
+// ---------------------------------------------------------------------------------------------
+// One launch between a SYNCHRONOUS call and its answer (small visible sets).  A synchronous frame used to be two dependent launches -- the scan, then
+// k_pack_small, whose workgroup 0 publishes the result after its own chain of round trips -- and the host's wait spanned the gap between them.  Here every
+// workgroup of the scan signs off when its waves are done (their item_slot stores go through to memory: ItemSink::slot_write_through, and every wave has
+// waited for its own stores in front of the workgroup's barrier), on a ticket counter in the line of one of the 64 frame-counter shards; the workgroup that
+// completes a shard signs the top-level counter, and the one that completes that -- the last of the launch, nobody waits for anybody -- publishes the frame
+// with its first wave: cursors, frame counters and the first 256 group slots of every list segment in ONE round trip (agent-scope loads: everything it reads
+// was written by atomics or write-through stores of this same launch), the histogram in LDS, the InstanceRange table and the result block straight into
+// mapped host memory (publish_to_host).  k_pack_small follows on the stream with PACK_NO_PUBLISH and moves the instances while the host is already back.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t SYNC_TAIL_ARGS_OFFSET = SCAN_CULL_ARGS_OFFSET + (uint32_t)((sizeof(ScanCullArgs) + 7u) & ~(size_t)7u);
+__device__ __forceinline__ uint32_t load_agent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sync_frame_publish(FrameHeader *hdr, const ItemSink &K, const PackArgs &A) {          // ONE wave
+    extern __shared__ uint32_t s_dyn[];                       // [nslots]: instances per group slot
+    const uint32_t lane = lane_id();
+    if (A.spec->stale) {                                      // cancelled frame (SpecState)
+        if (lane == 0) { HostResult r = {}; r.overflow = 2u; *A.hres = r; cancel_slab_header(A.out_count, A.frame); publish_to_host(&A.hres->done_frame, A.frame); }
+        return;
+    }
+    const uint32_t nslots = A.nslots;
+    // ---- the one round trip: cursors (lane k), this lane's counter shard, 4 group slots per lane and segment
+    unsigned long long mycur = 0;
+    if (lane < CURSOR_SHARDS) mycur = __hip_atomic_load(&hdr->cursors[lane * CURSOR_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t *cnt = hdr->counters + (lane & (COUNTER_SHARDS - 1u)) * 16u;
+    uint32_t fc_a = load_agent(cnt + 0), fc_b = load_agent(cnt + 1), fc_c = load_agent(cnt + 2);
+    uint32_t sl[CURSOR_SHARDS][4];
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++)
+#pragma unroll
+        for (uint32_t q = 0; q < 4; q++) { const uint32_t j = q * 64u + lane; sl[k][q] = (k < K.nshards && j < K.seg_cap) ? load_agent(&K.item_slot[k * K.seg_cap + j]) : 0xFFFFFFFFu; }
+    for (uint32_t i = lane; i < nslots && nslots <= SYNC_TAIL_SLOTS; i += 64u) s_dyn[i] = 0u;
+    uint32_t n[CURSOR_SHARDS], raw_items = 0, raw_sec = 0, T = 0; bool seg_over = false;
+    const uint32_t cur_lo = (uint32_t)mycur, cur_hi = (uint32_t)(mycur >> 32);
+#pragma unroll
+    for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+        const uint32_t v = __shfl(cur_hi, (int)k, 64);
+        raw_sec += __shfl(cur_lo, (int)k, 64); raw_items += v; seg_over |= v > K.seg_cap;
+        n[k] = v < K.seg_cap ? v : K.seg_cap; T += n[k];
+    }
+    const bool overflow = seg_over || T > PACK_SMALL_ITEMS || nslots > SYNC_TAIL_SLOTS;
+    uint32_t table_hash = 0, carry = 0, gcarry = 0;
+    if (!overflow) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (uint32_t k = 0; k < CURSOR_SHARDS; k++) {
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) if (q * 64u + lane < n[k] && sl[k][q] < nslots) atomicAdd(&s_dyn[sl[k][q]], 1u);
+            for (uint32_t j = 256u + lane; j < n[k]; j += 64u) { const uint32_t s2 = load_agent(&K.item_slot[k * K.seg_cap + j]); if (s2 < nslots) atomicAdd(&s_dyn[s2], 1u); }   // segments longer than the speculative batch
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // exclusive scan of the group counts -> the InstanceRange table, every entry stored by the lane that holds it (this wave alone writes what the host reads)
+        for (uint32_t base = 0; base < nslots; base += 64u) {
+            const uint32_t i = base + lane, v = i < nslots ? s_dyn[i] : 0u, nz = v ? 1u : 0u;
+            const uint32_t incl = wave_incl_scan(v), incn = wave_incl_scan(nz);
+            const uint32_t begin = carry + incl - v, gidx = gcarry + incn - nz;
+            if (v) {
+                const uint32_t gc = i >> 3, lod = i & 7u; InstanceRange r; r.model_index = A.gc_model[gc] | (lod << 25); r.render_system = A.gc_rs[gc]; r.sortable = A.gc_sort[gc]; r.begin = begin; r.count = v;
+                A.ranges[gidx] = r;
+                const uint32_t w0 = gidx * (uint32_t)(sizeof(InstanceRange) / 4u);
+                table_hash ^= table_word_hash(r.model_index, w0) ^ table_word_hash(r.render_system, w0 + 1u) ^ table_word_hash(r.sortable, w0 + 2u) ^ table_word_hash(r.begin, w0 + 3u) ^ table_word_hash(r.count, w0 + 4u);
+            }
+            carry += __shfl(incl, 63, 64); gcarry += __shfl(incn, 63, 64);
+        }
+        for (int d = 32; d >= 1; d >>= 1) table_hash ^= __shfl_xor(table_hash, d, 64);
+        table_hash |= 1u;
+    }
+    for (int d = 32; d >= 1; d >>= 1) { fc_a += __shfl_xor(fc_a, d, 64); fc_b += __shfl_xor(fc_b, d, 64); fc_c += __shfl_xor(fc_c, d, 64); }
+    wait_own_stores();                                        // the whole wave: every lane's table words have left before lane 0 publishes
+    if (lane == 0) {
+        HostResult r = {}; r.n_vis_map = fc_b; r.n_vis_vec = fc_c; r.n_candidates = fc_a;
+        r.n_groups = overflow ? 0u : gcarry; r.total = overflow ? 0u : carry;
+        r.overflow = seg_over ? RESULT_SEGMENT_OVERFLOW : (overflow ? 1u : 0u); r.n_entries = raw_sec; r.n_items = raw_items;
+        r.table_hash = table_hash ? result_seal(table_hash, A.frame, r.n_groups, r.total, r.n_vis_map, r.n_vis_vec, r.n_items) : 0u;
+        *A.hres = r;
+        if (!overflow) write_slab_header(A.out_count, carry, A.out_cap, A.frame);
+        else if (seg_over) cancel_slab_header(A.out_count, A.frame);
+        publish_to_host(&A.hres->done_frame, A.frame);
+    }
+}
+template <bool K32>
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull_sync(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                                                 uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A, PackArgs T) {
+    scan_cull_body<K32>(blockIdx.x, gridDim.x, keys, ncells, nsp, s0, c0, s1, c1, s2, c2, s3, c3, chunk_level, A);
+    wait_own_stores();                                        // this wave's list entries (write-through) and atomics have been performed ...
+    __syncthreads();                                          // ... before the workgroup signs off
+    if (threadIdx.x >= 64u) return;
+    typedef __attribute__((address_space(4))) const char *kernarg_ptr;
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));                              // (as in the body: none of these scalar loads in front of the key loads)
+    const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
+    FrameHeader *hdr = R.hdr;
+    uint32_t last = 0;
+    if (lane_id() == 0) {
+        const uint32_t nblk = gridDim.x, sh = blockIdx.x & (COUNTER_SHARDS - 1u), expect = (nblk - sh + COUNTER_SHARDS - 1u) / COUNTER_SHARDS;
+        if (atomicAdd(&hdr->counters[sh * 16u + 3u], 1u) + 1u == expect) {
+            const uint32_t ntop = nblk < COUNTER_SHARDS ? nblk : COUNTER_SHARDS;
+            if (atomicAdd(&hdr->counters[4], 1u) + 1u == ntop) last = 1u;           // (issued after the atomic above has returned)
+        }
+    }
+    if (!__shfl(last, 0, 64)) return;
+    const PackArgs &P2 = *(const PackArgs *)(ka + SYNC_TAIL_ARGS_OFFSET);
+    sync_frame_publish(hdr, R.K, P2);
+}
+template __global__ void k_scan_cull_sync<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, PackArgs);
+template __global__ void k_scan_cull_sync<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs, PackArgs);
 
 // ---------------------------------------------------------------------------------------------
 // K3: the ECS tick.  LogicFlow::apply_kinematics (flows/logic_flow.rs:366-448) + the component math of

@@ -273,12 +273,12 @@ class Pipeline:
         self._check(self._L.re_set_model_lod(self._h, model_index, render_system, len(lo), lo.ctypes.data_as(C.POINTER(C.c_float)), hi.ctypes.data_as(C.POINTER(C.c_float))), "re_set_model_lod")
 
     # -- Pipeline::execute, split at the reference's own seams -----------------------------------
-    def cull_and_pack(self, camera, emit_duplicates=False, asynchronous=False, copy=True, force_large_pack=False, defer_pack=False, two_lanes=False):
+    def cull_and_pack(self, camera, emit_duplicates=False, asynchronous=False, copy=True, force_large_pack=False, defer_pack=False, two_lanes=False, one_launch=False):
         """pipeline.rs:216-229 + render_flow.rs:401-410.  Returns dict(total, ids, mats, groups, ...)."""
         cam = camera if isinstance(camera, _capi.CameraC) else camera.to_c()
         vis = _capi.Visible()
         flags = (_capi.CULL_EMIT_DUPLICATES if emit_duplicates else 0) | (_capi.CULL_ASYNC if asynchronous else 0) | \
-            (_capi.CULL_FORCE_LARGE_PACK if force_large_pack else 0) | (_capi.CULL_DEFER_PACK if defer_pack else 0) | (_capi.CULL_TWO_LANES if two_lanes else 0)
+            (_capi.CULL_FORCE_LARGE_PACK if force_large_pack else 0) | (_capi.CULL_DEFER_PACK if defer_pack else 0) | (_capi.CULL_TWO_LANES if two_lanes else 0) | (_capi.CULL_ONE_LAUNCH if one_launch else 0)
         self._check(self._L.re_cull_pack(self._h, C.byref(cam), flags, C.byref(vis)), "re_cull_pack")
         if asynchronous:
             return None

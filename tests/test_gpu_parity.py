@@ -937,6 +937,38 @@ def test_rebucket_on_the_device(R, straddlers):
     p.close(); w.close()
 
 
+def test_one_launch_synchronous_frames(R):
+    """RE_CULL_ONE_LAUNCH: the scan's last workgroup publishes the frame's result itself (k_scan_cull_sync: ticket over the workgroups, list entries written
+    through to memory, one wave builds the InstanceRange table), k_pack_small only moves the instances.  Frames with movers, shared sections, duplicates
+    mode, an empty view, and a visible set too large for the small pack (the tail declines, the frame is redone through the large path)."""
+    ents = R.synthetic.mixed_world(3000, seed=33, spread=500.0)
+    ents["vel"] *= 6.0
+    p, w = build_pair(R, ents)
+    cams = [R.Camera((8192 + 40 * i, 8192 - 25 * i, 8700 - 20 * i), (0.02 * i, 0, -1), 900.0 + 300.0 * (i % 3)) for i in range(8)]
+    cams.append(R.Camera((200.0, 200.0, 200.0), (1, 0, 0), 50.0))                       # nothing in view
+    for f, cam in enumerate(cams):
+        oc = oracle_camera(cam)
+        vis_o = w.cull(oc)
+        g = p.cull_and_pack(cam, emit_duplicates=bool(f % 2), one_launch=True)
+        keys, mult = p.visible_sections()
+        np.testing.assert_array_equal(expand_vis(keys, mult), vis_o)
+        assert_render_equal(g, w.render(oc, emit_duplicates=bool(f % 2)))
+        assert_clean_publication(p)
+        n_o, oob_o = w.tick(oc, 0.05); t = p.tick(0.05)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
+    check_sections(p, w)
+    p.close(); w.close()
+    big = R.synthetic.lattice_world(cells_per_axis=40, first_cell=108)               # > 16 K visible instances: the small path declines
+    p, w = build_pair(R, big)
+    cam = R.Camera((8192, 8192, 10500), (0, 0, -1), 5000.0); oc = oracle_camera(cam)
+    for f in range(3):
+        w.cull(oc); g = p.cull_and_pack(cam, one_launch=True)
+        o = w.render(oc)
+        assert o["total"] > 16384
+        assert_render_equal(g, o)
+    p.close(); w.close()
+
+
 @pytest.mark.parametrize("seed,tight", [(5, False), (6, True), (7, False)])
 def test_device_rebucket_soak(R, seed, tight):
     """40 ticks of a world whose movers drift across section borders (about half of the placement changes involve a shared section): batch after batch
