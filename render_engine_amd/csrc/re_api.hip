@@ -212,6 +212,7 @@ struct re_ctx {
     DevBuf<uint64_t> d_base_keys; DevBuf<unsigned long long> d_ovl_keys; DevBuf<uint32_t> d_ovl_slots; uint32_t ovl_cap = 0, ovl_count = 0;
     bool rb_base_dirty = true, rb_ovl_dirty = true;
     DevBuf<uint64_t> d_rb_key, d_rb_ord, d_rb_key2, d_rb_ksorted; DevBuf<uint32_t> d_rb_row, d_rb_idx, d_rb_perm1, d_rb_perm, d_rb_tmprow, d_rb_refold, d_rb_free, d_rb_freeoff;
+    uint8_t *h_chg = nullptr, *d_chg = nullptr; DevBuf<WriteOp> d_chg_ops; DevBuf<uint32_t> d_chg_list;   // change batches: mapped staging block of k_apply_small; device scratch of larger batches
     DevBuf<uint32_t> d_hrb_list; DevBuf<uint8_t> d_hrb_nk; DevBuf<uint64_t> d_hrb_keys;   // scratch of the host-path re-bucket (the movers' new section decisions)
     DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
     // shared world sections on the device path: the table has sh_cap entries with STABLE indices (a retired entry is a hole until a host path rebuilds the
@@ -322,7 +323,8 @@ static void free_world(re_ctx *c) {
     c->d_rb_key.release(nullptr); c->d_rb_ord.release(nullptr); c->d_rb_key2.release(nullptr); c->d_rb_ksorted.release(nullptr); c->d_rb_row.release(nullptr); c->d_rb_idx.release(nullptr);
     c->d_rb_perm1.release(nullptr); c->d_rb_perm.release(nullptr); c->d_rb_tmprow.release(nullptr); c->d_rb_refold.release(nullptr); c->d_rb_free.release(nullptr); c->d_rb_freeoff.release(nullptr);
     c->d_rb_tmp.release(nullptr); c->d_rb_segs.release(nullptr); c->d_rb_status.release(nullptr); c->rb_cap = 0;
-    c->d_hrb_list.release(nullptr); c->d_hrb_nk.release(nullptr); c->d_hrb_keys.release(nullptr);
+    c->d_hrb_list.release(nullptr); c->d_hrb_nk.release(nullptr); c->d_hrb_keys.release(nullptr); c->d_chg_ops.release(nullptr); c->d_chg_list.release(nullptr);
+    if (c->h_chg) { (void)hipHostFree(c->h_chg); c->h_chg = nullptr; c->d_chg = nullptr; }
     c->d_sh_keys.release(nullptr); c->d_sh_nk.release(nullptr); c->d_cell_inact.release(nullptr); c->d_sh_rowcap.release(nullptr); c->d_sh_hidx.release(nullptr); c->d_sh_hkeys.release(nullptr);
     c->sh_cap = 0; c->rb_sh_dirty = true; c->sh_free.clear(); c->stale_shared.clear(); release_rb2(c);
     c->d_id.release(a); c->d_gclass.release(a); c->d_flags.release(a); c->d_row_cell.release(a); c->d_mat.release(a); c->d_pos.release(a); c->d_rot.release(a);
@@ -2146,7 +2148,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         c->moved_rows.resize(at + m0);
         HIPCHK(c, hipMemcpy(c->moved_rows.data() + at, c->d_movers.p, (size_t)m0 * 4, hipMemcpyDeviceToHost));
     }
-    if (!pre && !ghost_touched) {
+    if ((!pre || pre->empty()) && (!ghost_touched || ghost_touched->empty())) {     // a tick's movers, or a change batch that only moved entities (no make-static / wake-up / delete / add, no ghost of the frozen cache touched)
         static const bool v1 = getenv("RE_EXP_RB_V1") != nullptr;          // A/B switch: round 2's device path (unique, unlinked sections only)
         int drc = v1 ? rebucket_on_device(c, n_movers, &movers) : rebucket_on_device2(c, n_movers, &movers);
         if (drc < 0) return drc;
@@ -2892,9 +2894,41 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
     for (uint32_t r : trans) list.push_back(r | 0x80000000u);
     for (uint32_t r : kin) list.push_back(r);
     TickHeader th{};
-    if (!ops.empty() || !list.empty()) {
-        DevBuf<WriteOp> d_ops; DevBuf<uint32_t> d_list;
-        HIPCHK(c, d_ops.alloc(ops.size(), nullptr)); HIPCHK(c, d_list.alloc(list.size(), nullptr));
+    static const bool no_small = getenv("RE_EXP_NO_APPLY_SMALL") != nullptr;      // A/B switch of tools/change_cost.py
+    if ((!ops.empty() || !list.empty()) && ops.size() <= APPLY_SMALL_MAX && list.size() <= APPLY_SMALL_MAX && c->h_th && !no_small) {
+        // the common small batch: ONE launch that reads its input from a mapped staging block and publishes the counters (k_apply_small)
+        if (!c->h_chg) {
+            void *hp = nullptr, *dp = nullptr;
+            HIPCHK(c, hipHostMalloc(&hp, APPLY_SMALL_MAX * (sizeof(WriteOp) + 4u), hipHostMallocMapped));
+            HIPCHK(c, hipHostGetDevicePointer(&dp, hp, 0));
+            c->h_chg = static_cast<uint8_t *>(hp); c->d_chg = static_cast<uint8_t *>(dp);
+        }
+        if (!ops.empty()) memcpy(c->h_chg, ops.data(), ops.size() * sizeof(WriteOp));
+        if (!list.empty()) memcpy(c->h_chg + APPLY_SMALL_MAX * sizeof(WriteOp), list.data(), list.size() * 4);
+        std::atomic_thread_fence(std::memory_order_release);
+        const uint32_t seq = ++c->tick_seq;
+        hipLaunchKernelGGL(k_apply_small, dim3(1), dim3(256), 0, st, (uint32_t)ops.size(), reinterpret_cast<const WriteOp *>(c->d_chg), (uint32_t)list.size(),
+                           reinterpret_cast<const uint32_t *>(c->d_chg + APPLY_SMALL_MAX * sizeof(WriteOp)), row_arrays(c), c->d_dyn_vel.p, c->d_dyn_acc.p, c->d_dyn_rotvel.p, c->d_dyn_rotacc.p,
+                           c->d_row_cell.p, c->d_cell_key.p, c->d_sh_cells.p, c->cfg.outline_length, c->cfg.atomic_length, c->d_th.p, c->d_movers.p, c->d_oob.p, c->list_cap, c->d_hth, seq);
+        HIPCHK(c, hipGetLastError());
+        const volatile TickHeader *t = c->h_th; bool ok = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !(ok = (t->ticket == seq)); spins++)
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        if (ok) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            th.n_changed = t->n_changed; th.n_rebucket = t->n_rebucket; th.n_oob = t->n_oob;
+            ok = t->pad[0] == (table_word_hash(th.n_changed, 1u) ^ table_word_hash(th.n_rebucket, 2u) ^ table_word_hash(th.n_oob, 3u) ^ table_word_hash(seq, 4u));
+        }
+        if (!ok) {                                                              // (a slow box, or a block that did not agree with its seal at first sight: the stream's end is authoritative)
+            HIPCHK(c, sync_stream(st));
+            HIPCHK(c, hipMemcpy(&th, c->d_th.p, sizeof th, hipMemcpyDeviceToHost));
+        }
+        c->th_clean = false;
+    } else if (!ops.empty() || !list.empty()) {
+        DevBuf<WriteOp> &d_ops = c->d_chg_ops; DevBuf<uint32_t> &d_list = c->d_chg_list;        // kept across calls
+        if (d_ops.n < ops.size()) HIPCHK(c, d_ops.alloc(ops.size() * 2, nullptr));
+        if (d_list.n < list.size()) HIPCHK(c, d_list.alloc(list.size() * 2, nullptr));
         HIPCHK(c, hipMemsetAsync(c->d_th.p, 0, sizeof(TickHeader), st));
         if (!ops.empty()) {
             HIPCHK(c, hipMemcpyAsync(d_ops.p, ops.data(), ops.size() * sizeof(WriteOp), hipMemcpyHostToDevice, st));
@@ -2909,7 +2943,6 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(&th, c->d_th.p, sizeof th, hipMemcpyDeviceToHost, st));
         HIPCHK(c, sync_stream(st));
-        d_ops.release(nullptr); d_list.release(nullptr);
         c->th_clean = false;
     }
     if (th.n_oob) { int rc = absorb_out_of_bounds(c, th.n_oob); if (rc != RE_OK) return rc; }

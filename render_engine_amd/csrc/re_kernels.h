@@ -247,6 +247,10 @@ struct WriteOp { uint32_t comp, index; uint32_t v[4]; };
 constexpr uint32_t WRITE_GCLASS = 101;    // v[0] = group class of the row (0xFFFFFFFF hides it from the pack)
 constexpr uint32_t WRITE_FLAGS = 100;     // v[0] = and-mask, v[1] = or-mask, v[2] != 0: also retire the row's group class (entity removed)
 __global__ void k_write_components(uint32_t m, const WriteOp *ops, RowArrays R, float *dyn_vel, float *dyn_acc, float *dyn_rotvel, float *dyn_rotacc);
+constexpr uint32_t APPLY_SMALL_MAX = 256;   // component writes / moved entities of a change batch that k_apply_small takes in ONE launch of one workgroup
+__global__ void k_apply_small(uint32_t n_ops, const WriteOp *ops, uint32_t n_rows, const uint32_t *rows, RowArrays R, float *dyn_vel, float *dyn_acc, float *dyn_rotvel, float *dyn_rotacc,
+                              const uint32_t *row_cell, const uint64_t *cell_key, const int32_t *sh_cells, uint32_t outline, uint32_t atomic,
+                              TickHeader *th, uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap, TickHeader *h_th, uint32_t seq);
 __global__ void k_apply_rows(uint32_t m, const uint32_t *rows, RowArrays R, const uint32_t *row_cell, const uint64_t *cell_key, const int32_t *sh_cells, uint32_t outline,
                              uint32_t atomic, TickHeader *th, uint32_t *mover_rows, uint32_t *oob_rows, uint32_t list_cap);
 __global__ void k_assign_rows(uint32_t m, const uint32_t *rows, RowArrays R, uint32_t outline, uint32_t atomic, uint8_t *out_nk, uint64_t *out_keys);

@@ -1627,11 +1627,7 @@ __global__ __launch_bounds__(256) void k_assign_rows(uint32_t m, const uint32_t 
 // end_of_changes restricted to the changed sections of an incremental update: unchanged sections keep their (possibly stale) AABB
 // Component writes of user change requests (EntityChangeRequest::apply_changes -> ECS::write_component, objects/ecs.rs:457-474),
 // resolved to "last write wins" per (entity, component) on the host.  comp: RE_C_* (0..6) or WRITE_FLAGS (and-mask, or-mask[, kill]).
-__global__ __launch_bounds__(256) void k_write_components(uint32_t m, const WriteOp *__restrict__ ops, RowArrays R, float *__restrict__ dyn_vel, float *__restrict__ dyn_acc,
-                                                          float *__restrict__ dyn_rotvel, float *__restrict__ dyn_rotacc) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const WriteOp w = ops[i];
+__device__ __forceinline__ void write_component(const WriteOp &w, const RowArrays &R, float *__restrict__ dyn_vel, float *__restrict__ dyn_acc, float *__restrict__ dyn_rotvel, float *__restrict__ dyn_rotacc) {
     const float *v = reinterpret_cast<const float *>(w.v);
     switch (w.comp) {
         case 0: for (int k = 0; k < 3; k++) R.pos[(size_t)w.index * 3 + k] = v[k]; break;
@@ -1645,6 +1641,13 @@ __global__ __launch_bounds__(256) void k_write_components(uint32_t m, const Writ
         case WRITE_FLAGS: R.flags[w.index] = (R.flags[w.index] & w.v[0]) | w.v[1]; if (w.v[2]) R.gclass[w.index] = 0xFFFFFFFFu; break;
         default: break;
     }
+}
+__global__ __launch_bounds__(256) void k_write_components(uint32_t m, const WriteOp *__restrict__ ops, RowArrays R, float *__restrict__ dyn_vel, float *__restrict__ dyn_acc,
+                                                          float *__restrict__ dyn_rotvel, float *__restrict__ dyn_rotacc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const WriteOp w = ops[i];
+    write_component(w, R, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc);
 }
 
 // update_aabb_after_kinematic_change for the entities of one apply_change batch: rows[i] bit 31 = translation-only set
@@ -1660,6 +1663,39 @@ __global__ __launch_bounds__(256) void k_apply_rows(uint32_t m, const uint32_t *
     const float rot[4] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2], R.rot[r * 4 + 3] };
     atomicAdd(&th->n_changed, 1u);
     place_changed_entity(r, fl, fl, row_cell[r], pos, rot, translation_only, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap);
+}
+
+// A small change batch in ONE launch of one workgroup (the common case: the user entity re-inserted at the camera position every frame, logic_flow.rs:246-251, a handful of
+// requests from the collision callbacks): the tick counters zeroed, the component writes, a workgroup barrier (the writes are this workgroup's own: workgroup scope is enough),
+// update_aabb_after_kinematic_change for the moved entities, and the counters published to the host's mapped block -- the caller polls that word instead of a memset, two
+// copies, two launches, a copy back and a stream synchronise.  ops / rows are read straight from mapped host memory (a few hundred bytes).
+__global__ __launch_bounds__(256) void k_apply_small(uint32_t n_ops, const WriteOp *__restrict__ ops, uint32_t n_rows, const uint32_t *__restrict__ rows, RowArrays R,
+                                                     float *__restrict__ dyn_vel, float *__restrict__ dyn_acc, float *__restrict__ dyn_rotvel, float *__restrict__ dyn_rotacc,
+                                                     const uint32_t *__restrict__ row_cell, const uint64_t *__restrict__ cell_key, const int32_t *__restrict__ sh_cells, uint32_t outline, uint32_t atomic,
+                                                     TickHeader *th, uint32_t *__restrict__ mover_rows, uint32_t *__restrict__ oob_rows, uint32_t list_cap, TickHeader *h_th, uint32_t seq) {
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t i = tid; i < sizeof(TickHeader) / 4u; i += 256u) reinterpret_cast<uint32_t *>(th)[i] = 0u;
+    if (tid < n_ops) { const WriteOp w = ops[tid]; write_component(w, R, dyn_vel, dyn_acc, dyn_rotvel, dyn_rotacc); }
+    __threadfence_block();
+    __syncthreads();
+    if (tid < n_rows) {
+        const uint32_t r = rows[tid] & 0x7FFFFFFFu; const bool translation_only = (rows[tid] >> 31) != 0;
+        const uint32_t fl = R.flags[r];
+        if (!(fl & F_DEAD)) {
+            const float pos[3] = { R.pos[r * 3 + 0], R.pos[r * 3 + 1], R.pos[r * 3 + 2] };
+            const float rot[4] = { R.rot[r * 4 + 0], R.rot[r * 4 + 1], R.rot[r * 4 + 2], R.rot[r * 4 + 3] };
+            atomicAdd(&th->n_changed, 1u);
+            place_changed_entity(r, fl, fl, row_cell[r], pos, rot, translation_only, R, cell_key, sh_cells, outline, atomic, th, mover_rows, oob_rows, list_cap);
+        }
+    }
+    wait_own_stores();                                        // every wave: its stores and counter atomics have been performed
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t a = __hip_atomic_load(&th->n_changed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(&th->n_rebucket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       c2 = __hip_atomic_load(&th->n_oob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        h_th->n_changed = a; h_th->n_rebucket = b; h_th->n_oob = c2; h_th->pad[0] = table_word_hash(a, 1u) ^ table_word_hash(b, 2u) ^ table_word_hash(c2, 3u) ^ table_word_hash(seq, 4u);
+        publish_to_host(&h_th->ticket, seq);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fold_tight_masked(uint32_t ncells, const uint64_t *cell_key, const uint32_t *cell_begin, const uint32_t *cell_nlocal,
