@@ -211,10 +211,8 @@ struct re_ctx {
     DevBuf<uint32_t> d_cell_cap; DevBuf<uint8_t> d_cell_links; std::vector<uint32_t> h_linked_slots;   // (links: shared sections linking each unique section; non-zero keeps a batch on the host)
     DevBuf<uint64_t> d_base_keys; DevBuf<unsigned long long> d_ovl_keys; DevBuf<uint32_t> d_ovl_slots; uint32_t ovl_cap = 0, ovl_count = 0;
     bool rb_base_dirty = true, rb_ovl_dirty = true;
-    DevBuf<uint64_t> d_rb_key, d_rb_ord, d_rb_key2, d_rb_ksorted; DevBuf<uint32_t> d_rb_row, d_rb_idx, d_rb_perm1, d_rb_perm, d_rb_tmprow, d_rb_refold, d_rb_free, d_rb_freeoff;
     uint8_t *h_chg = nullptr, *d_chg = nullptr; DevBuf<WriteOp> d_chg_ops; DevBuf<uint32_t> d_chg_list;   // change batches: mapped staging block of k_apply_small; device scratch of larger batches
     DevBuf<uint32_t> d_hrb_list; DevBuf<uint8_t> d_hrb_nk; DevBuf<uint64_t> d_hrb_keys;   // scratch of the host-path re-bucket (the movers' new section decisions)
-    DevBuf<uint8_t> d_rb_tmp; DevBuf<RbSeg> d_rb_segs; DevBuf<RbStatus> d_rb_status; uint32_t rb_cap = 0;
     // shared world sections on the device path: the table has sh_cap entries with STABLE indices (a retired entry is a hole until a host path rebuilds the
     // table compactly); ids, row capacities and the id -> index hash are device-only, rebuilt from the host mirrors whenever a host path has touched the table
     uint32_t sh_cap = 0, sh_hmask = 0, sh_hash_used = 0; bool rb_sh_dirty = true;   // (sh_hash_used: entries of the id -> index hash, retired ones included)
@@ -320,9 +318,6 @@ static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
     c->d_light_rows.release(nullptr); c->d_light_out.release(nullptr); c->light_rows_dirty = true;
     c->d_cell_cap.release(a); c->d_cell_links.release(a); c->h_linked_slots.clear(); c->d_base_keys.release(a); c->d_ovl_keys.release(nullptr); c->d_ovl_slots.release(nullptr); c->rb_base_dirty = c->rb_ovl_dirty = true; c->stale_slots.clear();
-    c->d_rb_key.release(nullptr); c->d_rb_ord.release(nullptr); c->d_rb_key2.release(nullptr); c->d_rb_ksorted.release(nullptr); c->d_rb_row.release(nullptr); c->d_rb_idx.release(nullptr);
-    c->d_rb_perm1.release(nullptr); c->d_rb_perm.release(nullptr); c->d_rb_tmprow.release(nullptr); c->d_rb_refold.release(nullptr); c->d_rb_free.release(nullptr); c->d_rb_freeoff.release(nullptr);
-    c->d_rb_tmp.release(nullptr); c->d_rb_segs.release(nullptr); c->d_rb_status.release(nullptr); c->rb_cap = 0;
     c->d_hrb_list.release(nullptr); c->d_hrb_nk.release(nullptr); c->d_hrb_keys.release(nullptr); c->d_chg_ops.release(nullptr); c->d_chg_list.release(nullptr);
     if (c->h_chg) { (void)hipHostFree(c->h_chg); c->h_chg = nullptr; c->d_chg = nullptr; }
     c->d_sh_keys.release(nullptr); c->d_sh_nk.release(nullptr); c->d_cell_inact.release(nullptr); c->d_sh_rowcap.release(nullptr); c->d_sh_hidx.release(nullptr); c->d_sh_hkeys.release(nullptr);
@@ -1826,112 +1821,6 @@ static bool device_rebucket_applicable(const re_ctx *c) {
            && !(c->cfg.flags & (RE_CFG_PROBE | RE_CFG_FULL_REBUILD));
 }
 
-static int rebucket_on_device(re_ctx *c, uint32_t M, std::vector<uint32_t> *host_list) {
-    host_list->clear();
-    if (!M || !device_rebucket_applicable(c)) return 1;
-    hipStream_t st = c->stream;
-    static const bool timing = getenv("RE_EXP_TIME_REBUCKET") != nullptr;
-    auto t_begin = std::chrono::steady_clock::now(); auto lap = [&](const char *what) { if (timing) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  device rebucket %-10s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_begin).count()); t_begin = t; } };
-    // ---- lookup tables: the sorted keys of the last full build + the overlay of sections created since (rebuilt from extra_slots after a host-side patch)
-    if (c->rb_base_dirty) {
-        HIPCHK(c, c->d_base_keys.alloc(c->base_keys.size(), &c->dev_bytes));
-        HIPCHK(c, hipMemcpyAsync(c->d_base_keys.p, c->base_keys.data(), c->base_keys.size() * 8, hipMemcpyHostToDevice, st));
-        c->rb_base_dirty = false;
-    }
-    if (!c->ovl_cap) { c->ovl_cap = 1u << 17; HIPCHK(c, c->d_ovl_keys.alloc(c->ovl_cap, nullptr)); HIPCHK(c, c->d_ovl_slots.alloc(c->ovl_cap, nullptr)); c->rb_ovl_dirty = true; }
-    if (c->rb_ovl_dirty) {
-        { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
-        if (c->extra_slots.size() * 4u > c->ovl_cap) return 1;                  // (the host path will rebuild the table from scratch when its own slack is used up)
-        HIPCHK(c, hipMemsetAsync(c->d_ovl_keys.p, 0xFF, (size_t)c->ovl_cap * 8, st));
-        std::vector<Pair64> pr; pr.reserve(c->extra_slots.size());
-        for (auto &kv : c->extra_slots) pr.push_back(Pair64{ kv.second, 0u, kv.first });
-        if (!pr.empty()) {
-            if (c->d_stage.n < pr.size() * sizeof(Pair64)) HIPCHK(c, c->d_stage.alloc(pr.size() * sizeof(Pair64) * 2, nullptr));
-            HIPCHK(c, hipMemcpyAsync(c->d_stage.p, pr.data(), pr.size() * sizeof(Pair64), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_rb_ovl_insert, dim3(((uint32_t)pr.size() + 255) / 256), dim3(256), 0, st, (uint32_t)pr.size(), reinterpret_cast<const Pair64 *>(c->d_stage.p), rb_tables(c));
-            HIPCHK(c, sync_stream(st));                                // `pr` goes out of scope
-        }
-        c->ovl_count = (uint32_t)c->extra_slots.size(); c->rb_ovl_dirty = false;
-    }
-    // ---- scratch
-    const uint32_t nops = 2u * M;
-    if (c->rb_cap < nops) {
-        const uint32_t cap = std::max(nops * 2u, 4096u);
-        HIPCHK(c, c->d_rb_key.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_ord.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_key2.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_ksorted.alloc(cap, nullptr));
-        HIPCHK(c, c->d_rb_row.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_idx.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_perm1.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_perm.alloc(cap, nullptr));
-        HIPCHK(c, c->d_rb_tmprow.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_refold.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_segs.alloc(cap, nullptr)); HIPCHK(c, c->d_rb_free.alloc(cap, nullptr));
-        if (!c->d_rb_status.p) { HIPCHK(c, c->d_rb_status.alloc(1, nullptr)); HIPCHK(c, c->d_rb_freeoff.alloc(MAX_LEVELS, nullptr)); }
-        size_t t1 = 0, t2 = 0;
-        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, c->d_rb_ord.p, c->d_rb_key2.p, c->d_rb_idx.p, c->d_rb_perm1.p, cap, 0, 34, st));
-        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t2, c->d_rb_ord.p, c->d_rb_ksorted.p, c->d_rb_perm1.p, c->d_rb_perm.p, cap, 0, 64, st));
-        HIPCHK(c, c->d_rb_tmp.alloc(std::max(t1, t2) + 256, nullptr));
-        c->rb_cap = cap;
-    }
-    size_t tmp_bytes = c->d_rb_tmp.n;
-    RbStatus hs{}; hs.pool_used = c->pool_used;
-    HIPCHK(c, hipMemcpyAsync(c->d_rb_status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
-    const RbTables T = rb_tables(c); const RbCells C = rb_cells(c);
-    // ---- phase 1: ops, sorted by (section key, reference order), replayed per section on the counts
-    hipLaunchKernelGGL(k_rb_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), T, C, c->cfg.outline_length, c->cfg.atomic_length,
-                       c->d_rb_key.p, c->d_rb_ord.p, c->d_rb_row.p, c->d_rb_idx.p, c->d_rb_tmprow.p /* the host path's movers (free until phase 2 sorts arrivals there) */, c->d_rb_status.p);
-    HIPCHK(c, re::sort_pairs_u64_u32(c->d_rb_tmp.p, &tmp_bytes, c->d_rb_ord.p, c->d_rb_key2.p, c->d_rb_idx.p, c->d_rb_perm1.p, nops, 0, 34, st));
-    hipLaunchKernelGGL(k_rb_gather_keys, dim3((nops + 255) / 256), dim3(256), 0, st, nops, c->d_rb_perm1.p, c->d_rb_key.p, c->d_rb_ord.p);     // (d_rb_ord: free again, now the keys in reference order)
-    tmp_bytes = c->d_rb_tmp.n;
-    HIPCHK(c, re::sort_pairs_u64_u32(c->d_rb_tmp.p, &tmp_bytes, c->d_rb_ord.p, c->d_rb_ksorted.p, c->d_rb_perm1.p, c->d_rb_perm.p, nops, 0, 64, st));
-    hipLaunchKernelGGL(k_rb_segments, dim3((nops + 255) / 256), dim3(256), 0, st, nops, c->d_rb_perm.p, c->d_rb_ksorted.p, c->d_rb_row.p, T, C, c->d_rb_segs.p, c->d_rb_status.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&hs, c->d_rb_status.p, sizeof hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, sync_stream(st));
-    lap("phase 1");
-    if (hs.fallback) return 1;
-    // Movers the host path keeps (hs.n_host): it takes them as a second batch behind this one.  The two batches count total_world_aabb_combining
-    // separately, so the split is only made where the threshold cannot depend on it: this part alone is already above 500 (crowded changed
-    // sections fall back to their grid AABB in both parts).  A small batch with such movers goes to the host path whole (it is cheap there).
-    if (hs.n_host >= M || (hs.n_host && hs.total <= 500u)) return 1;
-    std::vector<uint32_t> keep(hs.n_host);
-    if (hs.n_host) HIPCHK(c, hipMemcpy(keep.data(), c->d_rb_tmprow.p, (size_t)hs.n_host * 4, hipMemcpyDeviceToHost));      // (before phase 2 reuses the array)
-    uint32_t need_total = 0;
-    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { if (hs.need_slots[l] > c->free_slots[l].size()) return 1; need_total += hs.need_slots[l]; }
-    if ((uint64_t)c->pool_used + hs.need_pool > c->pool_cap) return 1;
-    if (((uint64_t)c->ovl_count + need_total) * 2u > c->ovl_cap) return 1;
-    // ---- phase 2: the free slots the new sections take (the top of each level's list, so that the host only pops), then the patch itself
-    std::vector<uint32_t> fl, off(MAX_LEVELS, 0);
-    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { off[l] = (uint32_t)fl.size(); for (uint32_t j = 0; j < hs.need_slots[l]; j++) fl.push_back(c->free_slots[l][c->free_slots[l].size() - 1u - j]); }
-    if (!fl.empty()) HIPCHK(c, hipMemcpyAsync(c->d_rb_free.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(c->d_rb_freeoff.p, off.data(), MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
-    const uint32_t nseg = hs.nseg;
-    hipLaunchKernelGGL(k_rb_apply, dim3((nseg + 63) / 64), dim3(64), 0, st, c->d_rb_perm.p, c->d_rb_row.p, T, C, row_arrays(c), c->d_rb_segs.p, c->d_rb_status.p, c->d_rb_free.p, c->d_rb_freeoff.p,
-                       c->d_rb_tmprow.p, c->d_rb_refold.p);
-    // end_of_changes: tight AABBs of the changed sections (bounding_box_tree_v2.rs:1055-1130)
-    hipLaunchKernelGGL(k_fold_tight_list, dim3((nseg + 255) / 256), dim3(256), 0, st, nseg, c->d_rb_refold.p, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p,
-                       c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
-    HIPCHK(c, hipGetLastError());
-    std::vector<RbSeg> segs(nseg); RbStatus h2{};
-    HIPCHK(c, hipMemcpyAsync(&h2, c->d_rb_status.p, sizeof h2, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(segs.data(), c->d_rb_segs.p, (size_t)nseg * sizeof(RbSeg), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, sync_stream(st));
-    lap("phase 2");
-    // ---- what the host keeps in step at once: free slots, pool fill, section count; everything else waits for sync_mirrors
-    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
-        if (h2.popped[l] != hs.need_slots[l]) return c->fail(RE_E_STATE, "device re-bucket: free-slot accounting (level %u: %u taken, %u planned)", l, h2.popped[l], hs.need_slots[l]);
-        c->free_slots[l].resize(c->free_slots[l].size() - hs.need_slots[l]);
-    }
-    int32_t delta = 0;
-    for (const RbSeg &S : segs) {
-        if (S.slot < 0) continue;
-        c->stale_slots.push_back((uint32_t)S.slot);
-        if (S.freed) { c->free_slots[key_level(S.key) & (MAX_LEVELS - 1)].push_back((uint32_t)S.slot); delta--; }      // reusable from the next patch on
-        if (S.created) delta++;
-    }
-    if (h2.pool_used > c->pool_cap) return c->fail(RE_E_STATE, "device re-bucket: row-pool accounting");
-    c->pool_used = h2.pool_used; c->nrows_csr = c->pool_used; c->ovl_count += h2.n_created;
-    c->n_real_sections = (uint32_t)((int32_t)c->n_real_sections + delta);
-    c->n_patches++; c->n_device_rebuckets++;
-    host_list->swap(keep);
-    lap("bookkeeping");
-    return RE_OK;
-}
-
 // ------------------------------------------------------------------------------------------------
 // rebucket_on_device, round 3: the whole batch of a tick's movers on the device, shared world sections included (re_rebucket.hip).  Returns RE_OK (the
 // movers listed in host_list -- static rows -- are left for the host path as a second batch), 1 when the batch is left to the host path whole (nothing
@@ -2149,8 +2038,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         HIPCHK(c, hipMemcpy(c->moved_rows.data() + at, c->d_movers.p, (size_t)m0 * 4, hipMemcpyDeviceToHost));
     }
     if ((!pre || pre->empty()) && (!ghost_touched || ghost_touched->empty())) {     // a tick's movers, or a change batch that only moved entities (no make-static / wake-up / delete / add, no ghost of the frozen cache touched)
-        static const bool v1 = getenv("RE_EXP_RB_V1") != nullptr;          // A/B switch: round 2's device path (unique, unlinked sections only)
-        int drc = v1 ? rebucket_on_device(c, n_movers, &movers) : rebucket_on_device2(c, n_movers, &movers);
+        int drc = rebucket_on_device2(c, n_movers, &movers);
         if (drc < 0) return drc;
         if (drc == 0) { if (movers.empty()) return RE_OK; second_batch = true; }
     }

@@ -262,18 +262,6 @@ struct Pair64 { uint32_t idx, pad; uint64_t val; };
 struct FlagOp { uint32_t idx; uint8_t and_mask, or_mask, pad[2]; };
 // ---- device-side re-bucket bookkeeping (re_api.hip: rebucket_on_device) ----
 constexpr uint32_t RB_REMOVE = 0x80000000u;                  // op row word: bit 31 = remove_entity (else add_entity)
-struct RbStatus {                                            // one block the host reads between the two phases
-    uint32_t fallback;                                       // a mover the device path does not handle (shared sections, static rows): the host path takes the batch
-    uint32_t total;                                          // total_world_aabb_combining of the batch (> 500: crowded changed sections fall back to their grid AABB)
-    uint32_t nseg;                                           // affected world sections
-    uint32_t need_pool;                                      // row-pool entries the relocated / created segments need
-    uint32_t need_slots[MAX_LEVELS];                         // sections to create, per level
-    uint32_t popped[MAX_LEVELS];                             // phase 2: free slots handed out, per level
-    uint32_t pool_used;                                      // in: the pool's fill; out: after the relocations
-    uint32_t n_created, n_freed;
-    uint32_t n_host;                                         // movers left to the host path (shared sections, linked sections, static rows): rows in host_list
-};
-struct RbSeg { uint64_t key; int32_t slot; uint32_t op_begin, op_count, nl1, ns; uint8_t exists0, exists1, created, freed; };
 struct RbTables {                                            // key -> slot of the resident table: the immutable sorted keys of the last full build + an overlay of sections created since
     const uint64_t *base_keys; uint32_t nbase;
     unsigned long long *ovl_keys; uint32_t *ovl_slots; uint32_t ovl_mask;
@@ -340,13 +328,8 @@ __device__ __forceinline__ void rb_ovl_put(const RbTables &T, uint64_t key, uint
 #endif
 hipError_t sort_pairs_u64_u32(void *tmp, size_t *tmp_bytes, const uint64_t *keys_in, uint64_t *keys_out, const uint32_t *vals_in, uint32_t *vals_out,
                               uint32_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream);      // re_sort.hip (rocPRIM radix sort)
-__global__ void k_rb_ops(uint32_t m, const uint32_t *movers, RowArrays R, RbTables T, RbCells C, uint32_t outline, uint32_t atomic,
-                         uint64_t *op_key, uint64_t *op_ord, uint32_t *op_row, uint32_t *op_idx, uint32_t *host_list, RbStatus *st);
-__global__ void k_rb_gather_keys(uint32_t n, const uint32_t *perm, const uint64_t *op_key, uint64_t *key_sorted);
-__global__ void k_rb_segments(uint32_t n, const uint32_t *perm, const uint64_t *op_key, const uint32_t *op_row, RbTables T, RbCells C, RbSeg *segs, RbStatus *st);
-__global__ void k_rb_apply(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, RbSeg *segs, RbStatus *st,
-                           const uint32_t *free_slots, const uint32_t *free_off, uint32_t *tmp_row, uint32_t *refold);
 __global__ void k_rb_ovl_insert(uint32_t n, const Pair64 *pairs, RbTables T);
+__global__ void k_rb_gather_keys(uint32_t n, const uint32_t *perm, const uint64_t *key, uint64_t *out);
 __global__ void k_rb_gather_cells(uint32_t n, const uint32_t *slots, RbCells C, uint64_t *out_key, uint32_t *out_hdr);
 __global__ void k_rb_gather_rows(uint32_t n, const uint32_t *slots, const uint32_t *offs, RbCells C, uint32_t *out_rows);
 struct LightQuery { LevelBox box[MAX_LEVELS]; Aabb culler; uint32_t max_level, type_flag; };

@@ -1776,141 +1776,16 @@ __global__ __launch_bounds__(256) void k_query_flags(uint32_t n, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Re-bucket bookkeeping on the device: update_entity_in_tree -> BoundingBoxTree::add_entity (which first removes the entity from its
-// previous section) for every mover whose section changed, then end_of_changes (helper_things/entity_change_helpers.rs:217-262, 325-351;
-// world/bounding_box_tree_v2.rs:563-942, 1055-1213), for the common batch: movers between unique world sections.  The reference's sequential
-// order (translation-only movers, then kinematic movers, ascending EntityId) only matters per world section (the membership counts that decide
-// total_world_aabb_combining), so the batch becomes two ops per mover -- remove from the old section, add to the new one --, sorted by (section key,
-// order), and one thread replays each section's ops in order.  Movers into or out of shared sections, of sections that shared sections link, and static
-// rows are listed for the host path (re_api.hip: rebucket), which takes them as a second batch behind this one; worlds with ghosts of the frozen
-// static cache or hidden rows stay on the host path altogether.
+// Helpers of the device-side re-bucket (re_rebucket.hip): the overlay of sections created since the last full build, the gather of keys in sorted order,
+// and the kernels that fetch the host mirrors of the sections the device patched (re_api.hip: sync_mirrors).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rb_ovl_insert(uint32_t n, const Pair64 *__restrict__ pairs, RbTables T) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rb_ovl_put(T, pairs[i].val, pairs[i].idx);
 }
-__global__ __launch_bounds__(256) void k_rb_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbTables T, RbCells C,
-                                                uint32_t outline, uint32_t atomic, uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
-                                                uint32_t *__restrict__ op_idx, uint32_t *__restrict__ host_list, RbStatus *st) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const uint32_t w = movers[i], r = w & 0x7FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
-    Aabb bv = R.aabb[r];
-    normalize_aabb(&bv, (float)outline);
-    uint64_t keys[8];
-    const int nk = assign_sections(bv, atomic, keys);                      // add_entity with add_if_out_bounds = true: the box is clamped
-    if (rc == ROW_CELL_NONE || (fl & F_DEAD) || nk < 1) st->fallback = 1u;  // (not a mover the tick can have listed)
-    // movers the host path keeps: into or out of a shared section, static rows, and unique sections that a shared section links (their existence and
-    // static flag depend on that one too).  Their two ops get the key ~0 (sorted behind every section, skipped by k_rb_segments).
-    bool host = nk != 1 || (rc & ROW_CELL_SHARED) || (fl & F_STATIC) || rc == ROW_CELL_NONE;
-    if (!host) {
-        if (C.cell_links[rc]) host = true;
-        else { const int32_t ns = rb_find(T, C.cell_key, keys[0]); if (ns >= 0 && C.cell_links[ns]) host = true; }
-    }
-    if (host) host_list[atomicAdd(&st->n_host, 1u)] = w;
-    const uint64_t ord = ((uint64_t)((w >> 31) ? 0u : 1u) << 33) | ((uint64_t)R.id[r] << 1);   // translation-only movers first, then ascending EntityId; remove before add
-    op_key[2 * i] = host ? ~0ull : C.cell_key[rc]; op_ord[2 * i] = ord;       op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
-    op_key[2 * i + 1] = host ? ~0ull : keys[0];    op_ord[2 * i + 1] = ord | 1ull; op_row[2 * i + 1] = r;  op_idx[2 * i + 1] = 2 * i + 1;
-}
 __global__ __launch_bounds__(256) void k_rb_gather_keys(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ op_key, uint64_t *__restrict__ key_sorted) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) key_sorted[i] = op_key[perm[i]];
-}
-// phase 1: one thread per affected section replays remove_entity (:787-942) / add_entity (:563-762) on the section's counts, exactly as the host
-// path does (re_api.hip: rebucket, `replay`): what the section ends as, its share of total_world_aabb_combining, and what the patch will need
-__global__ __launch_bounds__(256) void k_rb_segments(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
-                                                     RbTables T, RbCells C, RbSeg *__restrict__ segs, RbStatus *st) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    const uint64_t key = key_sorted[t];
-    if (t > 0 && key_sorted[t - 1] == key) return;                           // segment heads only
-    if (key == ~0ull) return;                                               // the ops of the movers left to the host path
-    uint32_t e = t + 1u; while (e < n && key_sorted[e] == key) e++;
-    const int32_t slot = rb_find(T, C.cell_key, key);
-    if (slot >= 0 && C.cell_links[slot]) st->fallback = 1u;                   // a section some shared section links: its existence and static flag depend on that one too (host path)
-    const bool exists0 = slot >= 0;
-    uint32_t nl = exists0 ? C.cell_nl[slot] : 0u, ns = exists0 ? C.cell_ns[slot] : 0u, total = 0;
-    bool exists = exists0, changed = false;
-    for (uint32_t q = t; q < e; q++) {
-        if (op_row[perm[q]] & RB_REMOVE) {
-            if (nl) nl--;
-            if (nl == 0 && ns == 0) exists = false; else total += changed ? 1u : nl + ns;
-        } else if (exists) { nl++; total += changed ? 1u : nl + ns; }
-        else { nl = 1u; ns = 0u; exists = true; total += 1u; }
-        changed = true;
-    }
-    RbSeg S; S.key = key; S.slot = slot; S.op_begin = t; S.op_count = e - t; S.nl1 = nl; S.ns = ns; S.exists0 = exists0; S.exists1 = exists; S.created = 0; S.freed = 0;
-    segs[atomicAdd(&st->nseg, 1u)] = S;
-    if (total) atomicAdd(&st->total, total);
-    if (exists) {
-        const uint32_t size = nl + ns;
-        if (slot < 0) atomicAdd(&st->need_slots[key_level(key) & (MAX_LEVELS - 1)], 1u);
-        if (slot < 0 || size > C.cell_cap[slot]) { const uint32_t cap = size * 2u > 4u ? size * 2u : 4u; atomicAdd(&st->need_pool, cap); }
-    }
-}
-// phase 2 (after the host has checked the slack): one thread per affected section rewrites its segment of the row pool -- active rows in ascending
-// EntityId, then the static rows, as patch_sections does --, relocating it to the end of the pool when it outgrew its capacity; a new section takes a
-// free slot of its level run (handed over by the host), an emptied one becomes a padding slot.  update_static_world_sections (first loop) for it.
-__global__ __launch_bounds__(64) void k_rb_apply(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, RbSeg *__restrict__ segs, RbStatus *st,
-                                                 const uint32_t *__restrict__ free_slots, const uint32_t *__restrict__ free_off, uint32_t *__restrict__ tmp_row, uint32_t *__restrict__ refold) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= st->nseg) return;
-    RbSeg S = segs[s];
-    const uint32_t lv = key_level(S.key) & (MAX_LEVELS - 1);
-    refold[s] = 0xFFFFFFFFu;
-    if (!S.exists1) {
-        if (S.slot >= 0) {                                                    // emptied and not linked by a shared section: a padding slot from now on
-            const uint32_t sl = (uint32_t)S.slot;
-            C.cell_key[sl] = pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu); C.cell_key32[sl] = KEY32_PAD | 0x1FF7FDFFu;
-            C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = (uint8_t)(CF_PAD | CF_STATIC_SECTION);
-            S.freed = 1; atomicAdd(&st->n_freed, 1u); segs[s] = S;
-        }
-        return;
-    }
-    uint32_t sl;
-    if (S.slot < 0) {
-        sl = free_slots[free_off[lv] + atomicAdd(&st->popped[lv], 1u)];
-        S.slot = (int32_t)sl; S.created = 1; atomicAdd(&st->n_created, 1u);
-        C.cell_key[sl] = S.key; C.cell_key32[sl] = (key_x(S.key) << 20) | (key_z(S.key) << 10) | key_y(S.key);
-        C.cell_stamp[sl] = 0; C.cell_cap[sl] = 0; C.cell_begin[sl] = 0; C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0;
-        rb_ovl_put(T, S.key, sl);
-    } else sl = (uint32_t)S.slot;
-    const uint32_t nl0 = C.cell_nl[sl], ns = C.cell_ns[sl];
-    uint32_t begin = C.cell_begin[sl], cap = C.cell_cap[sl];
-    // the rows that arrive, in ascending EntityId (insertion sort into this section's share of the scratch array)
-    uint32_t a = 0;
-    for (uint32_t q = S.op_begin; q < S.op_begin + S.op_count; q++) {
-        const uint32_t w = op_row[perm[q]];
-        if (w & RB_REMOVE) continue;
-        const uint32_t id = R.id[w];
-        uint32_t k = a;
-        while (k > 0 && R.id[tmp_row[S.op_begin + k - 1u]] > id) { tmp_row[S.op_begin + k] = tmp_row[S.op_begin + k - 1u]; k--; }
-        tmp_row[S.op_begin + k] = w; a++;
-    }
-    // the active rows that stay
-    uint32_t m = 0;
-    auto leaves = [&](uint32_t r) { for (uint32_t q = S.op_begin; q < S.op_begin + S.op_count; q++) if (op_row[perm[q]] == (r | RB_REMOVE)) return true; return false; };
-    uint32_t kept = 0; for (uint32_t i = 0; i < nl0; i++) if (!leaves(C.rows[begin + i])) kept++;
-    const uint32_t nl1 = kept + a, size = nl1 + ns;
-    if (size > cap) {                                                         // relocate to the end of the pool (the host checked the room)
-        const uint32_t ncap = size * 2u > 4u ? size * 2u : 4u, nb = atomicAdd(&st->pool_used, ncap);
-        for (uint32_t i = 0; i < nl0 + ns; i++) { C.rows[nb + i] = C.rows[begin + i]; C.rows_gc[nb + i] = C.rows_gc[begin + i]; }
-        begin = nb; cap = ncap; C.cell_begin[sl] = nb; C.cell_cap[sl] = ncap;
-    }
-    for (uint32_t i = 0; i < nl0; i++) { const uint32_t r = C.rows[begin + i]; if (!leaves(r)) { C.rows[begin + m] = r; C.rows_gc[begin + m] = C.rows_gc[begin + i]; m++; } }
-    // the static rows follow the active ones
-    if (nl1 > nl0) for (uint32_t i = ns; i-- > 0;) { C.rows[begin + nl1 + i] = C.rows[begin + nl0 + i]; C.rows_gc[begin + nl1 + i] = C.rows_gc[begin + nl0 + i]; }
-    else if (nl1 < nl0) for (uint32_t i = 0; i < ns; i++) { C.rows[begin + nl1 + i] = C.rows[begin + nl0 + i]; C.rows_gc[begin + nl1 + i] = C.rows_gc[begin + nl0 + i]; }
-    // merge the arrivals into the kept rows, from the back
-    for (int32_t i = (int32_t)m - 1, j = (int32_t)a - 1, k = (int32_t)nl1 - 1; j >= 0; k--) {
-        if (i >= 0 && R.id[C.rows[begin + i]] > R.id[tmp_row[S.op_begin + j]]) { C.rows[begin + k] = C.rows[begin + i]; C.rows_gc[begin + k] = C.rows_gc[begin + i]; i--; }
-        else { const uint32_t r = tmp_row[S.op_begin + j]; C.rows[begin + k] = r; C.rows_gc[begin + k] = R.gclass[r]; C.row_cell[r] = sl; C.row_key[r] = S.key; j--; }
-    }
-    C.cell_nl[sl] = nl1;
-    const uint8_t f = S.created ? (uint8_t)0 : C.cell_flags[sl];
-    C.cell_flags[sl] = (uint8_t)((f & ~CF_STATIC_SECTION) | (nl1 == 0 ? CF_STATIC_SECTION : 0));      // update_static_world_sections, first loop: no active entities left
-    S.nl1 = nl1; segs[s] = S;
-    refold[s] = sl;
 }
 // host mirrors on demand: the state of the sections the device patched (re_api.hip: sync_mirrors)
 __global__ __launch_bounds__(256) void k_rb_gather_cells(uint32_t n, const uint32_t *__restrict__ slots, RbCells C, uint64_t *__restrict__ out_key, uint32_t *__restrict__ out_hdr) {
