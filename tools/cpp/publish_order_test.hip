@@ -8,6 +8,13 @@
 //   fence 0: every thread __threadfence_system() before the barrier    fence 1: only thread 0 fences (the k_group_scan bug pattern)
 //   flag  0: __threadfence_system() + PLAIN store of the done word     flag  1: release store at system scope (__hip_atomic_store)
 //   flag  2: __threadfence_system() + RELAXED system-scope atomic store (the scope bits alone)
+//   flag  3: NO fence anywhere: every thread waits for its own stores (s_waitcnt vmcnt(0)) in front of the barrier, thread 0 stores the result, waits again and
+//            stores the done word as a relaxed system-scope atomic -- the block lives in host memory, which the device does not cache, so the L2 write-back a
+//            system-scope release performs (every dirty line of the XCD: megabytes behind a tick) has nothing of the block to write (round 3: tick_sign_off)
+//            RESULT (round 3, MI355X): the TABLE is torn in ~99 % of the polled frames -- plain stores to mapped host memory do sit in the L2 until a system-scope
+//            write-back --, the result struct (same 64-byte line as the done word, stored by the same thread) never
+//   flag  4: as 3, but the result struct is stored word by word with relaxed SYSTEM-scope atomic stores (write-through), then the wait, then the done word:
+//            the form tick_sign_off uses for its four counters (look at "torn result structs"; the table is stored as in 3 and tears)
 //   load  0: idle device                                               load  1: a streaming kernel on a second stream keeps HBM busy
 // build: hipcc --offload-arch=gfx950 -O2 tools/cpp/publish_order_test.hip -o tools/cpp/publish_order_test
 #include <hip/hip_runtime.h>
@@ -28,12 +35,15 @@ __global__ void k_publish(Rec *table, uint32_t nrec, Res *res, uint32_t seq, int
         Rec r; for (int k = 0; k < 5; k++) r.w[k] = mix(seq, i, (uint32_t)k);
         table[i] = r;
     }
-    if (fence_all) __threadfence_system();
+    if (release_flag == 3 || release_flag == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (fence_all) __threadfence_system();
     __syncthreads();
     if (t == 0) {
         Res r = {}; for (int k = 0; k < 8; k++) r.v[k] = mix(seq, 0xFFFFu, (uint32_t)k);
-        *res = r;
-        if (release_flag == 1) { __hip_atomic_store(&res->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+        if (release_flag == 4) { for (int k = 0; k < 8; k++) __hip_atomic_store(&res->v[k], r.v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        else *res = r;
+        if (release_flag == 3 || release_flag == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(&res->done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+        else if (release_flag == 1) { __hip_atomic_store(&res->done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
         else if (release_flag == 2) { __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __hip_atomic_store(&res->done, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         else { __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); res->done = seq; }
     }
@@ -86,7 +96,7 @@ int main(int argc, char **argv) {
         hipStreamSynchronize(st);
         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
         printf("load %d alloc %s fence %s threads %4d flag %s: %u polled frames, torn tables %u (%u words, worst settle %.1f us), torn result structs %u  [%.2f s]\n",
-               load, alloc ? "one-coherent-block" : "two-blocks", fence_all ? "every-thread" : "thread0-only", threads, rel == 1 ? "release-atomic" : rel == 2 ? "fence+relaxed-system-atomic" : "fence+plain", iters / 3u, bad_iters, bad_words, worst_us, bad_res, el);
+               load, alloc ? "one-coherent-block" : "two-blocks", fence_all ? "every-thread" : "thread0-only", threads, rel == 1 ? "release-atomic" : rel == 2 ? "fence+relaxed-system-atomic" : rel == 3 ? "NO-fence: waits + relaxed-system-atomic" : rel == 4 ? "NO-fence: result words system-atomic + wait + relaxed-system-atomic" : "fence+plain", iters / 3u, bad_iters, bad_words, worst_us, bad_res, el);
         fflush(stdout);
         total_bad += (int)bad_iters + (int)bad_res;
         if (load) hipStreamSynchronize(st2);
