@@ -333,9 +333,11 @@ def random_changes(R, ents, rng, n, frozen, centre=(8192.0, 8192.0, 8192.0)):
     return ch
 
 
-def test_apply_changes_parity(R):
+@pytest.mark.parametrize("batch", [150, 700])
+def test_apply_changes_parity(R, batch):
     """apply_change for user change requests: Modify (all kinematic components), Delete, MakeObjectStatic, WakeUpRequest;
-    several batches interleaved with frames and ticks; sections, entities and visible sets stay bit-exact"""
+    several batches interleaved with frames and ticks; sections, entities and visible sets stay bit-exact.
+    batch 150: one launch per batch (k_apply_small: at most 256 component writes and 256 moved entities); 700: the general path"""
     ents = R.synthetic.mixed_world(3000, seed=21, spread=600.0)
     p, w = build_pair(R, ents)
     rng = np.random.default_rng(5)
@@ -347,7 +349,7 @@ def test_apply_changes_parity(R):
         n_o, oob_o = w.tick(oracle_camera(cam), 0.016)
         t = p.tick(0.016)
         assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
-        ch = random_changes(R, alive, rng, 150, frozen)
+        ch = random_changes(R, alive, rng, batch, frozen)
         if f == 2:                                           # push a few entities out of the world: with and without OutOfBoundsLogic
             far = np.zeros(6, R.CHANGE_DT)
             for i in range(6):
