@@ -33,7 +33,8 @@ def build_library(force=False, verbose=False):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
+    # (RE_BUILD_DEFINES="-DRE_EXP_STAGES": development builds for tools/stage_stop.py, tools/timeline.py)
+    cmd = [hipcc] + FLAGS + os.environ.get("RE_BUILD_DEFINES", "").split() + ["-I", INCLUDE, "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

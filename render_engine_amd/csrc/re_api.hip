@@ -981,6 +981,9 @@ static void make_frame_params(re_ctx *c, const re_camera *cam, uint32_t flags) {
     P.n_lod = cam->n_lod > 8 ? 8 : cam->n_lod;
     for (int k = 0; k < 8; k++) { P.lod_min[k] = cam->lod_min[k]; P.lod_max[k] = cam->lod_max[k]; }
     P.max_level = c->maxlevel; P.frame = c->frame; P.emit_duplicates = (flags & RE_CULL_EMIT_DUPLICATES) ? 1u : 0u;
+#ifdef RE_EXP_STAGES
+    { static const uint32_t stop = getenv("RE_EXP_STAGE_STOP") ? (uint32_t)atoi(getenv("RE_EXP_STAGE_STOP")) : 0u; P.pad = stop; }      // tools/stage_stop.py (development builds only)
+#endif
     float draw = wsl * 2.0f;                                                    // find_visible_world_ids_entire_world(.., wsl * 2.0, ..)
     fill_level_boxes(P.box[0], c->maxlevel, wsl, rmax(cam->position[0] - draw, 0.0f), cam->position[0] + draw, rmax(cam->position[1] - draw, 0.0f), cam->position[1] + draw,
                      rmax(cam->position[2] - draw, 0.0f), cam->position[2] + draw);

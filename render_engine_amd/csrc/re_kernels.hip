@@ -440,6 +440,9 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
 #ifdef RE_EXP_STAMPS
                 tl_pred = wall_clock64();
 #endif
+#ifdef RE_EXP_STAGES
+                if (P.pad & 2u) nv = 0;                                     // (tools/stage_stop.py: the launch without stage B)
+#endif
                 // stage B -- the visible sections only (usually one round of 64): everything indexed by the section in one memory round trip,
                 // then distance, LOD, active / cached-static row ranges, and the instance expansion
 #pragma unroll 1
@@ -469,6 +472,9 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
                             }
                         }
                     }
+#ifdef RE_EXP_STAGES
+                    if (P.pad & 4u) { for (uint32_t j = 0; j < EMIT_MAX; j++) cntv[j] = 0; }      // (tools/stage_stop.py: stage B without the instance expansion)
+#endif
                     emit_sections_multi(rbv, cntv, lodv, hdr, K, wave, hist, K.gc_lodtab ? q_key : nullptr);     // one reservation per slice of 256 visible sections
                 }
                 if (hist && nv) {                                           // flush: one atomic per non-empty group slot and wave, into the counts of this wave's cursor shard

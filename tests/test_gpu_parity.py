@@ -972,7 +972,7 @@ def test_one_launch_synchronous_frames(R):
 
 
 @pytest.mark.parametrize("seed,tight", [(5, False), (6, True), (7, False)])
-def test_device_rebucket_soak(R, seed, tight):
+def test_device_rebucket_long_soak(R, seed, tight):
     """40 ticks of a world whose movers drift across section borders (about half of the placement changes involve a shared section): batch after batch
     on the device without the host looking at the table in between (holes of the shared table reused, retired ids looked up again, sections
     that exist through links only), interleaved with asynchronous frames (cancelled and replayed) and -- tight: hardly any slack -- with batches that
