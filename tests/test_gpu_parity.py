@@ -997,7 +997,7 @@ def test_device_rebucket_long_soak(R, seed, tight):
             p.wait(); check_sections(p, w)
     p.wait()
     st = p.stats()
-    assert st["n_device_rebuckets"] >= (10 if tight else 30), st
+    assert st["n_device_rebuckets"] >= (0 if tight else 30) and (st["n_host_rebuckets"] > 0 or not tight), st      # (tight: a table without slack -- every batch may end on the host path)
     check_sections(p, w)
     check_entities(R, p, w, ents[::9])
     check_frame(R, p, w, cam, True)
