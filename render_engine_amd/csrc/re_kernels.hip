@@ -400,6 +400,9 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
 #ifdef RE_EXP_STAMPS
         tl_keys = wall_clock64(); tl_cand = any ? 1u : 0u;
 #endif
+#ifdef RE_EXP_STAGES
+        if (A.P.pad & 8u) any = 0;                                          // (tools/stage_stop.py: the stream and its tests alone -- costs every wave a scalar load, development builds only)
+#endif
         if (any) {                                                          // wave-uniform (scalar) branch: ~1% of the waves
             // Candidate waves read the rest of the kernel-argument segment through a pointer the compiler cannot see through, so that
             // none of those scalar loads is hoisted in front of the key loads of the other 99%.

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_scan_cull at far = 8192 with the kernel cut short (a development build: RE_BUILD_DEFINES=-DRE_EXP_STAGES python render_engine_amd/build.py; then RE_EXP_STAGE_STOP=2: no stage B,
-4: stage B without the expansion): where the launch's time goes.
+4: stage B without the expansion, 8: no candidate work at all -- the key stream and its tests alone): where the launch's time goes.
 Only the launch is timed; the frames' results are not looked at."""
 import os, sys, json
 import numpy as np
