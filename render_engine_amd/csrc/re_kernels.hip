@@ -403,7 +403,7 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
 #ifdef RE_EXP_STAGES
         if (A.P.pad & 8u) any = 0;                                          // (tools/stage_stop.py: the stream and its tests alone -- costs every wave a scalar load, development builds only)
 #endif
-        if (any) {                                                          // wave-uniform (scalar) branch: ~1% of the waves
+        if (__builtin_expect(any != 0ull, 0)) {                             // wave-uniform (scalar) branch: ~1% of the waves (laid out as the cold path: the 99% run straight through a few cache lines of code)
             // Candidate waves read the rest of the kernel-argument segment through a pointer the compiler cannot see through, so that
             // none of those scalar loads is hoisted in front of the key loads of the other 99%.
             typedef __attribute__((address_space(4))) const char *kernarg_ptr;
@@ -506,12 +506,12 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
         asm volatile("" : "+s"(ka));
         const ScanCullArgs &R = *(const ScanCullArgs *)(ka + SCAN_CULL_ARGS_OFFSET);
         const uint32_t nsh = R.S.n;
-        if (bid * CULL_THREADS < nsh && !R.spec->stale) {
+        if (__builtin_expect(bid * CULL_THREADS < nsh, 0) && !R.spec->stale) {
             const SharedArrays S = R.S; const ItemSink K = R.K;
             for (uint32_t s0 = bid * CULL_THREADS; s0 < nsh; s0 += nblk * CULL_THREADS)
                 cull_shared_section(s0 + threadIdx.x, S, R.cell_key64, R.cell_flags, R.cell_tight, K, R.hdr, R.P);
         }
-        if (bid == nblk - 1u && !R.spec->stale) {
+        if (__builtin_expect(bid == nblk - 1u, 0) && !R.spec->stale) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(&R.P); uint32_t *dst = reinterpret_cast<uint32_t *>(R.P_dev);
             for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += CULL_THREADS) dst[i] = src[i];
         }

@@ -48,6 +48,48 @@ __global__ __launch_bounds__(256) void NAME(const uint4 *__restrict__ p, uint32_
 RES_KERNEL(k_res_0_32, 0, "v31") RES_KERNEL(k_res_0_80, 0, "v79") RES_KERNEL(k_res_0_128, 0, "v127")
 RES_KERNEL(k_res_16k_32, 16384, "v31") RES_KERNEL(k_res_16k_80, 16384, "v79") RES_KERNEL(k_res_32k_80, 32768, "v79")
 __global__ void k_empty(uint32_t *out) { if (threadIdx.x == 9999) out[0] = 1; }
+// round 3: the 2 KB-per-wave chunk kernel with, step by step, what a wave of k_scan_cull that holds no candidate does besides reading its keys
+//   MODE bit 0: the level word of the wave's chunk (a scalar global load) and, behind it, the box of that level from the kernel-argument segment
+//   MODE bit 1: the guard-bit test of the 8 keys of a lane + one ballot per key
+//   MODE bit 2: the trailing block (two more words of the ~1.4 KB kernel-argument segment, the last workgroup copies 600 bytes of it)
+//   MODE bit 3: the workgroup -> chunk mapping through four spans (scalar arithmetic in front of everything)
+struct LikeBox { uint32_t lo, hi; };
+struct LikeArgs { LikeBox box[16]; uint32_t nsh, stale, words[320]; };
+template <int MODE> __global__ __launch_bounds__(256) void k_like(const uint4 *__restrict__ p, uint32_t n16, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
+                                                                  uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, uint32_t *out, LikeArgs A) {
+    __shared__ uint32_t lds[4096];
+    uint32_t chunk = blockIdx.x;
+    if (MODE & 8) {
+        const uint32_t st[4] = { s0, s1, s2, s3 }, ct[4] = { c0, c1, c2, c3 };
+        uint32_t acc = 0; bool in_span = false;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) if (i < nsp && !in_span) { if (chunk < acc + ct[i]) { chunk = st[i] + (chunk - acc); in_span = true; } else acc += ct[i]; }
+        if (!in_span) { chunk -= acc;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) if (i < nsp && chunk >= st[i]) chunk += ct[i]; }
+    }
+    const uint32_t lane = threadIdx.x & 63u, wave = chunk * 4u + (threadIdx.x >> 6);
+    const uint32_t base = wave * 128u + lane;
+    uint4 v[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const uint32_t q = base + i * 64u; v[i] = p[q < n16 ? q : n16 - 1u]; }
+    uint32_t lv = 0;
+    if (MODE & 1) lv = chunk_level[__builtin_amdgcn_readfirstlane(wave)] & 15u;
+    const LikeBox b = A.box[lv];
+    uint64_t any = 0;
+    if (MODE & 2) {
+        const uint32_t G = 0x20080200u, hig = b.hi | G;
+#pragma unroll
+        for (int i = 0; i < 2; i++) { const uint32_t w4[4] = { v[i].x, v[i].y, v[i].z, v[i].w };
+#pragma unroll
+            for (int h = 0; h < 4; h++) { const uint32_t x = w4[h]; const uint32_t in = ((x | G) - b.lo) & (hig - x) & G; any |= __ballot(in == G && (int32_t)x >= 0); } }
+    } else { uint32_t acc = 0; for (int i = 0; i < 2; i++) acc |= (v[i].x ^ 0x9E3779B9u) & (v[i].y ^ 0x85EBCA6Bu) & v[i].z & v[i].w; any = acc == 0xFFFFFFFFu ? 1 : 0; }
+    if (any) { lds[threadIdx.x] = (uint32_t)any; __syncthreads(); out[0] = lds[(threadIdx.x + 1) & 255]; }
+    if (MODE & 4) {
+        if (blockIdx.x * 256u < A.nsh && !A.stale) out[1] = A.words[0];
+        if (blockIdx.x == gridDim.x - 1u && !A.stale) for (uint32_t i = threadIdx.x; i < 150u; i += 256u) out[2 + i] = A.words[i];
+    }
+}
 
 template <typename F> static float median_us(F launch, hipStream_t st, int reps) {
     std::vector<float> us;
@@ -85,6 +127,16 @@ int main() {
         report("2048 B/wave, " LABEL, median_us([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(K, dim3(wgs), dim3(256), 0, st, a, b, 0, d, n16, out); }, st, 50)); }
     RES(k_res_0_32, "no LDS, 32 VGPRs") RES(k_res_0_80, "no LDS, 80 VGPRs") RES(k_res_0_128, "no LDS, 128 VGPRs")
     RES(k_res_16k_32, "16 KB LDS, 32 VGPRs") RES(k_res_16k_80, "16 KB LDS, 80 VGPRs") RES(k_res_32k_80, "32 KB LDS, 80 VGPRs")
+    {   // round 3: what a candidate-free wave of k_scan_cull adds to the read
+        uint32_t *lvl = nullptr; const uint32_t waves = (n16 + 127u) / 128u, wgs = (waves + 3u) / 4u;
+        CK(hipMalloc(&lvl, (size_t)(waves + 8) * 4)); CK(hipMemset(lvl, 0, (size_t)(waves + 8) * 4));
+        uint32_t *out2 = nullptr; CK(hipMalloc(&out2, 4096));
+        LikeArgs A{}; for (int i = 0; i < 16; i++) { A.box[i].lo = 0x1F07C1F0u; A.box[i].hi = 0x00000001u; }      // (no key of the 0x5A fill passes)
+        A.nsh = 0; A.stale = 0;
+        const uint32_t s0 = wgs / 3, c0 = wgs / 7;
+#define LIKE(M, LABEL) report("k_scan_cull-like: " LABEL, median_us([&](hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_like<M>, dim3(wgs), dim3(256), 0, st, a, b, 0, d, n16, 1u, s0, c0, 0u, 0u, 0u, 0u, 0u, 0u, (const uint32_t *)lvl, out2, A); }, st, 50));
+        LIKE(0, "read only (16 KB LDS, 1.4 KB kernarg)") LIKE(1, "+ level word -> box") LIKE(2, "+ tests and ballots") LIKE(3, "+ level word, tests") LIKE(7, "+ trailing block") LIKE(15, "+ span mapping (all)")
+    }
     STRIDE(2, 1024) STRIDE(2, 2048) STRIDE(4, 1024) STRIDE(4, 2048) STRIDE(8, 512) STRIDE(8, 1024)
     return 0;
 }
