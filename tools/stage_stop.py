@@ -16,7 +16,7 @@ for far in (1000.0, 8192.0):
     p = R.Pipeline(16384, atomic, max_instances=max(1 << 16, len(ents) // 2))
     p.register_model_instances(ents)
     cam = R.Camera((c, c, c), (0, 0, -1), far).to_c()
-    fl = F.CULL_ASYNC | (F.CULL_FORCE_LARGE_PACK if far > 2000 else 0)
+    fl = (0 if os.environ.get("SS_SYNC") else F.CULL_ASYNC) | (F.CULL_FORCE_LARGE_PACK if far > 2000 else 0)      # SS_SYNC=1: synchronous frames (the device idles between the launches)
     p.run_frames(cam, 600, 0.016, fl, F.TICK_ASYNC); p.wait()
     p.timing_begin(64, 1, kernel="scan"); p.run_frames(cam, 64, 0.016, fl, F.TICK_ASYNC); p.wait(); t = p.timing_collect()
     print("RE_EXP_STAGE_STOP=%s far %g: scan mean %.2f median %.2f min %.2f us" % (os.environ.get("RE_EXP_STAGE_STOP", "0"), far, np.mean(t), np.median(t), np.min(t)), flush=True)
