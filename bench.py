@@ -410,7 +410,7 @@ def far_leg(R, ents, atomic, centre, n_total, key_bytes):
             "kernel_us": kt,
             "launch_us": dict(own, note="each kernel's own launches (dispatch-bound HIP events); kernel_us = event pairs around the calls of synchronous frames"),
             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                         "scan": {"kernel": "k_scan_cull", "us": kt["cull"], "bytes_compulsory": b_scan, "frac": b_scan / (kt["cull"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["cull"] > 0 else None},
+                         "scan": {"kernel": "k_scan_cull_wide (the scan of frames with a large visible set: k_scan_cull with a wave's key loads requested together)", "us": kt["cull"], "bytes_compulsory": b_scan, "frac": b_scan / (kt["cull"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["cull"] > 0 else None},
                          "pack": {"kernel": "instance pack (large path)", "us": kt["pack"], "bytes_compulsory": b_pack, "frac": b_pack / (kt["pack"] * 1e-6) / 1e9 / HBM_PEAK_GBS if kt["pack"] > 0 else None},
                          "frame": {"us": dev, "bytes_compulsory": b_scan + b_pack, "frac": (b_scan + b_pack) / (dev * 1e-6) / 1e9 / HBM_PEAK_GBS if dev > 0 else None,
                                    "bytes_survey_8d": 40 * stats["n_sections"] + 8 * stats["n_entities"] + 132 * V,

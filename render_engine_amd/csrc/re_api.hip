@@ -1330,6 +1330,9 @@ static int issue_cull(re_ctx *c, const re_camera *cam, uint32_t flags) {
     else if (fuse)
         hipExtLaunchKernelGGL(k_scan_cull_fused<false>, dim3(scan_grid + c->deferred_grid), dim3(CULL_THREADS), fused_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key.p, c->ncells, SP.n | (c->deferred_grid << 8),
                               SP.start[0], SP.count[0], SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA, c->deferred);
+    else if (c->key32 && !small)      // a large visible set is expected: the schedule that has a wave's requests in flight together (k_scan_cull_wide)
+        hipExtLaunchKernelGGL(k_scan_cull_wide, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
+                              SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);
     else if (c->key32)
         hipExtLaunchKernelGGL(k_scan_cull<true>, dim3(scan_grid), dim3(CULL_THREADS), scan_lds, st, k1a, k1b, 0, (const void *)c->d_cell_key32.p, c->ncells, SP.n, SP.start[0], SP.count[0],
                               SP.start[1], SP.count[1], SP.start[2], SP.count[2], SP.start[3], SP.count[3], (const uint32_t *)c->d_chunk_level.p, SA);

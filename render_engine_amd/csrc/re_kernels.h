@@ -173,6 +173,8 @@ template <bool K32> __global__ void k_scan_cull(const void *keys, uint32_t ncell
                                                 uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A);   // the leading scalars arrive preloaded in SGPRs
 extern template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 extern template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
+__global__ void k_scan_cull_wide(const void *keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1, uint32_t s2, uint32_t c2,
+                                 uint32_t s3, uint32_t c3, const uint32_t *chunk_level, ScanCullArgs A);   // k_scan_cull<true> for frames with a large visible set
 __global__ void k_pack_small(FrameHeader *hdr, FrameHeader *hdr_next, TickHeader *th, PackArgs A, ItemSink K, uint32_t nrows);
 // One launch between the call and the host's answer for a SYNCHRONOUS frame with a small visible set: the scan, whose last workgroup to finish publishes the
 // InstanceRange table and the counts (k_pack_small then only moves the instances, stream-ordered behind it, while the host is already back).

@@ -300,7 +300,7 @@ __device__ __forceinline__ void cull_shared_section(uint32_t s, const SharedArra
 // The body of the scan + cull kernel for workgroup `bid` of `nblk` (the kernel's own grid, or the scan part of the fused launch below).
 // Force-inlined into its kernels: `A` is the kernel's by-value argument, and the kernel-argument offsets used below are those of the
 // common leading signature.
-template <bool K32>
+template <bool K32, bool EAGER = false>
 __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_t nblk, const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
                                                uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, const ScanCullArgs &A) {
     constexpr uint32_t WK = WAVE_KEYS, NB = WK / 64u, NLD = K32 ? 2u : CULL_ITERS;   // keys per wave; ballots per wave (one per key a lane holds); 16-byte loads per lane
@@ -336,7 +336,12 @@ __device__ __forceinline__ void scan_cull_body(const uint32_t bid, const uint32_
             uint4 kk[NLD];
 #pragma unroll
             for (uint32_t it = 0; it < NLD; it++) { uint32_t q = (wave_key0 >> 2) + it * 64u + lane; kk[it] = kp[q < nquads ? q : nquads - 1u]; }
-            lv0 = chunk_level[__builtin_amdgcn_readfirstlane(wave)] & (MAX_LEVELS - 1);      // scalar load, in flight together with the keys
+            const uint32_t lv_word = chunk_level[__builtin_amdgcn_readfirstlane(wave)];      // scalar load, in flight together with the keys
+            // EAGER (k_scan_cull_wide, frames with a large visible set): nothing that consumes a key is scheduled between the three requests.  Left to itself the compiler puts the
+            // first use of load 0's keys in front of load 1 (one key load in flight per wave, the level word behind the first) -- the faster stream when 1 % of the waves hold
+            // candidates (far = 1000: scan 12.2 vs 12.8 us), the slower one when half of them do (far = 8192: 29.3 vs 28.4 us).  profiles/r03_k1_code_layout.log
+            if constexpr (EAGER) __builtin_amdgcn_sched_barrier(0);
+            lv0 = lv_word & (MAX_LEVELS - 1);
             const PBox32 a0 = A.B32.box[lv0];
             const uint32_t hig = a0.hi | KEY32_GUARDS;
 #pragma unroll
@@ -528,6 +533,11 @@ __global__ __launch_bounds__(CULL_THREADS) void k_scan_cull(const void *__restri
 }
 template __global__ void k_scan_cull<false>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
 template __global__ void k_scan_cull<true>(const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, ScanCullArgs);
+// the same kernel for frames with a large visible set (compact keys): both key loads of a wave and its level word requested together (scan_cull_body: EAGER)
+__global__ __launch_bounds__(CULL_THREADS) void k_scan_cull_wide(const void *__restrict__ keys, uint32_t ncells, uint32_t nsp, uint32_t s0, uint32_t c0, uint32_t s1, uint32_t c1,
+                                                                 uint32_t s2, uint32_t c2, uint32_t s3, uint32_t c3, const uint32_t *__restrict__ chunk_level, ScanCullArgs A) {
+    scan_cull_body<true, true>(blockIdx.x, gridDim.x, keys, ncells, nsp, s0, c0, s1, c1, s2, c2, s3, c3, chunk_level, A);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Probe path (RE_CFG_PROBE): the same stage A / stage B as k_scan_cull, fed by hash probes of the candidate cells
