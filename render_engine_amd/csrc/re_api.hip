@@ -1915,6 +1915,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     const RbTables T = rb_tables(c); const RbCells C = rb_cells(c); const ShTable S = sh_table(c);
     auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm) -> int {      // by (placement key, reference order): two stable radix sorts
+        if (n <= RB2_SORT_SMALL) { hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, n, key_src, (const uint64_t *)B.ord.p, ksorted, perm); return RE_OK; }      // (one launch of one workgroup)
         size_t tb = B.tmp.n;
         HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, n, 0, 34, st));
         hipLaunchKernelGGL(k_rb_gather_keys, dim3((n + 255) / 256), dim3(256), 0, st, n, (const uint32_t *)B.perm_a.p, key_src, B.kgath.p);
@@ -1974,7 +1975,11 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
         HIPCHK(c, sync_stream(st));
         const uint32_t np = std::min(hs.n_pairs, np_max);
-        if (np) {
+        if (np && np <= RB2_SORT_SMALL) {      // (a stable sort by slot: the pair index is the tie-break, and pair i belongs to segment pair_seg[i])
+            hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, np, (const uint64_t *)B.pair_key.p, (const uint64_t *)nullptr, B.pair_key_s.p, B.perm_a.p);
+            hipLaunchKernelGGL(k_rb2_gather_u32, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint32_t *)B.perm_a.p, (const uint32_t *)B.pair_seg.p, B.pair_seg_s.p);
+            hipLaunchKernelGGL(k_rb2_static_second, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint64_t *)B.pair_key_s.p, (const uint32_t *)B.pair_seg_s.p, (const Rb2ShSeg *)B.segs_s.p, C);
+        } else if (np) {
             size_t tb = B.tmp.n;
             HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.pair_key.p, B.pair_key_s.p, B.pair_seg.p, B.pair_seg_s.p, np, 0, 32, st));
             hipLaunchKernelGGL(k_rb2_static_second, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint64_t *)B.pair_key_s.p, (const uint32_t *)B.pair_seg_s.p, (const Rb2ShSeg *)B.segs_s.p, C);
@@ -2590,7 +2595,11 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
     hipStream_t st = c->stream;
     if (c->tick_inflight) { int rc = finish_tick(c, nullptr); if (rc != RE_OK) return rc; }
     { int rc = resolve(c); if (rc != RE_OK) return rc; }
-    { int rc = sync_mirrors(c); if (rc != RE_OK) return rc; }
+    // The host mirrors of the section table (behind the device after a device-side re-bucket) are fetched only by the parts of a batch that read them: ghosts of the frozen
+    // cache, added entities, hidden / shown rows.  A batch that only writes components of non-static entities -- the per-frame re-insertion of the user entity -- does not
+    // (h_flags, which every batch reads, is never behind: the device path moves non-static rows and leaves their flags alone).
+    bool mirrors_fresh = false;
+    auto need_mirrors = [&]() -> int { if (mirrors_fresh) return RE_OK; mirrors_fresh = true; return sync_mirrors(c); };
     std::set<uint32_t> kin, trans, deleted;                                   // rows; the mover list is put in the reference's order (ascending EntityId) by rebucket()
     std::map<std::pair<uint32_t, uint32_t>, std::array<float, 4>> writes;     // (row, component) -> last value
     std::map<uint32_t, std::pair<uint32_t, uint32_t>> flag_ops;               // row -> (and-mask, or-mask)
@@ -2624,6 +2633,7 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
     auto plan_ghost = [&](uint32_t r) -> int {
         if (r >= c->n) return RE_OK;                                            // an entity this batch added: no cache entry can hold it
         if (ghosted.count(r)) return RE_OK;
+        { int rcm = need_mirrors(); if (rcm != RE_OK) return rcm; }
         ghosted.insert(r); hide.insert(r);
         if (c->h_row_nk[r] == 1) {                                              // cached by its own section -- unless that lay beyond the draw distance when the cache froze (an empty entry)
             if (cell_flags_h.empty() && c->ncells) { cell_flags_h.resize(c->ncells); HIPCHK(c, hipMemcpy(cell_flags_h.data(), c->d_cell_flags.p, c->ncells, hipMemcpyDeviceToHost)); }
@@ -2731,6 +2741,7 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
     if (trans.size() + kin.size() > c->list_cap) return c->fail(RE_E_CAPACITY, "re_apply_changes: %zu moved entities exceed the mover list (%u); split the batch", trans.size() + kin.size(), c->list_cap);
     if (c->n_ghost + ghosts.size() > c->ghost_cap) return c->fail(RE_E_CAPACITY, "re_apply_changes: more than %u ghost instances of the frozen static cache", c->ghost_cap);
     // ---- the list is valid: from here on the context changes
+    if (!new_rows.empty() || !pre.empty() || !hide.empty() || !unhide.empty() || !sortable_ops.empty() || !dyn_alloc.empty()) { int rcm = need_mirrors(); if (rcm != RE_OK) return rcm; }
     std::set<uint64_t> ghost_touched;
     if (!ghosts.empty()) {
         std::vector<Pair32> cl; cl.reserve(ghosts.size());

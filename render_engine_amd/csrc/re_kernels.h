@@ -292,6 +292,9 @@ struct Rb2Status {                                           // one block the ho
 };
 struct Rb2Seg { uint64_t key; int32_t slot; uint32_t op_begin, op_count, nl1, ns, links1; uint8_t exists0, exists1, created, freed, changed, pad[3]; };
 struct Rb2ShSeg { uint64_t pkey; uint64_t keys[8]; int32_t idx; uint32_t op_begin, op_count, na1, nst, nk; uint8_t exists0, exists1, created, freed, relink, pad[3]; };
+constexpr uint32_t RB2_SORT_SMALL = 2048;   // ops one workgroup sorts in LDS (k_rb2_sort_small: 40 KB)
+__global__ void k_rb2_sort_small(uint32_t n, const uint64_t *key, const uint64_t *ord, uint64_t *key_sorted, uint32_t *perm);
+__global__ void k_rb2_gather_u32(uint32_t n, const uint32_t *perm, const uint32_t *src, uint32_t *dst);
 __global__ void k_rb2_hash_insert(uint32_t n, ShTable S);
 __global__ void k_rb2_ops(uint32_t m, const uint32_t *movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic, uint64_t *op_key, uint64_t *op_key2, uint64_t *op_ord,
                           uint32_t *op_row, uint32_t *op_idx, uint64_t *mk, uint8_t *mnk, uint32_t *host_list, Rb2Status *st);

@@ -66,6 +66,30 @@ __global__ __launch_bounds__(256) void k_rb2_hash_insert(uint32_t n, ShTable S) 
     sh_hash_put(S, sh_id_pkey(S.keys + (size_t)s * 8, S.nk[s]), s);
 }
 
+// ---- small batches: (placement key, reference order) sorted by ONE workgroup (a bitonic network in LDS) instead of two radix sorts and a gather -- a batch of a
+// handful of movers (a change request that carries the user entity across a section border) is bound by the number of launches, not by the sorting
+__global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint64_t *__restrict__ key, const uint64_t *__restrict__ ord, uint64_t *__restrict__ key_sorted, uint32_t *__restrict__ perm) {
+    __shared__ uint64_t s_key[RB2_SORT_SMALL], s_ord[RB2_SORT_SMALL]; __shared__ uint32_t s_idx[RB2_SORT_SMALL];
+    const uint32_t tid = threadIdx.x;
+    uint32_t m = 1; while (m < n) m <<= 1;                                  // (n <= RB2_SORT_SMALL: the host chose this kernel)
+    for (uint32_t i = tid; i < m; i += 1024u) { const bool on = i < n; s_key[i] = on ? key[i] : ~0ull; s_ord[i] = on ? (ord ? ord[i] : 0ull) : ~0ull; s_idx[i] = on ? i : 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < m; i += 1024u) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const uint64_t ka = s_key[i], kb = s_key[l], oa = s_ord[i], ob = s_ord[l]; const uint32_t ia = s_idx[i], ib = s_idx[l];
+                    const bool a_gt_b = ka != kb ? ka > kb : (oa != ob ? oa > ob : ia > ib);      // (the op index last: a total order, so the network's result is the stable order)
+                    if (a_gt_b == up) { s_key[i] = kb; s_key[l] = ka; s_ord[i] = ob; s_ord[l] = oa; s_idx[i] = ib; s_idx[l] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < n; i += 1024u) { key_sorted[i] = s_key[i]; perm[i] = s_idx[i]; }
+}
+
 // ---- phase 1: two ops per mover --------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic,
                                                  uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_key2, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
@@ -350,6 +374,10 @@ __global__ __launch_bounds__(256) void k_rb2_static_second(uint32_t n, const uin
     C.cell_flags[sl] = f;
 }
 
+__global__ __launch_bounds__(256) void k_rb2_gather_u32(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
 // ---- host mirrors on demand: the state of the shared entries the device changed (re_api.hip: sync_mirrors) ----------------------------------------------------
 __global__ __launch_bounds__(256) void k_rb2_gather_shared(uint32_t n, const uint32_t *__restrict__ idxs, ShTable S, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_hdr, int32_t *__restrict__ out_cells) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
