@@ -1910,7 +1910,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         HIPCHK(c, B.tmp.alloc(std::max(t1, t2) + 256, nullptr));
         B.cap = mc;
     }
-    if (!c->d_cell_inact.p || c->d_cell_inact.n < c->ncells) HIPCHK(c, c->d_cell_inact.alloc(std::max(c->ncells, 1u), nullptr));
+    if (!c->d_cell_inact.p || c->d_cell_inact.n < c->ncells) { HIPCHK(c, c->d_cell_inact.alloc(std::max(c->ncells, 1u), nullptr)); HIPCHK(c, hipMemsetAsync(c->d_cell_inact.p, 0, std::max(c->ncells, 1u), st)); }      // (all zero between batches)
     Rb2Status hs{}; hs.pool_used = c->pool_used;
     HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     const RbTables T = rb_tables(c); const RbCells C = rb_cells(c); const ShTable S = sh_table(c);
@@ -1966,9 +1966,9 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     if (ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3((ns + 63) / 64), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p,
                                (const uint32_t *)B.free_s.p, B.tmp_s.p);
     // update_static_world_sections: first loop (changed / new unique sections), second loop (changed shared sections in canonical order)
-    HIPCHK(c, hipMemsetAsync(c->d_cell_inact.p, 0, std::max(c->ncells, 1u), st));
-    if (nsh_after) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p);
+    if (nsh_after && nu) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p, (uint8_t)1);
     if (nu) hipLaunchKernelGGL(k_rb2_static_first, dim3((nu + 255) / 256), dim3(256), 0, st, C, (const uint8_t *)c->d_cell_links.p, (const uint8_t *)c->d_cell_inact.p, (const Rb2Seg *)B.segs_u.p, (const Rb2Status *)B.status.p);
+    if (nsh_after && nu) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p, (uint8_t)0);
     if (ns) {
         hipLaunchKernelGGL(k_rb2_static_pairs, dim3((ns + 255) / 256), dim3(256), 0, st, (const Rb2ShSeg *)B.segs_s.p, (const Rb2Status *)B.status.p, S, B.pair_key.p, B.pair_seg.p, B.status.p);
         const uint32_t np_max = 8u * ns;                                      // (pairs beyond n_pairs carry stale keys: sort only what was written -- the count comes back with the status below, so sort the bound and let the kernel stop at n_pairs)
@@ -2326,10 +2326,12 @@ static int resolve(re_ctx *c) {
     { int rc = drain_other_lane(c); if (rc != RE_OK) return rc; }
     { int rc = flush_deferred_pack(c); if (rc != RE_OK) return rc; }
     HIPCHK(c, sync_stream(c->stream));
-    if (c->tick_inflight && c->ndyn && c->h_th) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }   // (stream-ordered copy)   // n_changed, n_rebucket, n_oob of the last tick that ran
+    // n_changed, n_rebucket, n_oob of the last tick that ran: a synchronous tick has published them into the mapped block itself (tick_sign_off); otherwise a stream-ordered copy
+    auto published = [&]() { return c->tick_published && c->h_th && *reinterpret_cast<const volatile uint32_t *>(&c->h_th->ticket) == c->tick_seq; };
+    if (c->tick_inflight && c->ndyn && c->h_th && !published()) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }
     while (c->h_spec && c->h_spec->stale) {
         const uint32_t sf = c->h_spec->stale_frame;
-        c->h_spec->stale = 0; HIPCHK(c, hipMemset(c->d_spec.p, 0, sizeof(SpecState)));
+        c->h_spec->stale = 0; HIPCHK(c, hipMemsetAsync(c->d_spec.p, 0, sizeof(SpecState), c->stream));      // (stream-ordered: in front of whatever is launched next)
         const TickHeader th = *c->h_th;
         if (th.n_oob) { int rc = absorb_out_of_bounds(c, th.n_oob); if (rc != RE_OK) return rc; c->n_dead += th.n_oob; }
         c->last_tick = re_tick_result{ th.n_changed, th.n_rebucket, th.n_oob };
@@ -2353,8 +2355,10 @@ static int resolve(re_ctx *c) {
             }
             c->ext_out_ids = keep_ids; c->ext_out_mats = keep_mats; c->ext_out_cap = keep_cap; c->ext_out_count = keep_cnt;
         }
-        HIPCHK(c, sync_stream(c->stream));
-        if (c->ndyn) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }
+        if (!replay.empty()) {                                              // (without a replay nothing has run since the counters above were taken)
+            HIPCHK(c, sync_stream(c->stream));
+            if (c->ndyn) { int rc_ = fetch_tick_counters(c); if (rc_ != RE_OK) return rc_; }
+        }
     }
     c->pending.clear();
     return RE_OK;

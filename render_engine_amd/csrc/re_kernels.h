@@ -304,7 +304,7 @@ __global__ void k_rb2_unique_segments(uint32_t n, const uint32_t *perm, const ui
 __global__ void k_rb2_apply_unique(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st,
                                    const uint32_t *free_slots, const uint32_t *free_off, uint32_t *tmp_row, uint32_t *refold);
 __global__ void k_rb2_apply_shared(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, ShTable S, Rb2ShSeg *segs, Rb2Status *st, const uint32_t *free_sh, uint32_t *tmp_row);
-__global__ void k_rb2_mark_inactive(uint32_t nsh, ShTable S, uint8_t *cell_inact);
+__global__ void k_rb2_mark_inactive(uint32_t nsh, ShTable S, uint8_t *cell_inact, uint8_t value);
 __global__ void k_rb2_static_first(RbCells C, const uint8_t *cell_links, const uint8_t *cell_inact, const Rb2Seg *segs, const Rb2Status *st);
 __global__ void k_rb2_static_pairs(const Rb2ShSeg *segs, const Rb2Status *st, ShTable S, uint64_t *pair_key, uint32_t *pair_seg, Rb2Status *stw);
 __global__ void k_rb2_static_second(uint32_t n, const uint64_t *slot_sorted, const uint32_t *seg_sorted, const Rb2ShSeg *segs, RbCells C);

@@ -329,10 +329,11 @@ __global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restr
 // ---- phase 4c: update_static_world_sections (bounding_box_tree_v2.rs:1133-1213) --------------------------------------------------------------------------
 // which sections a shared section WITHOUT active entities links (first loop: an empty section is a static section when nothing links it, or when one of
 // the shared sections linking it has no active entity)
-__global__ __launch_bounds__(256) void k_rb2_mark_inactive(uint32_t nsh, ShTable S, uint8_t *__restrict__ cell_inact) {
+// (value 1 in front of the first loop, value 0 behind it: the array is all zero between batches -- clearing its ncells bytes per batch was a 10 MB memset in a 10 M-section world)
+__global__ __launch_bounds__(256) void k_rb2_mark_inactive(uint32_t nsh, ShTable S, uint8_t *__restrict__ cell_inact, uint8_t value) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nsh || !S.nk[s] || S.nact[s] != 0u) return;
-    for (uint32_t k = 0; k < 8; k++) { const int32_t c = S.cells[(size_t)s * 8 + k]; if (c >= 0) cell_inact[c] = 1; }
+    for (uint32_t k = 0; k < 8; k++) { const int32_t c = S.cells[(size_t)s * 8 + k]; if (c >= 0) cell_inact[c] = value; }
 }
 __global__ __launch_bounds__(256) void k_rb2_static_first(RbCells C, const uint8_t *__restrict__ cell_links, const uint8_t *__restrict__ cell_inact, const Rb2Seg *__restrict__ segs, const Rb2Status *st) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
