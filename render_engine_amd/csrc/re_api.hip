@@ -222,6 +222,10 @@ struct re_ctx {
         uint32_t cap = 0;                                 // movers the buffers are sized for
         DevBuf<uint64_t> key, key2, ord, ord_s, kgath, ksorted1, ksorted2, mk, pair_key, pair_key_s; DevBuf<uint32_t> row, idx, perm_a, perm1, perm2, host_list, refold, tmp_u, tmp_s, free_u, free_off, free_s, pair_seg, pair_seg_s;
         DevBuf<uint8_t> mnk, tmp; DevBuf<Rb2Seg> segs_u; DevBuf<Rb2ShSeg> segs_s; DevBuf<Rb2Status> status;
+        // pinned host staging of everything that travels between the host and the device inside one batch (status blocks, free slots, the segments' outcome): copies from / to
+        // pageable memory cost 15-20 us each, and a batch made eight of them -- most of a small batch's time
+        uint8_t *pin = nullptr; size_t pin_bytes = 0;
+        Rb2Status *h_status = nullptr; uint32_t *h_free_off = nullptr, *h_free_u = nullptr, *h_free_s = nullptr, *h_keep = nullptr; Rb2Seg *h_segs_u = nullptr; Rb2ShSeg *h_segs_s = nullptr;
     } rb2;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
     uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0;
@@ -313,6 +317,7 @@ static void release_rb2(re_ctx *c) {
     for (DevBuf<uint64_t> *b : { &B.key, &B.key2, &B.ord, &B.ord_s, &B.kgath, &B.ksorted1, &B.ksorted2, &B.mk, &B.pair_key, &B.pair_key_s }) b->release(nullptr);
     for (DevBuf<uint32_t> *b : { &B.row, &B.idx, &B.perm_a, &B.perm1, &B.perm2, &B.host_list, &B.refold, &B.tmp_u, &B.tmp_s, &B.free_u, &B.free_off, &B.free_s, &B.pair_seg, &B.pair_seg_s }) b->release(nullptr);
     B.mnk.release(nullptr); B.tmp.release(nullptr); B.segs_u.release(nullptr); B.segs_s.release(nullptr); B.status.release(nullptr); B.cap = 0;
+    if (B.pin) { (void)hipHostFree(B.pin); B.pin = nullptr; B.pin_bytes = 0; }
 }
 static void free_world(re_ctx *c) {
     uint64_t *a = &c->dev_bytes;
@@ -1908,10 +1913,21 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, oc, 0, 34, st));
         HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t2, B.kgath.p, B.ksorted1.p, B.perm_a.p, B.perm1.p, oc, 0, 64, st));
         HIPCHK(c, B.tmp.alloc(std::max(t1, t2) + 256, nullptr));
+        {   // the pinned staging block, laid out for mc movers
+            auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            const size_t o_off = up(sizeof(Rb2Status)), o_fu = o_off + up(MAX_LEVELS * 4), o_fs = o_fu + up((size_t)oc * 4), o_keep = o_fs + up((size_t)2 * mc * 4),
+                         o_su = o_keep + up((size_t)mc * 4), o_ss = o_su + up((size_t)oc * sizeof(Rb2Seg)), total = o_ss + up((size_t)2 * mc * sizeof(Rb2ShSeg));
+            if (B.pin) { (void)hipHostFree(B.pin); B.pin = nullptr; }
+            void *hp = nullptr; HIPCHK(c, hipHostMalloc(&hp, total, hipHostMallocDefault));
+            B.pin = static_cast<uint8_t *>(hp); B.pin_bytes = total;
+            B.h_status = reinterpret_cast<Rb2Status *>(B.pin); B.h_free_off = reinterpret_cast<uint32_t *>(B.pin + o_off); B.h_free_u = reinterpret_cast<uint32_t *>(B.pin + o_fu);
+            B.h_free_s = reinterpret_cast<uint32_t *>(B.pin + o_fs); B.h_keep = reinterpret_cast<uint32_t *>(B.pin + o_keep);
+            B.h_segs_u = reinterpret_cast<Rb2Seg *>(B.pin + o_su); B.h_segs_s = reinterpret_cast<Rb2ShSeg *>(B.pin + o_ss);
+        }
         B.cap = mc;
     }
     if (!c->d_cell_inact.p || c->d_cell_inact.n < c->ncells) { HIPCHK(c, c->d_cell_inact.alloc(std::max(c->ncells, 1u), nullptr)); HIPCHK(c, hipMemsetAsync(c->d_cell_inact.p, 0, std::max(c->ncells, 1u), st)); }      // (all zero between batches)
-    Rb2Status hs{}; hs.pool_used = c->pool_used;
+    Rb2Status &hs = *B.h_status; hs = Rb2Status{}; hs.pool_used = c->pool_used;
     HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     const RbTables T = rb_tables(c); const RbCells C = rb_cells(c); const ShTable S = sh_table(c);
     auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm) -> int {      // by (placement key, reference order): two stable radix sorts
@@ -1946,24 +1962,24 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     // movers the host path keeps (static rows): as a second batch behind this one, only where the threshold of total_world_aabb_combining cannot depend on the split
     if (hs.n_host >= M || (hs.n_host && hs.total <= 500u)) return 1;
     std::vector<uint32_t> keep(hs.n_host);
-    if (hs.n_host) HIPCHK(c, hipMemcpy(keep.data(), B.host_list.p, (size_t)hs.n_host * 4, hipMemcpyDeviceToHost));
+    if (hs.n_host) { HIPCHK(c, hipMemcpyAsync(B.h_keep, B.host_list.p, (size_t)hs.n_host * 4, hipMemcpyDeviceToHost, st)); HIPCHK(c, sync_stream(st)); memcpy(keep.data(), B.h_keep, (size_t)hs.n_host * 4); }
     uint32_t need_total = 0;
     for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { if (hs.need_slots[l] > c->free_slots[l].size()) return 1; need_total += hs.need_slots[l]; }
     if ((uint64_t)c->pool_used + hs.need_pool > c->pool_cap) return 1;
     if (((uint64_t)c->ovl_count + need_total) * 2u > c->ovl_cap) return 1;
     if (hs.need_sh > c->sh_free.size() + (c->sh_cap - c->nsh)) return 1;      // (the host path rebuilds the table compactly and with more room)
     // ---- phase 4: free slots / free shared indices for what is created, then the patch itself
-    std::vector<uint32_t> fl, off(MAX_LEVELS, 0), fs;
-    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { off[l] = (uint32_t)fl.size(); for (uint32_t j = 0; j < hs.need_slots[l]; j++) fl.push_back(c->free_slots[l][c->free_slots[l].size() - 1u - j]); }
-    { uint32_t bump = c->nsh; for (uint32_t j = 0; j < hs.need_sh; j++) fs.push_back(j < c->sh_free.size() ? c->sh_free[c->sh_free.size() - 1u - j] : bump++); }
-    if (!fl.empty()) HIPCHK(c, hipMemcpyAsync(B.free_u.p, fl.data(), fl.size() * 4, hipMemcpyHostToDevice, st));
-    if (!fs.empty()) HIPCHK(c, hipMemcpyAsync(B.free_s.p, fs.data(), fs.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(B.free_off.p, off.data(), MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> fs; uint32_t nfl = 0;
+    for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { B.h_free_off[l] = nfl; for (uint32_t j = 0; j < hs.need_slots[l]; j++) B.h_free_u[nfl++] = c->free_slots[l][c->free_slots[l].size() - 1u - j]; }
+    { uint32_t bump = c->nsh; for (uint32_t j = 0; j < hs.need_sh; j++) { fs.push_back(j < c->sh_free.size() ? c->sh_free[c->sh_free.size() - 1u - j] : bump++); B.h_free_s[j] = fs.back(); } }
+    if (nfl) HIPCHK(c, hipMemcpyAsync(B.free_u.p, B.h_free_u, (size_t)nfl * 4, hipMemcpyHostToDevice, st));
+    if (!fs.empty()) HIPCHK(c, hipMemcpyAsync(B.free_s.p, B.h_free_s, fs.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(B.free_off.p, B.h_free_off, MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
     const uint32_t nu = hs.nseg_u, ns = hs.nseg_s;
     uint32_t nsh_after = c->nsh; for (uint32_t x : fs) nsh_after = std::max(nsh_after, x + 1u);
-    if (nu) hipLaunchKernelGGL(k_rb2_apply_unique, dim3((nu + 63) / 64), dim3(64), 0, st, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), c->d_cell_links.p, B.segs_u.p, B.status.p,
+    if (nu) hipLaunchKernelGGL(k_rb2_apply_unique, dim3(nu), dim3(64), 0, st, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), c->d_cell_links.p, B.segs_u.p, B.status.p,
                                (const uint32_t *)B.free_u.p, (const uint32_t *)B.free_off.p, B.tmp_u.p, B.refold.p);
-    if (ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3((ns + 63) / 64), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p,
+    if (ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3(ns), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p,
                                (const uint32_t *)B.free_s.p, B.tmp_s.p);
     // update_static_world_sections: first loop (changed / new unique sections), second loop (changed shared sections in canonical order)
     if (nsh_after && nu) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p, (uint8_t)1);
@@ -1989,28 +2005,30 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     if (nu) hipLaunchKernelGGL(k_fold_tight_list, dim3((nu + 255) / 256), dim3(256), 0, st, nu, (const uint32_t *)B.refold.p, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p,
                                c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
     HIPCHK(c, hipGetLastError());
-    std::vector<Rb2Seg> su(nu); std::vector<Rb2ShSeg> ss(ns); Rb2Status h2{};
+    const Rb2Status planned = hs;                                            // (the plan of the phases above; the block is read back once more below)
+    Rb2Status &h2 = *B.h_status;
     HIPCHK(c, hipMemcpyAsync(&h2, B.status.p, sizeof h2, hipMemcpyDeviceToHost, st));
-    if (nu) HIPCHK(c, hipMemcpyAsync(su.data(), B.segs_u.p, (size_t)nu * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st));
-    if (ns) HIPCHK(c, hipMemcpyAsync(ss.data(), B.segs_s.p, (size_t)ns * sizeof(Rb2ShSeg), hipMemcpyDeviceToHost, st));
+    if (nu) HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nu * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st));
+    if (ns) HIPCHK(c, hipMemcpyAsync(B.h_segs_s, B.segs_s.p, (size_t)ns * sizeof(Rb2ShSeg), hipMemcpyDeviceToHost, st));
     HIPCHK(c, sync_stream(st));
+    const Rb2Seg *su = B.h_segs_u; const Rb2ShSeg *ss = B.h_segs_s;
     lap("apply");
     // ---- what the host keeps in step at once: free slots / indices, pool fill, counts; everything else waits for sync_mirrors
     if (h2.err) return c->fail(RE_E_STATE, "device re-bucket: accounting error %u in the apply phase", h2.err);
     for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) {
-        if (h2.popped[l] != hs.need_slots[l]) return c->fail(RE_E_STATE, "device re-bucket: free-slot accounting (level %u: %u taken, %u planned)", l, h2.popped[l], hs.need_slots[l]);
-        c->free_slots[l].resize(c->free_slots[l].size() - hs.need_slots[l]);
+        if (h2.popped[l] != planned.need_slots[l]) return c->fail(RE_E_STATE, "device re-bucket: free-slot accounting (level %u: %u taken, %u planned)", l, h2.popped[l], planned.need_slots[l]);
+        c->free_slots[l].resize(c->free_slots[l].size() - planned.need_slots[l]);
     }
-    if (h2.popped_sh != hs.need_sh) return c->fail(RE_E_STATE, "device re-bucket: shared-index accounting (%u taken, %u planned)", h2.popped_sh, hs.need_sh);
-    { const uint32_t from_holes = std::min<uint32_t>(hs.need_sh, (uint32_t)c->sh_free.size()); c->sh_free.resize(c->sh_free.size() - from_holes); }
+    if (h2.popped_sh != planned.need_sh) return c->fail(RE_E_STATE, "device re-bucket: shared-index accounting (%u taken, %u planned)", h2.popped_sh, planned.need_sh);
+    { const uint32_t from_holes = std::min<uint32_t>(planned.need_sh, (uint32_t)c->sh_free.size()); c->sh_free.resize(c->sh_free.size() - from_holes); }
     int32_t delta = 0;
-    for (const Rb2Seg &G : su) {
+    for (uint32_t i2 = 0; i2 < nu; i2++) { const Rb2Seg &G = su[i2];
         if (G.slot < 0) continue;
         c->stale_slots.push_back((uint32_t)G.slot);
         if (G.freed) { c->free_slots[key_level(G.key) & (MAX_LEVELS - 1)].push_back((uint32_t)G.slot); delta--; }
         if (G.created) delta++;
     }
-    for (const Rb2ShSeg &G : ss) {
+    for (uint32_t i2 = 0; i2 < ns; i2++) { const Rb2ShSeg &G = ss[i2];
         if (G.idx < 0) continue;
         c->stale_shared.push_back((uint32_t)G.idx);
         if (G.freed) c->sh_free.push_back((uint32_t)G.idx);

@@ -251,53 +251,127 @@ __device__ __forceinline__ uint32_t rb2_rewrite_members(const uint32_t *__restri
     return na1;
 }
 
-// ---- phase 4a: the unique sections ----------------------------------------------------------------------------------------------------------------------
+// The same rewrite by a whole WAVE (round 3, second step): the serial version above walks the ops and the members with dependent loads -- two per op, one per member, the ops again for
+// every member ("does it leave?"), the ids again for every comparison of the merge -- about a hundred round trips for a section with five members and two ops, 145 us for the apply
+// phase of a batch however small.  Here lane l holds op l AND member l (both at most 64; larger placements fall back to the serial version in lane 0): every load is one round
+// trip of the wave, "leaves", the ranks among the arrivals and the merge positions are loops over lanes (shuffles, no memory), and every lane stores its element where it ends up:
+//   position of a kept active row  = its index among the kept rows + the arrivals with a smaller EntityId
+//   position of an arriving row    = its rank among the arrivals + the kept rows with a smaller EntityId          (ids are unique; the kept rows are in ascending id)
+//   position of a static row       = new active count + its index among the static rows
+struct Rb2Rewrite { uint32_t begin, cap, na1, last_row; };      // last_row: the row that ends last in the segment (active rows, then static rows), ~0 when it is empty
+__device__ __forceinline__ Rb2Rewrite rb2_rewrite_members_wave(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, uint32_t op_begin, uint32_t op_count, const RbCells &C, const RowArrays &R,
+                                                               uint32_t begin, uint32_t cap, uint32_t na0, uint32_t nst, uint32_t *__restrict__ tmp_row, Rb2Status *st, uint32_t place_word,
+                                                               bool set_key, uint64_t key) {
+    const uint32_t lane = threadIdx.x & 63u;
+    Rb2Rewrite out; out.begin = begin; out.cap = cap; out.na1 = na0; out.last_row = 0xFFFFFFFFu;
+    if (op_count > 64u || na0 + nst > 64u) {                                 // wave-uniform: a crowded placement, the serial version in lane 0
+        uint32_t b2 = begin, c2 = cap, n1 = 0, last = 0xFFFFFFFFu;
+        if (lane == 0) {
+            n1 = rb2_rewrite_members(perm, op_row, op_begin, op_count, C, R, &b2, &c2, na0, nst, tmp_row, st, place_word);
+            if (set_key) for (uint32_t q = op_begin; q < op_begin + op_count; q++) { const uint32_t w = op_row[perm[q]]; if (!(w & RB_REMOVE) && w != RB2_LINK_INC && w != RB2_LINK_DEC) C.row_key[w] = key; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (n1 + nst) last = __hip_atomic_load(&C.rows[b2 + n1 + nst - 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (this lane's own store a moment ago: past the L1)
+        }
+        out.begin = __shfl(b2, 0, 64); out.cap = __shfl(c2, 0, 64); out.na1 = __shfl(n1, 0, 64); out.last_row = __shfl(last, 0, 64);
+        return out;
+    }
+    // ---- one round trip each: the ops, the members, then the ids
+    const bool has_op = lane < op_count, has_mem = lane < na0 + nst;
+    const uint32_t w = has_op ? op_row[perm[op_begin + lane]] : 0xFFFFFFFFu;
+    const bool arrives = has_op && !(w & RB_REMOVE) && w != RB2_LINK_INC && w != RB2_LINK_DEC;
+    const uint32_t mrow = has_mem ? C.rows[begin + lane] : 0xFFFFFFFFu, mgc = has_mem ? C.rows_gc[begin + lane] : 0u;
+    const bool active = lane < na0, is_static = has_mem && !active;
+    const uint32_t aid = arrives ? R.id[w] : 0u, agc = arrives ? R.gclass[w] : 0u;
+    const uint32_t mid = active ? R.id[mrow] : 0u;
+    // ---- which active rows leave (an op "remove this row"); loops over lanes
+    bool leaves = false;
+    for (uint32_t q = 0; q < op_count; q++) { const uint32_t wq = __shfl(w, (int)q, 64); if (active && wq == (mrow | RB_REMOVE)) leaves = true; }
+    const bool kept = active && !leaves;
+    const uint64_t kmask = __ballot(kept), amask = __ballot(arrives);
+    const uint32_t nkept = (uint32_t)__popcll(kmask), narr = (uint32_t)__popcll(amask), na1 = nkept + narr, size = na1 + nst;
+    uint32_t pos_m = 0xFFFFFFFFu, pos_a = 0xFFFFFFFFu;
+    if (kept) pos_m = (uint32_t)__popcll(kmask & ((1ull << lane) - 1ull));
+    if (is_static) pos_m = na1 + (lane - na0);
+    uint32_t a_rank = 0, a_before_m = 0;
+    for (uint32_t q = 0; q < op_count; q++) {
+        const uint32_t idq = __shfl(aid, (int)q, 64); const bool aq = (amask >> q) & 1ull;
+        if (aq && arrives && idq < aid) a_rank++;
+        if (aq && kept && idq < mid) a_before_m++;
+    }
+    uint32_t k_before_a = 0;
+    for (uint32_t m2 = 0; m2 < na0; m2++) { const uint32_t idm = __shfl(mid, (int)m2, 64); if (((kmask >> m2) & 1ull) && arrives && idm < aid) k_before_a++; }
+    if (kept) pos_m += a_before_m;
+    if (arrives) pos_a = a_rank + k_before_a;
+    // ---- room: relocated to the end of the pool when the segment outgrew its capacity (the host checked the total)
+    uint32_t nb = begin, ncap = cap;
+    if (size > cap) {
+        ncap = size * 2u > 4u ? size * 2u : 4u;
+        if (lane == 0) nb = atomicAdd(&st->pool_used, ncap);
+        nb = __shfl(nb, 0, 64);
+        if ((uint64_t)nb + ncap > C.pool_cap) { if (lane == 0) st->err = 1u; return out; }      // (cannot happen)
+    }
+    // ---- every element to its place (all of them were read above: the old and the new segment may overlap)
+    if (kept || is_static) { C.rows[nb + pos_m] = mrow; C.rows_gc[nb + pos_m] = mgc; }
+    if (arrives) { C.rows[nb + pos_a] = w; C.rows_gc[nb + pos_a] = agc; C.row_cell[w] = place_word; if (set_key) C.row_key[w] = key; }
+    // the row that ends last
+    uint32_t last = 0xFFFFFFFFu;
+    if (size) {
+        const uint64_t lm = __ballot((kept || is_static) && pos_m == size - 1u), la = __ballot(arrives && pos_a == size - 1u);
+        if (lm) last = __shfl(mrow, __ffsll((long long)lm) - 1, 64); else if (la) last = __shfl(w, __ffsll((long long)la) - 1, 64);
+    }
+    out.begin = nb; out.cap = ncap; out.na1 = na1; out.last_row = last;
+    return out;
+}
+
+// ---- phase 4a: the unique sections (one WAVE per section) -------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_rb2_apply_unique(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, uint8_t *__restrict__ cell_links,
                                                          Rb2Seg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_slots, const uint32_t *__restrict__ free_off,
                                                          uint32_t *__restrict__ tmp_row, uint32_t *__restrict__ refold) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
     if (s >= st->nseg_u) return;
     Rb2Seg S = segs[s];
     const uint32_t lv = key_level(S.key) & (MAX_LEVELS - 1);
-    refold[s] = 0xFFFFFFFFu;
     if (!S.exists1) {
-        if (S.slot >= 0) {                                                    // no member and no link left: a padding slot from now on
-            const uint32_t sl = (uint32_t)S.slot;
-            C.cell_key[sl] = pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu); C.cell_key32[sl] = KEY32_PAD | 0x1FF7FDFFu;
-            C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = (uint8_t)(CF_PAD | CF_STATIC_SECTION); cell_links[sl] = 0;
-            S.freed = 1; atomicAdd(&st->n_freed, 1u); segs[s] = S;
+        if (lane == 0) {
+            refold[s] = 0xFFFFFFFFu;
+            if (S.slot >= 0) {                                                // no member and no link left: a padding slot from now on
+                const uint32_t sl = (uint32_t)S.slot;
+                C.cell_key[sl] = pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu); C.cell_key32[sl] = KEY32_PAD | 0x1FF7FDFFu;
+                C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = (uint8_t)(CF_PAD | CF_STATIC_SECTION); cell_links[sl] = 0;
+                S.freed = 1; atomicAdd(&st->n_freed, 1u); segs[s] = S;
+            }
         }
         return;
     }
-    uint32_t sl;
-    if (S.slot < 0) {
-        sl = free_slots[free_off[lv] + atomicAdd(&st->popped[lv], 1u)];
-        S.slot = (int32_t)sl; S.created = 1; atomicAdd(&st->n_created, 1u);
-        C.cell_key[sl] = S.key; C.cell_key32[sl] = (key_x(S.key) << 20) | (key_z(S.key) << 10) | key_y(S.key);
-        C.cell_stamp[sl] = 0; C.cell_cap[sl] = 0; C.cell_begin[sl] = 0; C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = 0;
-        rb_ovl_put(T, S.key, sl);
+    uint32_t sl = 0; const bool create = S.slot < 0;
+    if (create) {
+        if (lane == 0) {
+            sl = free_slots[free_off[lv] + atomicAdd(&st->popped[lv], 1u)];
+            atomicAdd(&st->n_created, 1u);
+            C.cell_key[sl] = S.key; C.cell_key32[sl] = (key_x(S.key) << 20) | (key_z(S.key) << 10) | key_y(S.key);
+            C.cell_stamp[sl] = 0; C.cell_cap[sl] = 0; C.cell_begin[sl] = 0; C.cell_nl[sl] = 0; C.cell_ns[sl] = 0; C.cell_ng[sl] = 0; C.cell_flags[sl] = 0;
+            rb_ovl_put(T, S.key, sl);
+        }
+        sl = __shfl(sl, 0, 64); S.slot = (int32_t)sl; S.created = 1;
     } else sl = (uint32_t)S.slot;
-    cell_links[sl] = (uint8_t)(S.links1 > 255u ? 255u : S.links1);
+    if (lane == 0) cell_links[sl] = (uint8_t)(S.links1 > 255u ? 255u : S.links1);
     if (S.changed) {
-        uint32_t begin = C.cell_begin[sl], cap = C.cell_cap[sl];
-        const uint32_t nl1 = rb2_rewrite_members(perm, op_row, S.op_begin, S.op_count, C, R, &begin, &cap, C.cell_nl[sl], C.cell_ns[sl], tmp_row, st, sl);
-        C.cell_begin[sl] = begin; C.cell_cap[sl] = cap; C.cell_nl[sl] = nl1;
-        // (the rows that arrived: the key of their own section, streamed by the tick)
-        for (uint32_t q = S.op_begin; q < S.op_begin + S.op_count; q++) { const uint32_t w = op_row[perm[q]]; if (!(w & RB_REMOVE) && w != RB2_LINK_INC && w != RB2_LINK_DEC) C.row_key[w] = S.key; }
-        S.nl1 = nl1;
+        const uint32_t begin = create ? 0u : C.cell_begin[sl], cap = create ? 0u : C.cell_cap[sl], nl0 = create ? 0u : C.cell_nl[sl], ns0 = create ? 0u : C.cell_ns[sl];
+        const Rb2Rewrite r = rb2_rewrite_members_wave(perm, op_row, S.op_begin, S.op_count, C, R, begin, cap, nl0, ns0, tmp_row, st, sl, true, S.key);
+        if (lane == 0) { C.cell_begin[sl] = r.begin; C.cell_cap[sl] = r.cap; C.cell_nl[sl] = r.na1; }
+        S.nl1 = r.na1;
     }
-    segs[s] = S;
-    if (S.changed || S.created) refold[s] = sl;                              // end_of_changes / update_static_world_sections touch the changed (and the new) sections
+    if (lane == 0) { segs[s] = S; refold[s] = (S.changed || S.created) ? sl : 0xFFFFFFFFu; }      // end_of_changes / update_static_world_sections touch the changed (and the new) sections
 }
 
-// ---- phase 4b: the shared sections (stable indices: a retired entry is a hole, a new one takes a free index the host handed over) ---------------------------
+// ---- phase 4b: the shared sections (stable indices: a retired entry is a hole, a new one takes a free index the host handed over); one WAVE per section ---------
 __global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, ShTable S,
                                                          Rb2ShSeg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_sh, uint32_t *__restrict__ tmp_row) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = blockIdx.x, lane = threadIdx.x;
     if (s >= st->nseg_s) return;
     Rb2ShSeg G = segs[s];
     if (!G.exists1) {
-        if (G.idx >= 0) {
+        if (G.idx >= 0 && lane == 0) {
             const uint32_t idx = (uint32_t)G.idx;
             for (uint32_t h = rb_hash(G.pkey) & S.hmask;; h = (h + 1u) & S.hmask) { const unsigned long long k = S.hkeys[h]; if (k == ~0ull) break; if (k == G.pkey) { S.hidx[h] = 0xFFFFFFFFu; break; } }
             S.nact[idx] = 0; S.nstat[idx] = 0; S.nk[idx] = 0; S.owner[idx] = -1; S.cached[idx] = 0; S.dirty[idx] = 0;
@@ -306,24 +380,29 @@ __global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restr
         }
         return;
     }
-    uint32_t idx;
-    if (G.idx < 0) {
-        idx = free_sh[atomicAdd(&st->popped_sh, 1u)];
-        G.idx = (int32_t)idx; G.created = 1; atomicAdd(&st->n_sh_created, 1u);
-        S.nk[idx] = (uint8_t)G.nk; for (uint32_t k = 0; k < 8; k++) S.keys[(size_t)idx * 8 + k] = G.keys[k];
-        S.begin[idx] = 0; S.rowcap[idx] = 0; S.nact[idx] = 0; S.nstat[idx] = 0; S.owner[idx] = -1; S.cached[idx] = 0; S.dirty[idx] = 0;
-        sh_hash_put(S, G.pkey, idx);
+    uint32_t idx = 0; const bool create = G.idx < 0;
+    if (create) {
+        if (lane == 0) {
+            idx = free_sh[atomicAdd(&st->popped_sh, 1u)];
+            atomicAdd(&st->n_sh_created, 1u);
+            S.nk[idx] = (uint8_t)G.nk; for (uint32_t k = 0; k < 8; k++) S.keys[(size_t)idx * 8 + k] = G.keys[k];
+            S.begin[idx] = 0; S.rowcap[idx] = 0; S.nact[idx] = 0; S.nstat[idx] = 0; S.owner[idx] = -1; S.cached[idx] = 0; S.dirty[idx] = 0;
+            sh_hash_put(S, G.pkey, idx);
+        }
+        idx = __shfl(idx, 0, 64); G.idx = (int32_t)idx; G.created = 1;
     } else idx = (uint32_t)G.idx;
-    if (G.relink || G.created)                                               // (a section emptied and refilled within the batch may find a linked section in another slot)
-        for (uint32_t k = 0; k < 8; k++) { int32_t c = -1; if (k < G.nk) { c = rb_find(T, C.cell_key, G.keys[k]); if (c < 0) st->err = 2u; } S.cells[(size_t)idx * 8 + k] = c; }
-    uint32_t begin = S.begin[idx], cap = S.rowcap[idx];
-    const uint32_t na1 = rb2_rewrite_members(perm, op_row, G.op_begin, G.op_count, C, R, &begin, &cap, S.nact[idx], S.nstat[idx], tmp_row, st, ROW_CELL_SHARED | idx);
-    S.begin[idx] = begin; S.rowcap[idx] = cap; S.nact[idx] = na1;
-    const uint32_t nm = na1 + S.nstat[idx];                                   // end_of_changes, shared branch (:1104-1125): the AABB of the last entity iterated (entities, then static_entities)
-    Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    if (nm) u = R.aabb[C.rows[begin + nm - 1u]];
-    S.aabb[idx] = u;
-    G.na1 = na1; segs[s] = G;
+    if (G.relink || G.created) {                                             // (a section emptied and refilled within the batch may find a linked section in another slot); lane k looks key k up
+        if (lane < 8u) { int32_t c = -1; if (lane < G.nk) { c = rb_find(T, C.cell_key, G.keys[lane]); if (c < 0) st->err = 2u; } S.cells[(size_t)idx * 8 + lane] = c; }
+    }
+    const uint32_t begin = create ? 0u : S.begin[idx], cap = create ? 0u : S.rowcap[idx], na0 = create ? 0u : S.nact[idx], nst = create ? 0u : S.nstat[idx];
+    const Rb2Rewrite r = rb2_rewrite_members_wave(perm, op_row, G.op_begin, G.op_count, C, R, begin, cap, na0, nst, tmp_row, st, ROW_CELL_SHARED | idx, false, 0ull);
+    if (lane == 0) {
+        S.begin[idx] = r.begin; S.rowcap[idx] = r.cap; S.nact[idx] = r.na1;
+        Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };                               // end_of_changes, shared branch (:1104-1125): the AABB of the last entity iterated (entities, then static_entities)
+        if (r.last_row != 0xFFFFFFFFu) u = R.aabb[r.last_row];
+        S.aabb[idx] = u;
+        G.na1 = r.na1; segs[s] = G;
+    }
 }
 
 // ---- phase 4c: update_static_world_sections (bounding_box_tree_v2.rs:1133-1213) --------------------------------------------------------------------------
