@@ -257,6 +257,70 @@ impl GpuVisibleSet {
     }
 }
 
+/// `UniqueWorldSectionId` (world/bounding_box_tree_v2.rs:21-26) <-> the library's packed key `level:16 | x:16 | z:16 | y:16`
+pub fn section_key_parts(key: u64) -> (u16, u16, u16, u16) { ((key >> 48) as u16, (key >> 32) as u16, (key >> 16) as u16, key as u16) }      // (level, x, z, y)
+
+impl GpuVisibleSet {
+    /// The CONTENT of `CullResult` (flows/visible_world_flow.rs:17-36) for callers that do want the ids -- debug overlays, `debug_execute`, tests:
+    /// `.0` = `visible_sections_map` (every visible section once, ascending key), `.1` = `visible_sections_vec` (a section found by both the logic and the render
+    /// culler appears twice, as in the reference's concatenation, pipeline.rs:222-229).  Build the crate's types with `section_key_parts`:
+    /// `UniqueWorldSectionId::new(level, SectionOffsets{ x, z, y })`.  A device read-back: not for the per-frame path (use `cull_result` there).
+    pub fn cull_result_sections(&mut self, frame: &Frame) -> Result<(Vec<u64>, Vec<u64>), GpuError> {
+        let cap = frame.visible_sections.max(1);
+        let mut keys = vec![0u64; cap as usize]; let mut mult = vec![0u8; cap as usize]; let mut n = 0u32;
+        self.check(unsafe { re_debug_get_visible_sections(self.ctx, cap, keys.as_mut_ptr(), mult.as_mut_ptr(), &mut n) })?;
+        keys.truncate(n.min(cap) as usize); mult.truncate(n.min(cap) as usize);
+        let mut vec_ids = Vec::with_capacity(frame.visible_sections_vec as usize);
+        for (k, m) in keys.iter().zip(mult.iter()) { for _ in 0..*m { vec_ids.push(*k); } }
+        Ok((keys, vec_ids))
+    }
+}
+
+/// History / replay files of a session (threads/history_thread.rs:150-205, helper_things/game_loader.rs:32-71): the `FrameChange` stream in the reference's
+/// bincode layout; the ECS / tree blobs in front of it pass through as opaque bytes.  Host code only -- no GPU context involved.
+pub struct History { h: *mut ReHistory }
+impl History {
+    /// `ids`: the `TypeIdentifier` bits of the running build, e.g. `TypeIdentifier::from(TypeId::of::<Position>())` (objects/ecs.rs:97-110)
+    pub fn new(ids: &ReTypeIds) -> Result<History, GpuError> {
+        let mut h: *mut ReHistory = std::ptr::null_mut();
+        let rc = unsafe { re_history_create(ids, 0, &mut h) };
+        if rc != RE_OK { return Err(GpuError { code: rc, message: String::from("re_history_create failed") }); }
+        Ok(History { h })
+    }
+    /// GameLoadResult::load: reads the pair `gameplay_history.txt` / `gameplay_byte_lookup.txt`
+    pub fn load(ids: &ReTypeIds, history_path: &str, lookup_path: &str) -> Result<History, GpuError> {
+        let (hp, lp) = (std::ffi::CString::new(history_path).unwrap(), std::ffi::CString::new(lookup_path).unwrap());
+        let mut h: *mut ReHistory = std::ptr::null_mut();
+        let rc = unsafe { re_history_load(ids, 0, hp.as_ptr(), lp.as_ptr(), &mut h) };
+        if rc != RE_OK { return Err(GpuError { code: rc, message: format!("re_history_load({}) failed", history_path) }); }
+        Ok(History { h })
+    }
+    fn check(&self, rc: i32) -> Result<(), GpuError> {
+        if rc == RE_OK { return Ok(()); }
+        let p = unsafe { re_history_last_error(self.h) };
+        Err(GpuError { code: rc, message: if p.is_null() { String::new() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() } })
+    }
+    /// the serialized ECS and BoundingBoxTree the reference writes in front of the records (opaque here)
+    pub fn set_state(&mut self, ecs_blob: &[u8], tree_blob: &[u8]) -> Result<(), GpuError> {
+        self.check(unsafe { re_history_set_state(self.h, ecs_blob.as_ptr() as *const std::ffi::c_void, ecs_blob.len() as u64, tree_blob.as_ptr() as *const std::ffi::c_void, tree_blob.len() as u64) })
+    }
+    /// HistoryThread's per-frame record (one `FrameChange`: a camera / window change or the frame's `EntityChange` list as `ReChange`s)
+    pub fn record(&mut self, fc: &ReFrameChange) -> Result<(), GpuError> { self.check(unsafe { re_history_record(self.h, fc) }) }
+    pub fn len(&mut self) -> Result<u32, GpuError> { let mut n = 0u32; self.check(unsafe { re_history_count(self.h, &mut n) })?; Ok(n) }
+    /// record `index`; its `changes` pointer stays valid until the next call on this object (feed it to `GpuVisibleSet::apply_changes` in a replay loop, pipeline.rs:279-421)
+    pub fn get(&mut self, index: u32) -> Result<ReFrameChange, GpuError> {
+        let mut fc = MaybeUninit::<ReFrameChange>::uninit();
+        self.check(unsafe { re_history_get(self.h, index, fc.as_mut_ptr()) })?;
+        Ok(unsafe { fc.assume_init() })
+    }
+    /// HistoryThread::write_to_disk: the history file and its byte-offset lookup file
+    pub fn write(&mut self, history_path: &str, lookup_path: &str) -> Result<(), GpuError> {
+        let (hp, lp) = (std::ffi::CString::new(history_path).unwrap(), std::ffi::CString::new(lookup_path).unwrap());
+        self.check(unsafe { re_history_write(self.h, hp.as_ptr(), lp.as_ptr()) })
+    }
+}
+impl Drop for History { fn drop(&mut self) { if !self.h.is_null() { unsafe { re_history_destroy(self.h) }; self.h = std::ptr::null_mut(); } } }
+
 impl Drop for GpuVisibleSet {
     fn drop(&mut self) { if !self.ctx.is_null() { unsafe { re_destroy(self.ctx) }; self.ctx = std::ptr::null_mut(); } }
 }
