@@ -1828,8 +1828,9 @@ static int sync_shared_mirrors(re_ctx *c) {
 
 static bool device_rebucket_applicable(const re_ctx *c) {
     static const bool off = getenv("RE_EXP_HOST_REBUCKET") != nullptr;         // A/B switch of tools/rebucket_cost.py
-    return !off && c->ncells && c->ghost_map.empty() && c->h_uncached.empty() && c->dormant_cached.empty()
-           && !(c->cfg.flags & (RE_CFG_PROBE | RE_CFG_FULL_REBUILD));
+    // (worlds whose frozen render cache holds ghost instances or hidden rows are eligible since round 3: a batch falls back only when it changes a section that parks
+    // ghosts -- k_rb2_unique_segments -- or creates / retires a section whose key the host's ghost books know -- rebucket_on_device2; hidden rows are static and never move here)
+    return !off && c->ncells && !(c->cfg.flags & (RE_CFG_PROBE | RE_CFG_FULL_REBUILD));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1959,6 +1960,14 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     HIPCHK(c, sync_stream(st));
     lap("unique");
     if (hs.fallback) return 1;
+    if (!c->ghost_map.empty() || !c->dormant_cached.empty()) {               // sections this batch would create or retire: none may be one the ghost books of the frozen cache know
+        const uint32_t nq = hs.nseg_u;
+        if (nq) { HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nq * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st)); HIPCHK(c, sync_stream(st)); }
+        for (uint32_t i2 = 0; i2 < nq; i2++) {
+            const Rb2Seg &G = B.h_segs_u[i2];
+            if (G.exists0 != G.exists1 && (c->ghost_map.count(G.key) || c->dormant_cached.count(G.key))) return 1;
+        }
+    }
     // movers the host path keeps (static rows): as a second batch behind this one, only where the threshold of total_world_aabb_combining cannot depend on the split
     if (hs.n_host >= M || (hs.n_host && hs.total <= 500u)) return 1;
     std::vector<uint32_t> keep(hs.n_host);

@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void k_rb2_unique_segments(uint32_t n, const u
     segs[atomicAdd(&st->nseg_u, 1u)] = S;
     if (total) atomicAdd(&st->total, total);
     if (links > 254u) st->fallback = 1u;
+    if (slot >= 0 && (changed || !exists) && C.cell_ng[slot] != 0u) st->fallback = 1u;     // ghost instances of the frozen render cache are parked in this section: the host path keeps their books
     if (exists) {
         const uint32_t size = nl + ns;
         if (slot < 0) atomicAdd(&st->need_slots[key_level(key) & (MAX_LEVELS - 1)], 1u);
