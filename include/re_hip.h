@@ -400,7 +400,7 @@ typedef struct {
     uint32_t n_segment_redos;    /* frames issued a second time because clustered world sections overflowed one cursor segment of the instance list: the frame is redone
                                   * with the list as one segment (which holds every instance of the world twice), and the context keeps that layout until the next upload */
     uint32_t n_host_rebuckets;  /* batches of section changes (or the rest of one the device took in part) whose bookkeeping ran on the host: change-request batches, static movers,
-                                 * worlds with ghost instances of the frozen render cache, a table without slack */
+                                 * batches that touch a section parking ghost instances of the frozen render cache, a table without slack */
 } re_stats;
 int re_get_stats(re_ctx *ctx, re_stats *out);
 /* world sections in ascending key order: key = level<<48 | x<<32 | z<<16 | y (UniqueWorldSectionId field order,
