@@ -1868,7 +1868,7 @@ static int ensure_device_shared(re_ctx *c) {
     c->rb_sh_dirty = false; c->sh_hash_used = n - (uint32_t)c->sh_free.size();
     return RE_OK;
 }
-static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *host_list) {
+static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *host_list, uint32_t n_deleted = 0) {      // n_deleted: rows of a DeleteRequest behind the M movers of the list (RB2_MOVER_DELETED)
     host_list->clear();
     if (!M || !device_rebucket_applicable(c)) return 1;
     hipStream_t st = c->stream;
@@ -1911,7 +1911,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         HIPCHK(c, B.pair_key.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_key_s.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_seg.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_seg_s.alloc(16u * mc, nullptr));
         if (!B.status.p) HIPCHK(c, B.status.alloc(1, nullptr));
         size_t t1 = 0, t2 = 0;
-        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, oc, 0, 34, st));
+        HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, oc, 0, 35, st));
         HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t2, B.kgath.p, B.ksorted1.p, B.perm_a.p, B.perm1.p, oc, 0, 64, st));
         HIPCHK(c, B.tmp.alloc(std::max(t1, t2) + 256, nullptr));
         {   // the pinned staging block, laid out for mc movers
@@ -1934,7 +1934,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm) -> int {      // by (placement key, reference order): two stable radix sorts
         if (n <= RB2_SORT_SMALL) { hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, n, key_src, (const uint64_t *)B.ord.p, ksorted, perm); return RE_OK; }      // (one launch of one workgroup)
         size_t tb = B.tmp.n;
-        HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, n, 0, 34, st));
+        HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, n, 0, 35, st));
         hipLaunchKernelGGL(k_rb_gather_keys, dim3((n + 255) / 256), dim3(256), 0, st, n, (const uint32_t *)B.perm_a.p, key_src, B.kgath.p);
         tb = B.tmp.n;
         HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.kgath.p, ksorted, B.perm_a.p, perm, n, 0, 64, st));
@@ -1969,7 +1969,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         }
     }
     // movers the host path keeps (static rows): as a second batch behind this one, only where the threshold of total_world_aabb_combining cannot depend on the split
-    if (hs.n_host >= M || (hs.n_host && hs.total <= 500u)) return 1;
+    if (hs.n_host >= M || (hs.n_host && hs.total <= 500u) || (hs.n_host && n_deleted)) return 1;      // (a batch with deletions is not split: the host's second batch would count them again)
     std::vector<uint32_t> keep(hs.n_host);
     if (hs.n_host) { HIPCHK(c, hipMemcpyAsync(B.h_keep, B.host_list.p, (size_t)hs.n_host * 4, hipMemcpyDeviceToHost, st)); HIPCHK(c, sync_stream(st)); memcpy(keep.data(), B.h_keep, (size_t)hs.n_host * 4); }
     uint32_t need_total = 0;
@@ -2013,6 +2013,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     // end_of_changes: tight AABBs of the changed sections (bounding_box_tree_v2.rs:1055-1130)
     if (nu) hipLaunchKernelGGL(k_fold_tight_list, dim3((nu + 255) / 256), dim3(256), 0, st, nu, (const uint32_t *)B.refold.p, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p,
                                c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
+    if (n_deleted) hipLaunchKernelGGL(k_rb2_clear_deleted, dim3((M + 255) / 256), dim3(256), 0, st, M, (const uint32_t *)c->d_movers.p, c->d_row_cell.p);
     HIPCHK(c, hipGetLastError());
     const Rb2Status planned = hs;                                            // (the plan of the phases above; the block is read back once more below)
     Rb2Status &h2 = *B.h_status;
@@ -2075,10 +2076,24 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
         c->moved_rows.resize(at + m0);
         HIPCHK(c, hipMemcpy(c->moved_rows.data() + at, c->d_movers.p, (size_t)m0 * 4, hipMemcpyDeviceToHost));
     }
-    if ((!pre || pre->empty()) && (!ghost_touched || ghost_touched->empty())) {     // a tick's movers, or a change batch that only moved entities (no make-static / wake-up / delete / add, no ghost of the frozen cache touched)
-        int drc = rebucket_on_device2(c, n_movers, &movers);
+    // The device takes a tick's movers, and a change batch that moved and / or DELETED non-static entities (no make-static / wake-up / add, no ghost of the frozen cache touched):
+    // the deleted rows are appended to the mover list (RB2_MOVER_DELETED) in the order of the batch.
+    bool only_deletes = true; uint32_t n_del = 0;
+    if (pre) for (const TreeOp &op : *pre) { if (op.kind != 3 || (c->h_flags[op.row] & F_STATIC)) { only_deletes = false; break; } n_del++; }
+    if (only_deletes && (!ghost_touched || ghost_touched->empty()) && n_movers + n_del <= c->list_cap && (n_movers + n_del) != 0) {
+        if (n_del) {
+            std::vector<uint32_t> del; del.reserve(n_del);
+            for (const TreeOp &op : *pre) del.push_back(op.row | RB2_MOVER_DELETED);
+            HIPCHK(c, hipMemcpyAsync(c->d_movers.p + n_movers, del.data(), (size_t)n_del * 4, hipMemcpyHostToDevice, st));
+            HIPCHK(c, sync_stream(st));                                       // (`del` goes out of scope)
+        }
+        int drc = rebucket_on_device2(c, n_movers + n_del, &movers, n_del);
         if (drc < 0) return drc;
-        if (drc == 0) { if (movers.empty()) return RE_OK; second_batch = true; }
+        if (drc == 0) {
+            for (uint32_t i2 = 0; i2 < n_del; i2++) { const uint32_t r = (*pre)[i2].row; c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 0; c->h_row_key[r] = 0; c->h_row_cell[r] = ROW_CELL_NONE; }      // (in no section: no later sync_mirrors will look at them)
+            if (movers.empty()) return RE_OK;
+            second_batch = true; pre = nullptr;                               // (the deletions are done; cannot happen with deletions: such a batch is not split)
+        }
     }
     c->n_host_rebuckets++;
     { int src = sync_mirrors(c); if (src != RE_OK) return src; }

@@ -91,12 +91,28 @@ __global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint6
 }
 
 // ---- phase 1: two ops per mover --------------------------------------------------------------------------------------------------------------
+// The list may end with the rows a change batch DELETES (RB2_MOVER_DELETED; DeleteRequest -> remove_entity, entity_change_helpers.rs:109-136): they only have a remove op, ordered in
+// front of every mover in the order of the batch (apply_change removes them inline, before the kinematic re-adds).
 __global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic,
                                                  uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_key2, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
                                                  uint32_t *__restrict__ op_idx, uint64_t *__restrict__ mk, uint8_t *__restrict__ mnk, uint32_t *__restrict__ host_list, Rb2Status *st) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    const uint32_t w = movers[i], r = w & 0x7FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
+    if (movers[i] & RB2_MOVER_DELETED) {
+        const uint32_t r = movers[i] & 0x3FFFFFFFu, rc = C.row_cell[r];
+        uint64_t pold = ~0ull;                                              // (an entity that is in no section -- it left the world earlier -- has nothing to remove)
+        if (rc != ROW_CELL_NONE) {
+            if (rc & ROW_CELL_SHARED) { const uint32_t s = rc & ~ROW_CELL_SHARED; if (s < S.cap && S.nk[s]) pold = sh_id_pkey(S.keys + (size_t)s * 8, S.nk[s]); else st->fallback = 1u; }
+            else pold = C.cell_key[rc];
+        }
+        for (int k = 0; k < 8; k++) mk[(size_t)i * 8 + k] = 0ull;
+        mnk[i] = 0;
+        op_key[2 * i] = pold; op_ord[2 * i] = (uint64_t)i << 1; op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
+        op_key[2 * i + 1] = ~0ull; op_ord[2 * i + 1] = ((uint64_t)i << 1) | 1ull; op_row[2 * i + 1] = r; op_idx[2 * i + 1] = 2 * i + 1;
+        op_key2[2 * i] = (pold & RB2_SHARED_BIT) ? ~0ull : pold; op_key2[2 * i + 1] = ~0ull;
+        return;
+    }
+    const uint32_t w = movers[i], r = w & 0x3FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
     Aabb bv = R.aabb[r];
     normalize_aabb(&bv, (float)outline);
     uint64_t keys[8];
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__r
     }
     for (int k = 0; k < 8; k++) mk[(size_t)i * 8 + k] = k < nk ? keys[k] : 0ull;
     mnk[i] = (uint8_t)(nk < 0 ? 0 : nk);
-    const uint64_t ord = ((uint64_t)((w >> 31) ? 0u : 1u) << 33) | ((uint64_t)R.id[r] << 1);   // translation-only movers first, then ascending EntityId; remove before add
+    const uint64_t ord = (1ull << 34) | ((uint64_t)((w >> 31) ? 0u : 1u) << 33) | ((uint64_t)R.id[r] << 1);   // (behind the batch's deletions) translation-only movers first, then ascending EntityId; remove before add
     op_key[2 * i] = pold; op_ord[2 * i] = ord; op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
     op_key[2 * i + 1] = pnew; op_ord[2 * i + 1] = ord | 1ull; op_row[2 * i + 1] = r; op_idx[2 * i + 1] = 2 * i + 1;
     // the second sort (unique placements + the link ops of the shared ones) leaves the shared placements' member ops behind every section
@@ -458,6 +474,10 @@ __global__ __launch_bounds__(256) void k_rb2_static_second(uint32_t n, const uin
 __global__ __launch_bounds__(256) void k_rb2_gather_u32(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[perm[i]];
+}
+__global__ __launch_bounds__(256) void k_rb2_clear_deleted(uint32_t n, const uint32_t *__restrict__ movers, uint32_t *__restrict__ row_cell) {      // the deleted rows are in no section any more
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (movers[i] & RB2_MOVER_DELETED)) row_cell[movers[i] & 0x3FFFFFFFu] = ROW_CELL_NONE;
 }
 // ---- host mirrors on demand: the state of the shared entries the device changed (re_api.hip: sync_mirrors) ----------------------------------------------------
 __global__ __launch_bounds__(256) void k_rb2_gather_shared(uint32_t n, const uint32_t *__restrict__ idxs, ShTable S, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_hdr, int32_t *__restrict__ out_cells) {

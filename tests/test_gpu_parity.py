@@ -942,6 +942,39 @@ def test_rebucket_on_the_device(R, straddlers):
     p.close(); w.close()
 
 
+def test_delete_and_move_batches_on_the_device(R):
+    """change batches that move and DELETE non-static entities (DeleteRequest -> remove_entity inline, before the kinematic re-adds): the tree bookkeeping of the whole
+    batch runs on the device -- the deleted rows ride at the end of the mover list with a remove op only, ordered in front of every mover.  Entities in unique and in
+    shared sections, sections emptied by a deletion and re-created by a mover of the same batch; compared with the oracle after every batch."""
+    ents = hopping_world(R, dims=(10, 10, 10), first=123)
+    mv = np.nonzero((ents["flags"] & R.F_HAS_VEL) != 0)[0]
+    for k, i in enumerate(mv[::7]):                                             # some wide movers: members of shared sections
+        h = np.float32(22.0 + 6.0 * (k % 3)); ents["original"][i] = (-h, h, -h, h, -h, h)
+    p, w = build_pair(R, ents)
+    rng = np.random.default_rng(9)
+    C = R._capi
+    alive = list(ents["id"][mv])
+    cam = R.Camera((8192, 8192, 8192 + 2200), (0, 0, -1), 5000.0)
+    for f in range(6):
+        check_frame(R, p, w, cam, f % 2 == 0)
+        n_o, oob_o = w.tick(oracle_camera(cam), 1.0); t = p.tick(1.0)
+        assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o) == 0
+        host_before = p.stats()["n_host_rebuckets"]
+        rng.shuffle(alive)
+        dele, move = alive[:12], alive[12:40]; alive = alive[12:]
+        ch = np.zeros(len(dele) + len(move), R.CHANGE_DT); o = 0
+        for k in range(max(len(dele), len(move))):                               # deletions and moves interleaved in the list
+            if k < len(move): ch[o] = (C.CHANGE_MODIFY, move[k], C.C_POSITION, 0, (64.0 * (123 + int(rng.integers(0, 10))) + 32.0, 64.0 * (123 + int(rng.integers(0, 10))) + 32.0, 64.0 * (123 + int(rng.integers(0, 10))) + 32.0, 0)); o += 1
+            if k < len(dele): ch[o] = (C.CHANGE_DELETE, dele[k], 0, 0, (0, 0, 0, 0)); o += 1
+        n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT)); g = p.apply_changes(ch)
+        assert g["n_changed"] == n_a and g["n_out_of_bounds"] == len(oob_a)
+        assert p.stats()["n_host_rebuckets"] == host_before, "a batch of moves and deletions of non-static entities left the device path"
+        check_sections(p, w)
+    check_entities(R, p, w, ents[::3])
+    check_frame(R, p, w, cam, True)
+    p.close(); w.close()
+
+
 def test_one_launch_synchronous_frames(R):
     """RE_CULL_ONE_LAUNCH: the scan's last workgroup publishes the frame's result itself (k_scan_cull_sync: ticket over the workgroups, list entries written
     through to memory, one wave builds the InstanceRange table), k_pack_small only moves the instances.  Frames with movers, shared sections, duplicates
