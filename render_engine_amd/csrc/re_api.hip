@@ -228,7 +228,7 @@ struct re_ctx {
         Rb2Status *h_status = nullptr; uint32_t *h_free_off = nullptr, *h_free_u = nullptr, *h_free_s = nullptr, *h_keep = nullptr; Rb2Seg *h_segs_u = nullptr; Rb2ShSeg *h_segs_s = nullptr;
     } rb2;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
-    uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0;
+    uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0, last_added_rejected = 0;
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -2078,19 +2078,27 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     }
     // The device takes a tick's movers, and a change batch that moved and / or DELETED non-static entities (no make-static / wake-up / add, no ghost of the frozen cache touched):
     // the deleted rows are appended to the mover list (RB2_MOVER_DELETED) in the order of the batch.
-    bool only_deletes = true; uint32_t n_del = 0;
-    if (pre) for (const TreeOp &op : *pre) { if (op.kind != 3 || (c->h_flags[op.row] & F_STATIC)) { only_deletes = false; break; } n_del++; }
+    bool only_deletes = true; uint32_t n_del = 0;                             // (deletions and additions of non-static entities)
+    if (pre) for (const TreeOp &op : *pre) {
+        bool ok = (op.kind == 3 && !(c->h_flags[op.row] & F_STATIC));
+        if (op.kind == 4) { auto ak = c->add_keys.find(op.row); ok = ak != c->add_keys.end() && !ak->second.is_static && !(c->h_flags[op.row] & F_STATIC); }
+        if (!ok) { only_deletes = false; break; }
+        n_del++;
+    }
     if (only_deletes && (!ghost_touched || ghost_touched->empty()) && n_movers + n_del <= c->list_cap && (n_movers + n_del) != 0) {
         if (n_del) {
             std::vector<uint32_t> del; del.reserve(n_del);
-            for (const TreeOp &op : *pre) del.push_back(op.row | RB2_MOVER_DELETED);
+            for (const TreeOp &op : *pre) del.push_back(op.row | (op.kind == 4 ? RB2_MOVER_ADDED : RB2_MOVER_DELETED));
             HIPCHK(c, hipMemcpyAsync(c->d_movers.p + n_movers, del.data(), (size_t)n_del * 4, hipMemcpyHostToDevice, st));
             HIPCHK(c, sync_stream(st));                                       // (`del` goes out of scope)
         }
         int drc = rebucket_on_device2(c, n_movers + n_del, &movers, n_del);
         if (drc < 0) return drc;
         if (drc == 0) {
-            for (uint32_t i2 = 0; i2 < n_del; i2++) { const uint32_t r = (*pre)[i2].row; c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 0; c->h_row_key[r] = 0; c->h_row_cell[r] = ROW_CELL_NONE; }      // (in no section: no later sync_mirrors will look at them)
+            for (uint32_t i2 = 0; i2 < n_del; i2++) {                         // (a deleted row is in no section: no later sync_mirrors will look at it; an added one is a member of a noted section)
+                if ((*pre)[i2].kind != 3) continue;
+                const uint32_t r = (*pre)[i2].row; c->h_row_shared_keys.erase(r); c->h_row_nk[r] = 0; c->h_row_key[r] = 0; c->h_row_cell[r] = ROW_CELL_NONE;
+            }
             if (movers.empty()) return RE_OK;
             second_batch = true; pre = nullptr;                               // (the deletions are done; cannot happen with deletions: such a batch is not split)
         }
@@ -2590,6 +2598,7 @@ static int create_rows(re_ctx *c, const re_entities *E, const std::vector<NewRow
     if (d_key.alloc(m, nullptr) != hipSuccess || d_nk.alloc(m, nullptr) != hipSuccess || d_sr.alloc(m, nullptr) != hipSuccess || d_cnt.alloc(4, nullptr) != hipSuccess) return done(c->fail(RE_E_HIP, "create_rows: out of device memory"));
     (void)hipMemsetAsync(d_cnt.p, 0, 16, st);
     hipLaunchKernelGGL(k_transform_assign, dim3((m + 255) / 256), dim3(256), 0, st, row_arrays(c), row0, m, c->cfg.outline_length, c->cfg.atomic_length, d_key.p, d_nk.p, d_sr.p, d_cnt.p, m);
+    (void)hipMemsetAsync(c->d_row_cell.p + row0, 0xFF, (size_t)m * 4, st);      // ROW_CELL_NONE: in no section yet (the device-side re-bucket reads it; rows beyond the upload were never written)
     std::vector<uint64_t> key(m); std::vector<uint8_t> nk(m); uint32_t nsr = 0;
     (void)hipMemcpyAsync(key.data(), d_key.p, (size_t)m * 8, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(nk.data(), d_nk.p, m, hipMemcpyDeviceToHost, st); (void)hipMemcpyAsync(&nsr, d_cnt.p, 4, hipMemcpyDeviceToHost, st);
     if (hipGetLastError() != hipSuccess || sync_stream(st) != hipSuccess) return done(c->fail(RE_E_HIP, "create_rows: kernel / copy failed"));
@@ -2929,6 +2938,7 @@ static int apply_changes_impl(re_ctx *c, const re_change *changes, uint32_t n, c
         int rc = upload_row_gc(c, gc);
         if (rc != RE_OK) return rc;
     }
+    c->last_added_rejected = 0; for (auto &kv : c->add_keys) if (!kv.second.nk) c->last_added_rejected++;      // (out of bounds: created, not inserted -- re_add_entities reports the count)
     c->add_keys.clear();
     if (in_frame && c->dirty_pending) {                                         // Pipeline::execute: clear_changed_static_unique after the logic flow (pipeline.rs:271)
         uint32_t m = std::max(c->ncells, c->nsh);
@@ -2961,7 +2971,8 @@ extern "C" int re_add_entities(re_ctx *c, const re_entities *E, uint32_t *n_reje
     const uint32_t row0 = c->n;
     int rc = apply_changes_impl(c, ch.data(), E->n, E, nullptr, false);
     if (rc != RE_OK) return rc;
-    if (n_rejected) { uint32_t rej = 0; for (uint32_t r = row0; r < c->n; r++) if (c->h_row_nk[r] == 0) rej++; *n_rejected = rej; }
+    (void)row0;
+    if (n_rejected) *n_rejected = c->last_added_rejected;                      // (not from the host mirrors: the section inserts may have run on the device, whose mirrors follow on demand)
     return RE_OK;
 } RE_ABI_GUARD(c, "re_add_entities")
 

@@ -293,6 +293,7 @@ struct Rb2Status {                                           // one block the ho
 struct Rb2Seg { uint64_t key; int32_t slot; uint32_t op_begin, op_count, nl1, ns, links1; uint8_t exists0, exists1, created, freed, changed, pad[3]; };
 struct Rb2ShSeg { uint64_t pkey; uint64_t keys[8]; int32_t idx; uint32_t op_begin, op_count, na1, nst, nk; uint8_t exists0, exists1, created, freed, relink, pad[3]; };
 constexpr uint32_t RB2_MOVER_DELETED = 0x40000000u;   // word of the mover list: a row the batch deletes (remove op only); bit 31 = translation-only mover as before
+constexpr uint32_t RB2_MOVER_ADDED = 0x20000000u;     // ... a row the batch adds (AddEntity: add op only, where its StaticAABB puts it)
 __global__ void k_rb2_clear_deleted(uint32_t n, const uint32_t *movers, uint32_t *row_cell);
 constexpr uint32_t RB2_SORT_SMALL = 2048;   // ops one workgroup sorts in LDS (k_rb2_sort_small: 40 KB)
 __global__ void k_rb2_sort_small(uint32_t n, const uint64_t *key, const uint64_t *ord, uint64_t *key_sorted, uint32_t *perm);

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__r
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     if (movers[i] & RB2_MOVER_DELETED) {
-        const uint32_t r = movers[i] & 0x3FFFFFFFu, rc = C.row_cell[r];
+        const uint32_t r = movers[i] & 0x1FFFFFFFu, rc = C.row_cell[r];
         uint64_t pold = ~0ull;                                              // (an entity that is in no section -- it left the world earlier -- has nothing to remove)
         if (rc != ROW_CELL_NONE) {
             if (rc & ROW_CELL_SHARED) { const uint32_t s = rc & ~ROW_CELL_SHARED; if (s < S.cap && S.nk[s]) pold = sh_id_pkey(S.keys + (size_t)s * 8, S.nk[s]); else st->fallback = 1u; }
@@ -112,7 +112,23 @@ __global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__r
         op_key2[2 * i] = (pold & RB2_SHARED_BIT) ? ~0ull : pold; op_key2[2 * i + 1] = ~0ull;
         return;
     }
-    const uint32_t w = movers[i], r = w & 0x3FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
+    if (movers[i] & RB2_MOVER_ADDED) {                                       // AddEntity -> add_entity(id, aabb, add_if_out_bounds = false, ..): out of bounds -> not inserted
+        const uint32_t r = movers[i] & 0x1FFFFFFFu;
+        Aabb bv = R.aabb[r];
+        const bool oob = normalize_aabb(&bv, (float)outline);
+        uint64_t keys[8];
+        int nk = oob ? 0 : assign_sections(bv, atomic, keys);
+        if (nk < 0) nk = 0;
+        if (C.row_cell[r] != ROW_CELL_NONE || (R.flags[r] & F_STATIC)) st->fallback = 1u;      // (not a row the host may have listed as added here)
+        const uint64_t pnew = nk == 0 ? ~0ull : (nk == 1 ? keys[0] : sh_id_pkey(keys, (uint32_t)nk));
+        for (int k = 0; k < 8; k++) mk[(size_t)i * 8 + k] = k < nk ? keys[k] : 0ull;
+        mnk[i] = (uint8_t)nk;
+        op_key[2 * i] = ~0ull; op_ord[2 * i] = (uint64_t)i << 1; op_row[2 * i] = r | RB_REMOVE; op_idx[2 * i] = 2 * i;
+        op_key[2 * i + 1] = pnew; op_ord[2 * i + 1] = ((uint64_t)i << 1) | 1ull; op_row[2 * i + 1] = r; op_idx[2 * i + 1] = 2 * i + 1;
+        op_key2[2 * i] = ~0ull; op_key2[2 * i + 1] = (pnew & RB2_SHARED_BIT) ? ~0ull : pnew;
+        return;
+    }
+    const uint32_t w = movers[i], r = w & 0x1FFFFFFFu, fl = R.flags[r], rc = C.row_cell[r];
     Aabb bv = R.aabb[r];
     normalize_aabb(&bv, (float)outline);
     uint64_t keys[8];
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(256) void k_rb2_gather_u32(uint32_t n, const uint32
 }
 __global__ __launch_bounds__(256) void k_rb2_clear_deleted(uint32_t n, const uint32_t *__restrict__ movers, uint32_t *__restrict__ row_cell) {      // the deleted rows are in no section any more
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (movers[i] & RB2_MOVER_DELETED)) row_cell[movers[i] & 0x3FFFFFFFu] = ROW_CELL_NONE;
+    if (i < n && (movers[i] & RB2_MOVER_DELETED)) row_cell[movers[i] & 0x1FFFFFFFu] = ROW_CELL_NONE;
 }
 // ---- host mirrors on demand: the state of the shared entries the device changed (re_api.hip: sync_mirrors) ----------------------------------------------------
 __global__ __launch_bounds__(256) void k_rb2_gather_shared(uint32_t n, const uint32_t *__restrict__ idxs, ShTable S, uint64_t *__restrict__ out_keys, uint32_t *__restrict__ out_hdr, int32_t *__restrict__ out_cells) {

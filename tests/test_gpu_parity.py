@@ -389,7 +389,9 @@ def test_add_entities_between_frames(R):
                 new["model_index"] = 100 + np.arange(len(new), dtype=np.uint32) % 170      # 170 more models: the group table outgrows the result block's InstanceRange capacity (regrow_groups) and the one-launch packs' 512 slots
             if f == 2:
                 new["pos"][5] = (-900.0, 100.0, 100.0)                   # out of bounds: created, not inserted
+            host_before = p.stats()["n_host_rebuckets"]
             assert p.register_model_instances(new) == w.register(to_oracle(new)) == (1 if f == 2 else 0)
+            if f == 0: assert p.stats()["n_host_rebuckets"] == host_before, "the section inserts of non-static added entities left the device path"      # (a later batch may find the spare slots of a level used up: host path, full rebuild)
             all_ents = np.concatenate([all_ents, new])
             check_sections(p, w)
             assert p.stats()["n_entities"] == len(all_ents)
