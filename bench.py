@@ -453,6 +453,27 @@ def spinner_leg(R, a, atomic):
                                        "frac_async_frames": B_TICK * tr["n_changed"] / (t_async * 1e-6) / 1e9 / HBM_PEAK_GBS if t_async else None,
                                        "note": "k_tick's own launches (dispatch-bound HIP events) in synchronous and in asynchronous frame loops; at ~100 K ticking entities the launch holds "
                                                "1.5 waves per SIMD and is bound by the length of one wave's instruction stream, not by HBM (dense_tick_all fills the machine)"}}
+    # user change requests (apply_change, helper_things/entity_change_helpers.rs:32-189): the reference's frame loop re-inserts the user entity at the camera position every frame
+    # (logic_flow.rs:246-251) -- one Position change per frame; wall time of the call from Python (the ctypes call itself is ~8 us of it)
+    try:
+        cam0 = R.Camera((c, c, c), (0, 0, -1), 1000.0).to_c()
+        ids_dyn = p.get_indexes_for_components([R._capi.C_ROTATION_VEL])
+        eid = int(ids_dyn[len(ids_dyn) // 2])
+        base = np.array(p.read_component(eid, R._capi.C_POSITION)[:3], np.float32)
+        chg = {}
+        for label, step in (("inside_its_section", 0.01), ("across_a_section_border", float(atomic))):
+            ts = []
+            for f in range(40):
+                p.cull_and_pack(cam0, copy=False)
+                pos = base + np.float32(step * (f % 2 if step > 1 else f))
+                ch = np.zeros(1, R.CHANGE_DT); ch[0] = (R._capi.CHANGE_MODIFY, eid, R._capi.C_POSITION, 0, (pos[0], pos[1], pos[2], 0))
+                t0 = time.perf_counter(); p.apply_changes(ch); ts.append(time.perf_counter() - t0)
+                p.tick(1e-4)
+            chg[label + "_us"] = float(np.median(ts[8:])) * 1e6
+        chg["note"] = "one Position change of a dynamic entity per frame (re_apply_changes), median wall time of the call; k_apply_small + the device-side re-bucket when the section changes"
+        out["change_request"] = chg
+    except Exception as e:      # noqa: BLE001
+        out["change_request"] = {"error": str(e)[:200]}
     p.close()
     # the same kernel with the machine full: every 10th entity a rotating body (1,007,770 ticking entities, ~15 waves per SIMD instead of 1.5)
     ents = synthetic.lattice_world(cells_per_axis=a.axis, first_cell=first, atomic=atomic, spinner_every=10)

@@ -228,7 +228,7 @@ struct re_ctx {
         Rb2Status *h_status = nullptr; uint32_t *h_free_off = nullptr, *h_free_u = nullptr, *h_free_s = nullptr, *h_keep = nullptr; Rb2Seg *h_segs_u = nullptr; Rb2ShSeg *h_segs_s = nullptr;
     } rb2;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
-    uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0, last_added_rejected = 0;
+    uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0, last_added_rejected = 0, slack_boost = 1;
     std::vector<uint32_t> h_light_rows; DevBuf<uint32_t> d_light_rows, d_light_out; bool light_rows_dirty = true;   // rows that carry a FindLightType (members of their section's light set)
     std::vector<hipEvent_t> k1_events; uint32_t k1_used = 0, k1_every = 1, k1_seen = 0, k1_kind = 0; bool k1_timing = false;   // per-launch timing of one kernel (re_timing_begin): k_scan_cull, k_tick or k_pack_large
 
@@ -476,8 +476,10 @@ static int build_sections(re_ctx *c, const std::vector<uint64_t> &row_key, const
             uint32_t lv = key_level(keys[i]);
             const size_t run0 = padded.size();
             while (i < keys.size() && key_level(keys[i]) == lv) padded.push_back(keys[i++]);
-            // worlds with movers get spare slots per level run (sections created by re-bucket patches live there): ~0.8 %, at least one chunk
-            size_t spare = (has_movers && !(c->cfg.flags & RE_CFG_TIGHT_SLACK)) ? std::max<size_t>(wave_keys, (padded.size() - run0) / 128) : 0;
+            // spare slots per level run (sections created by re-bucket patches, change requests and added entities live there): at least one chunk for every world -- a table
+            // without any made every section a change request created a full rebuild (1.4 s at 10 M sections: round 3, bench.py change_request) --, ~0.8 % of the run for worlds
+            // with movers; doubled (slack_boost) every time a rebuild was forced by exhausted slack
+            size_t spare = (c->cfg.flags & RE_CFG_TIGHT_SLACK) ? 0 : std::max<size_t>(wave_keys, has_movers ? (padded.size() - run0) / 128 : 0) * c->slack_boost;
             for (size_t k = 0; k < spare; k++) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
             while (padded.size() % wave_keys) padded.push_back(pack_key(lv, 0xFFFFu, 0xFFFFu, 0xFFFFu));
         }
@@ -2236,6 +2238,7 @@ static int rebucket(re_ctx *c, uint32_t n_movers, const std::vector<TreeOp> *pre
     }
     // full rebuild: key-sorted arrays from the patched per-row decisions, carrying over what the reference leaves untouched.
     // The previous state is fetched by key (slots are no longer key-ordered after patches).
+    if (!(c->cfg.flags & RE_CFG_FULL_REBUILD) && c->slack_boost < 64u) c->slack_boost *= 2u;      // (the slack was used up: the rebuilt table gets twice the spare slots)
     {
         const uint32_t oc = c->ncells;
         std::vector<Aabb> tight(oc); std::vector<uint8_t> fl(oc);
