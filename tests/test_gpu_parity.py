@@ -977,6 +977,33 @@ def test_delete_and_move_batches_on_the_device(R):
     p.close(); w.close()
 
 
+@pytest.mark.parametrize("k", [1, 255, 256, 257, 1023, 1024, 1025])
+def test_change_batch_size_boundaries(R, k):
+    """k Position changes that each carry a dynamic entity into another section: around the limits of the one-launch path of small batches (256 writes / moved
+    entities: k_apply_small vs the general path) and of the one-workgroup sort of the device re-bucket (2,048 ops = 1,024 movers: k_rb2_sort_small vs the radix sorts)"""
+    ents = hopping_world(R, dims=(16, 16, 16), first=120, every=2)
+    p, w = build_pair(R, ents)
+    C = R._capi
+    dyn = ents["id"][(ents["flags"] & R.F_HAS_VEL) != 0]
+    assert len(dyn) >= 1025
+    cam = R.Camera((8192, 8192, 8192 + 2200), (0, 0, -1), 5000.0)
+    rng = np.random.default_rng(k)
+    for rep in range(2):
+        check_frame(R, p, w, cam, rep == 1)
+        ids = rng.choice(dyn, k, replace=False)
+        ch = np.zeros(k, R.CHANGE_DT)
+        for i in range(k):
+            ch[i] = (C.CHANGE_MODIFY, ids[i], C.C_POSITION, 0, (64.0 * (120 + int(rng.integers(0, 16))) + 32.0, 64.0 * (120 + int(rng.integers(0, 16))) + 32.0, 64.0 * (120 + int(rng.integers(0, 16))) + 32.0, 0))
+        host_before = p.stats()["n_host_rebuckets"]
+        n_a, oob_a = w.apply_changes(ch.view(ro.CHANGE_DT)); g = p.apply_changes(ch)
+        assert g["n_changed"] == n_a == k and g["n_out_of_bounds"] == len(oob_a) == 0
+        assert p.stats()["n_host_rebuckets"] == host_before
+        check_sections(p, w)
+    check_entities(R, p, w, ents[::11])
+    check_frame(R, p, w, cam, False)
+    p.close(); w.close()
+
+
 def test_one_launch_synchronous_frames(R):
     """RE_CULL_ONE_LAUNCH: the scan's last workgroup publishes the frame's result itself (k_scan_cull_sync: ticket over the workgroups, list entries written
     through to memory, one wave builds the InstanceRange table), k_pack_small only moves the instances.  Frames with movers, shared sections, duplicates
@@ -997,6 +1024,14 @@ def test_one_launch_synchronous_frames(R):
         n_o, oob_o = w.tick(oc, 0.05); t = p.tick(0.05)
         assert t["n_changed"] == n_o and t["n_out_of_bounds"] == len(oob_o)
     check_sections(p, w)
+    p.close(); w.close()
+    many = R.synthetic.mixed_world(1500, seed=34, spread=400.0)                    # more group slots than the tail takes (40 models x 8 bands > 256): the flag is ignored, two launches
+    many["model_index"] = np.arange(len(many), dtype=np.uint32) % 40
+    p, w = build_pair(R, many)
+    for f in range(2):
+        cam = R.Camera((8192 + 20 * f, 8192, 8600), (0, 0, -1), 1200.0); oc = oracle_camera(cam)
+        w.cull(oc); g = p.cull_and_pack(cam, one_launch=True)
+        assert_render_equal(g, w.render(oc)); assert_clean_publication(p)
     p.close(); w.close()
     big = R.synthetic.lattice_world(cells_per_axis=40, first_cell=108)               # > 16 K visible instances: the small path declines
     p, w = build_pair(R, big)
