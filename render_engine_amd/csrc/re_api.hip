@@ -224,8 +224,10 @@ struct re_ctx {
         DevBuf<uint8_t> mnk, tmp; DevBuf<Rb2Seg> segs_u; DevBuf<Rb2ShSeg> segs_s; DevBuf<Rb2Status> status;
         // pinned host staging of everything that travels between the host and the device inside one batch (status blocks, free slots, the segments' outcome): copies from / to
         // pageable memory cost 15-20 us each, and a batch made eight of them -- most of a small batch's time
-        uint8_t *pin = nullptr; size_t pin_bytes = 0;
-        Rb2Status *h_status = nullptr; uint32_t *h_free_off = nullptr, *h_free_u = nullptr, *h_free_s = nullptr, *h_keep = nullptr; Rb2Seg *h_segs_u = nullptr; Rb2ShSeg *h_segs_s = nullptr;
+        uint8_t *pin = nullptr, *d_pin = nullptr; size_t pin_bytes = 0;     // (d_pin: the device's address of the mapped block)
+        bool status_clean = false; uint32_t status_pool = 0;                  // the device status block was reset by the last batch's final read-back and holds this pool fill
+        Rb2Status *h_status = nullptr, *d_h_status = nullptr; uint32_t *h_seq = nullptr, *d_h_seq = nullptr, seq = 0;      // (d_h_*: the device's view of the mapped block)
+        uint32_t *h_free_off = nullptr, *h_free_u = nullptr, *h_free_s = nullptr, *h_keep = nullptr; Rb2Seg *h_segs_u = nullptr; Rb2ShSeg *h_segs_s = nullptr;
     } rb2;
     std::vector<uint32_t> stale_slots;                   // sections patched on the device since the host mirrors (h_cell_*, h_rows, h_row_*, extra_slots) were last brought up to date
     uint32_t n_device_rebuckets = 0, n_host_rebuckets = 0, n_phantom = 0, last_added_rejected = 0, slack_boost = 1;
@@ -1911,19 +1913,20 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         HIPCHK(c, B.segs_u.alloc(oc, nullptr)); HIPCHK(c, B.segs_s.alloc(2u * mc, nullptr));
         HIPCHK(c, B.free_u.alloc(oc, nullptr)); HIPCHK(c, B.free_off.alloc(MAX_LEVELS, nullptr)); HIPCHK(c, B.free_s.alloc(2u * mc, nullptr));
         HIPCHK(c, B.pair_key.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_key_s.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_seg.alloc(16u * mc, nullptr)); HIPCHK(c, B.pair_seg_s.alloc(16u * mc, nullptr));
-        if (!B.status.p) HIPCHK(c, B.status.alloc(1, nullptr));
+        if (!B.status.p) { HIPCHK(c, B.status.alloc(1, nullptr)); B.status_clean = false; }
         size_t t1 = 0, t2 = 0;
         HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t1, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, oc, 0, 35, st));
         HIPCHK(c, re::sort_pairs_u64_u32(nullptr, &t2, B.kgath.p, B.ksorted1.p, B.perm_a.p, B.perm1.p, oc, 0, 64, st));
         HIPCHK(c, B.tmp.alloc(std::max(t1, t2) + 256, nullptr));
         {   // the pinned staging block, laid out for mc movers
             auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-            const size_t o_off = up(sizeof(Rb2Status)), o_fu = o_off + up(MAX_LEVELS * 4), o_fs = o_fu + up((size_t)oc * 4), o_keep = o_fs + up((size_t)2 * mc * 4),
+            const size_t o_seq = up(sizeof(Rb2Status)), o_off = o_seq + 256, o_fu = o_off + up(MAX_LEVELS * 4), o_fs = o_fu + up((size_t)oc * 4), o_keep = o_fs + up((size_t)2 * mc * 4),
                          o_su = o_keep + up((size_t)mc * 4), o_ss = o_su + up((size_t)oc * sizeof(Rb2Seg)), total = o_ss + up((size_t)2 * mc * sizeof(Rb2ShSeg));
             if (B.pin) { (void)hipHostFree(B.pin); B.pin = nullptr; }
-            void *hp = nullptr; HIPCHK(c, hipHostMalloc(&hp, total, hipHostMallocDefault));
-            B.pin = static_cast<uint8_t *>(hp); B.pin_bytes = total;
-            B.h_status = reinterpret_cast<Rb2Status *>(B.pin); B.h_free_off = reinterpret_cast<uint32_t *>(B.pin + o_off); B.h_free_u = reinterpret_cast<uint32_t *>(B.pin + o_fu);
+            void *hp = nullptr, *dp = nullptr; HIPCHK(c, hipHostMalloc(&hp, total, hipHostMallocMapped)); HIPCHK(c, hipHostGetDevicePointer(&dp, hp, 0));
+            B.pin = static_cast<uint8_t *>(hp); B.d_pin = static_cast<uint8_t *>(dp); B.pin_bytes = total;
+            B.h_status = reinterpret_cast<Rb2Status *>(B.pin); B.d_h_status = reinterpret_cast<Rb2Status *>(dp);
+            B.h_seq = reinterpret_cast<uint32_t *>(B.pin + o_seq); B.d_h_seq = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(dp) + o_seq); *B.h_seq = 0; B.seq = 0; B.h_free_off = reinterpret_cast<uint32_t *>(B.pin + o_off); B.h_free_u = reinterpret_cast<uint32_t *>(B.pin + o_fu);
             B.h_free_s = reinterpret_cast<uint32_t *>(B.pin + o_fs); B.h_keep = reinterpret_cast<uint32_t *>(B.pin + o_keep);
             B.h_segs_u = reinterpret_cast<Rb2Seg *>(B.pin + o_su); B.h_segs_s = reinterpret_cast<Rb2ShSeg *>(B.pin + o_ss);
         }
@@ -1931,10 +1934,26 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     }
     if (!c->d_cell_inact.p || c->d_cell_inact.n < c->ncells) { HIPCHK(c, c->d_cell_inact.alloc(std::max(c->ncells, 1u), nullptr)); HIPCHK(c, hipMemsetAsync(c->d_cell_inact.p, 0, std::max(c->ncells, 1u), st)); }      // (all zero between batches)
     Rb2Status &hs = *B.h_status; hs = Rb2Status{}; hs.pool_used = c->pool_used;
-    HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    if (!(B.status_clean && B.status_pool == c->pool_used)) HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));      // (else: the last batch's final read-back left the block ready)
+    B.status_clean = false;
+    auto mapped = [&](const void *h) { return reinterpret_cast<uint32_t *>(B.d_pin + (reinterpret_cast<const uint8_t *>(h) - B.pin)); };
     const RbTables T = rb_tables(c); const RbCells C = rb_cells(c); const ShTable S = sh_table(c);
-    auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm) -> int {      // by (placement key, reference order): two stable radix sorts
-        if (n <= RB2_SORT_SMALL) { hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, n, key_src, (const uint64_t *)B.ord.p, ksorted, perm); return RE_OK; }      // (one launch of one workgroup)
+    // the status block as the kernels so far left it: published into the mapped block by one small kernel and polled (a copy plus a stream synchronise costs ~15 us more, three times a batch)
+    auto read_status = [&](const void *src_a = nullptr, void *h_a = nullptr, uint32_t words_a = 0, const void *src_b = nullptr, void *h_b = nullptr, uint32_t words_b = 0, bool reset = false) -> int {
+        const uint32_t seq = ++B.seq;
+        hipLaunchKernelGGL(k_rb2_publish_status, dim3(1), dim3(256), 0, st, B.status.p, B.d_h_status, B.d_h_seq, seq, static_cast<const uint32_t *>(src_a), words_a ? mapped(h_a) : nullptr, words_a,
+                           static_cast<const uint32_t *>(src_b), words_b ? mapped(h_b) : nullptr, words_b, reset ? 1u : 0u);
+        HIPCHK(c, hipGetLastError());
+        const volatile uint32_t *flag = B.h_seq; bool done = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; !(done = (*flag == seq)); spins++)
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;   // a long batch: let the driver wait
+        if (!done) { HIPCHK(c, sync_stream(st)); if (*flag != seq) return c->fail(RE_E_STATE, "device re-bucket: the status block was not published"); }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return RE_OK;
+    };
+    auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm, const uint32_t *n_extra = nullptr) -> int {      // by (placement key, reference order): two stable radix sorts
+        if (n <= RB2_SORT_SMALL) { hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, n, key_src, (const uint64_t *)B.ord.p, ksorted, perm, n_extra); return RE_OK; }      // (one launch of one workgroup)
         size_t tb = B.tmp.n;
         HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.ord.p, B.ord_s.p, B.idx.p, B.perm_a.p, n, 0, 35, st));
         hipLaunchKernelGGL(k_rb_gather_keys, dim3((n + 255) / 256), dim3(256), 0, st, n, (const uint32_t *)B.perm_a.p, key_src, B.kgath.p);
@@ -1948,20 +1967,25 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     { int rc = sort_ops(n1, B.key.p, B.ksorted1.p, B.perm1.p); if (rc != RE_OK) return rc; }
     hipLaunchKernelGGL(k_rb2_shared_segments, dim3((n1 + 255) / 256), dim3(256), 0, st, n1, M, (const uint32_t *)B.perm1.p, (const uint64_t *)B.ksorted1.p, (const uint32_t *)B.row.p, B.ord.p,
                        (const uint64_t *)B.mk.p, (const uint8_t *)B.mnk.p, S, C, B.key2.p, B.row.p, B.idx.p, link_cap, B.segs_s.p, B.status.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, sync_stream(st));
-    lap("shared");
-    if (hs.fallback || hs.n_link > link_cap) return 1;
-    // ---- phase 3: the unique placements with the link ops merged in
-    const uint32_t n2 = n1 + hs.n_link;
-    { int rc = sort_ops(n2, B.key2.p, B.ksorted2.p, B.perm2.p); if (rc != RE_OK) return rc; }
-    hipLaunchKernelGGL(k_rb2_unique_segments, dim3((n2 + 255) / 256), dim3(256), 0, st, n2, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, sync_stream(st));
+    // ---- phase 3: the unique placements with the link ops merged in.  A batch whose ops AND every link op they can emit (8 per op) fit the one-workgroup sort does not
+    // wait for the count of link ops: the kernels read it from the status block, and a fallback raised by phase 2 is seen with phase 3's (nothing is touched before phase 4)
+    const bool general = getenv("RE_EXP_RB2_GENERAL") != nullptr;            // (tests: small batches through the kernels of large ones; read per batch)
+    const bool chained = 9u * n1 <= RB2_SORT_SMALL && !general;
+    if (chained) {
+        const uint32_t *n_link = &B.status.p->n_link;
+        { int rc = sort_ops(n1, B.key2.p, B.ksorted2.p, B.perm2.p, n_link); if (rc != RE_OK) return rc; }
+        hipLaunchKernelGGL(k_rb2_unique_segments, dim3((9u * n1 + 255) / 256), dim3(256), 0, st, n1, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p, n_link);
+    } else {
+        { int rc = read_status(); if (rc != RE_OK) return rc; }
+        lap("shared");
+        if (hs.fallback || hs.n_link > link_cap) return 1;
+        const uint32_t n2 = n1 + hs.n_link;
+        { int rc = sort_ops(n2, B.key2.p, B.ksorted2.p, B.perm2.p); if (rc != RE_OK) return rc; }
+        hipLaunchKernelGGL(k_rb2_unique_segments, dim3((n2 + 255) / 256), dim3(256), 0, st, n2, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p, (const uint32_t *)nullptr);
+    }
+    { int rc = read_status(); if (rc != RE_OK) return rc; }
     lap("unique");
-    if (hs.fallback) return 1;
+    if (hs.fallback || hs.n_link > link_cap) return 1;
     if (!c->ghost_map.empty() || !c->dormant_cached.empty()) {               // sections this batch would create or retire: none may be one the ghost books of the frozen cache know
         const uint32_t nq = hs.nseg_u;
         if (nq) { HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nq * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st)); HIPCHK(c, sync_stream(st)); }
@@ -1983,27 +2007,34 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     std::vector<uint32_t> fs; uint32_t nfl = 0;
     for (uint32_t l = 0; l < (uint32_t)MAX_LEVELS; l++) { B.h_free_off[l] = nfl; for (uint32_t j = 0; j < hs.need_slots[l]; j++) B.h_free_u[nfl++] = c->free_slots[l][c->free_slots[l].size() - 1u - j]; }
     { uint32_t bump = c->nsh; for (uint32_t j = 0; j < hs.need_sh; j++) { fs.push_back(j < c->sh_free.size() ? c->sh_free[c->sh_free.size() - 1u - j] : bump++); B.h_free_s[j] = fs.back(); } }
-    if (nfl) HIPCHK(c, hipMemcpyAsync(B.free_u.p, B.h_free_u, (size_t)nfl * 4, hipMemcpyHostToDevice, st));
-    if (!fs.empty()) HIPCHK(c, hipMemcpyAsync(B.free_s.p, B.h_free_s, fs.size() * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(B.free_off.p, B.h_free_off, MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
+    const bool inline_free = nfl + fs.size() <= RB2_INLINE_WORDS;            // a small batch: the apply kernels read the lists from the mapped block (three stream copies less)
+    if (!inline_free) {
+        if (nfl) HIPCHK(c, hipMemcpyAsync(B.free_u.p, B.h_free_u, (size_t)nfl * 4, hipMemcpyHostToDevice, st));
+        if (!fs.empty()) HIPCHK(c, hipMemcpyAsync(B.free_s.p, B.h_free_s, fs.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(B.free_off.p, B.h_free_off, MAX_LEVELS * 4, hipMemcpyHostToDevice, st));
+    }
+    const uint32_t *a_free_u = inline_free ? mapped(B.h_free_u) : B.free_u.p, *a_free_s = inline_free ? mapped(B.h_free_s) : B.free_s.p, *a_free_off = inline_free ? mapped(B.h_free_off) : B.free_off.p;
     const uint32_t nu = hs.nseg_u, ns = hs.nseg_s;
     uint32_t nsh_after = c->nsh; for (uint32_t x : fs) nsh_after = std::max(nsh_after, x + 1u);
     if (nu) hipLaunchKernelGGL(k_rb2_apply_unique, dim3(nu), dim3(64), 0, st, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), c->d_cell_links.p, B.segs_u.p, B.status.p,
-                               (const uint32_t *)B.free_u.p, (const uint32_t *)B.free_off.p, B.tmp_u.p, B.refold.p);
+                               a_free_u, a_free_off, B.tmp_u.p, B.refold.p);
     if (ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3(ns), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p,
-                               (const uint32_t *)B.free_s.p, B.tmp_s.p);
+                               a_free_s, B.tmp_s.p);
     // update_static_world_sections: first loop (changed / new unique sections), second loop (changed shared sections in canonical order)
+    const bool static_small = 8u * ns <= RB2_STATIC_SMALL_PAIRS && nsh_after <= RB2_STATIC_SMALL_SHARED && nu <= 16384u && !general;
+    if (static_small) {
+        if (nu || ns) hipLaunchKernelGGL(k_rb2_static_small, dim3(1), dim3(1024), 0, st, nsh_after, S, C, (const uint8_t *)c->d_cell_links.p, c->d_cell_inact.p, (const Rb2Seg *)B.segs_u.p, (const Rb2ShSeg *)B.segs_s.p, (const Rb2Status *)B.status.p);
+    } else {
     if (nsh_after && nu) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p, (uint8_t)1);
     if (nu) hipLaunchKernelGGL(k_rb2_static_first, dim3((nu + 255) / 256), dim3(256), 0, st, C, (const uint8_t *)c->d_cell_links.p, (const uint8_t *)c->d_cell_inact.p, (const Rb2Seg *)B.segs_u.p, (const Rb2Status *)B.status.p);
     if (nsh_after && nu) hipLaunchKernelGGL(k_rb2_mark_inactive, dim3((nsh_after + 255) / 256), dim3(256), 0, st, nsh_after, S, c->d_cell_inact.p, (uint8_t)0);
     if (ns) {
         hipLaunchKernelGGL(k_rb2_static_pairs, dim3((ns + 255) / 256), dim3(256), 0, st, (const Rb2ShSeg *)B.segs_s.p, (const Rb2Status *)B.status.p, S, B.pair_key.p, B.pair_seg.p, B.status.p);
         const uint32_t np_max = 8u * ns;                                      // (pairs beyond n_pairs carry stale keys: sort only what was written -- the count comes back with the status below, so sort the bound and let the kernel stop at n_pairs)
-        HIPCHK(c, hipMemcpyAsync(&hs, B.status.p, sizeof hs, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, sync_stream(st));
+        { int rc = read_status(); if (rc != RE_OK) return rc; }
         const uint32_t np = std::min(hs.n_pairs, np_max);
         if (np && np <= RB2_SORT_SMALL) {      // (a stable sort by slot: the pair index is the tie-break, and pair i belongs to segment pair_seg[i])
-            hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, np, (const uint64_t *)B.pair_key.p, (const uint64_t *)nullptr, B.pair_key_s.p, B.perm_a.p);
+            hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, np, (const uint64_t *)B.pair_key.p, (const uint64_t *)nullptr, B.pair_key_s.p, B.perm_a.p, (const uint32_t *)nullptr);
             hipLaunchKernelGGL(k_rb2_gather_u32, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint32_t *)B.perm_a.p, (const uint32_t *)B.pair_seg.p, B.pair_seg_s.p);
             hipLaunchKernelGGL(k_rb2_static_second, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint64_t *)B.pair_key_s.p, (const uint32_t *)B.pair_seg_s.p, (const Rb2ShSeg *)B.segs_s.p, C);
         } else if (np) {
@@ -2012,6 +2043,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
             hipLaunchKernelGGL(k_rb2_static_second, dim3((np + 255) / 256), dim3(256), 0, st, np, (const uint64_t *)B.pair_key_s.p, (const uint32_t *)B.pair_seg_s.p, (const Rb2ShSeg *)B.segs_s.p, C);
         }
     }
+    }
     // end_of_changes: tight AABBs of the changed sections (bounding_box_tree_v2.rs:1055-1130)
     if (nu) hipLaunchKernelGGL(k_fold_tight_list, dim3((nu + 255) / 256), dim3(256), 0, st, nu, (const uint32_t *)B.refold.p, c->d_cell_key.p, c->d_cell_begin.p, c->d_cell_nlocal.p, c->d_cell_nstatic.p, c->d_rows.p,
                                c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
@@ -2019,10 +2051,16 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     HIPCHK(c, hipGetLastError());
     const Rb2Status planned = hs;                                            // (the plan of the phases above; the block is read back once more below)
     Rb2Status &h2 = *B.h_status;
-    HIPCHK(c, hipMemcpyAsync(&h2, B.status.p, sizeof h2, hipMemcpyDeviceToHost, st));
-    if (nu) HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nu * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st));
-    if (ns) HIPCHK(c, hipMemcpyAsync(B.h_segs_s, B.segs_s.p, (size_t)ns * sizeof(Rb2ShSeg), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, sync_stream(st));
+    static_assert(sizeof(Rb2Seg) % 4u == 0 && sizeof(Rb2ShSeg) % 4u == 0, "segment lists are copied by words");
+    const uint32_t wu = nu * (uint32_t)(sizeof(Rb2Seg) / 4u), ws = ns * (uint32_t)(sizeof(Rb2ShSeg) / 4u);
+    if ((uint64_t)wu + ws <= RB2_INLINE_WORDS) {
+        int rc = read_status(B.segs_u.p, B.h_segs_u, wu, B.segs_s.p, B.h_segs_s, ws, true); if (rc != RE_OK) return rc;
+    } else {
+        if (nu) HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nu * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st));
+        if (ns) HIPCHK(c, hipMemcpyAsync(B.h_segs_s, B.segs_s.p, (size_t)ns * sizeof(Rb2ShSeg), hipMemcpyDeviceToHost, st));
+        int rc = read_status(nullptr, nullptr, 0, nullptr, nullptr, 0, true); if (rc != RE_OK) return rc;      // (stream order: the segment copies above have landed when the sequence word arrives)
+    }
+    B.status_clean = h2.err == 0; B.status_pool = h2.pool_used;
     const Rb2Seg *su = B.h_segs_u; const Rb2ShSeg *ss = B.h_segs_s;
     lap("apply");
     // ---- what the host keeps in step at once: free slots / indices, pool fill, counts; everything else waits for sync_mirrors

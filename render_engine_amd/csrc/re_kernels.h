@@ -295,15 +295,20 @@ struct Rb2ShSeg { uint64_t pkey; uint64_t keys[8]; int32_t idx; uint32_t op_begi
 constexpr uint32_t RB2_MOVER_DELETED = 0x40000000u;   // word of the mover list: a row the batch deletes (remove op only); bit 31 = translation-only mover as before
 constexpr uint32_t RB2_MOVER_ADDED = 0x20000000u;     // ... a row the batch adds (AddEntity: add op only, where its StaticAABB puts it)
 __global__ void k_rb2_clear_deleted(uint32_t n, const uint32_t *movers, uint32_t *row_cell);
+__global__ void k_rb2_publish_status(Rb2Status *st, Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, const uint32_t *src_a, uint32_t *dst_a, uint32_t words_a,
+                                     const uint32_t *src_b, uint32_t *dst_b, uint32_t words_b, uint32_t reset);
+constexpr uint32_t RB2_STATIC_SMALL_PAIRS = 2048, RB2_STATIC_SMALL_SHARED = 32768;   // k_rb2_static_small: update_static_world_sections of a batch with up to 256 changed shared sections in a world of up to 32,768, by one workgroup
+__global__ void k_rb2_static_small(uint32_t nsh, ShTable S, RbCells C, const uint8_t *cell_links, uint8_t *cell_inact, const Rb2Seg *segs_u, const Rb2ShSeg *segs_s, const Rb2Status *st);
+constexpr uint32_t RB2_INLINE_WORDS = 2048;   // segment lists up to this many words travel with the status block (k_rb2_publish_status) instead of as stream copies; free lists up to this many entries are read by the apply kernels from the mapped block
 constexpr uint32_t RB2_SORT_SMALL = 2048;   // ops one workgroup sorts in LDS (k_rb2_sort_small: 40 KB)
-__global__ void k_rb2_sort_small(uint32_t n, const uint64_t *key, const uint64_t *ord, uint64_t *key_sorted, uint32_t *perm);
+__global__ void k_rb2_sort_small(uint32_t n, const uint64_t *key, const uint64_t *ord, uint64_t *key_sorted, uint32_t *perm, const uint32_t *n_extra);
 __global__ void k_rb2_gather_u32(uint32_t n, const uint32_t *perm, const uint32_t *src, uint32_t *dst);
 __global__ void k_rb2_hash_insert(uint32_t n, ShTable S);
 __global__ void k_rb2_ops(uint32_t m, const uint32_t *movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic, uint64_t *op_key, uint64_t *op_key2, uint64_t *op_ord,
                           uint32_t *op_row, uint32_t *op_idx, uint64_t *mk, uint8_t *mnk, uint32_t *host_list, Rb2Status *st);
 __global__ void k_rb2_shared_segments(uint32_t n, uint32_t m, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, uint64_t *op_ord, const uint64_t *mk, const uint8_t *mnk,
                                       ShTable S, RbCells C, uint64_t *op_key2, uint32_t *op_row_w, uint32_t *op_idx, uint32_t link_cap, Rb2ShSeg *segs, Rb2Status *st);
-__global__ void k_rb2_unique_segments(uint32_t n, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, RbTables T, RbCells C, uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st);
+__global__ void k_rb2_unique_segments(uint32_t n, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, RbTables T, RbCells C, uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st, const uint32_t *n_extra);
 __global__ void k_rb2_apply_unique(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st,
                                    const uint32_t *free_slots, const uint32_t *free_off, uint32_t *tmp_row, uint32_t *refold);
 __global__ void k_rb2_apply_shared(const uint32_t *perm, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, ShTable S, Rb2ShSeg *segs, Rb2Status *st, const uint32_t *free_sh, uint32_t *tmp_row);

@@ -68,9 +68,10 @@ __global__ __launch_bounds__(256) void k_rb2_hash_insert(uint32_t n, ShTable S) 
 
 // ---- small batches: (placement key, reference order) sorted by ONE workgroup (a bitonic network in LDS) instead of two radix sorts and a gather -- a batch of a
 // handful of movers (a change request that carries the user entity across a section border) is bound by the number of launches, not by the sorting
-__global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint64_t *__restrict__ key, const uint64_t *__restrict__ ord, uint64_t *__restrict__ key_sorted, uint32_t *__restrict__ perm) {
+__global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint64_t *__restrict__ key, const uint64_t *__restrict__ ord, uint64_t *__restrict__ key_sorted, uint32_t *__restrict__ perm, const uint32_t *n_extra) {
     __shared__ uint64_t s_key[RB2_SORT_SMALL], s_ord[RB2_SORT_SMALL]; __shared__ uint32_t s_idx[RB2_SORT_SMALL];
     const uint32_t tid = threadIdx.x;
+    if (n_extra) n = min(n + *n_extra, RB2_SORT_SMALL);                    // (a count an earlier kernel of the batch left on the device: the host has not read it)
     uint32_t m = 1; while (m < n) m <<= 1;                                  // (n <= RB2_SORT_SMALL: the host chose this kernel)
     for (uint32_t i = tid; i < m; i += 1024u) { const bool on = i < n; s_key[i] = on ? key[i] : ~0ull; s_ord[i] = on ? (ord ? ord[i] : 0ull) : ~0ull; s_idx[i] = on ? i : 0xFFFFFFFFu; }
     __syncthreads();
@@ -211,8 +212,9 @@ __global__ __launch_bounds__(256) void k_rb2_shared_segments(uint32_t n, uint32_
 
 // ---- phase 3: the unique placements, member ops and link ops merged by the reference's order -----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rb2_unique_segments(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
-                                                             RbTables T, RbCells C, uint8_t *__restrict__ cell_links, Rb2Seg *__restrict__ segs, Rb2Status *st) {
+                                                             RbTables T, RbCells C, uint8_t *__restrict__ cell_links, Rb2Seg *__restrict__ segs, Rb2Status *st, const uint32_t *n_extra) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_extra) n += *n_extra;                                              // (as in k_rb2_sort_small; the grid covers the bound)
     if (t >= n) return;
     const uint64_t key = key_sorted[t];
     if (key == ~0ull) return;
@@ -486,10 +488,94 @@ __global__ __launch_bounds__(256) void k_rb2_static_second(uint32_t n, const uin
     else f = (uint8_t)((f & ~CF_STATIC_SECTION) | (segs[last].na1 == 0u ? CF_STATIC_SECTION : 0));
     C.cell_flags[sl] = f;
 }
+// small batches: both loops in ONE workgroup (mark, first loop, unmark, the pairs, their sort in LDS, second loop) -- eight launches and a read-back of the pair count less.
+// The arrays are read and written through plain pointers (no __restrict__): later steps read what earlier steps of this kernel wrote, ordered by the workgroup barriers.
+__global__ __launch_bounds__(1024) void k_rb2_static_small(uint32_t nsh, ShTable S, RbCells C, const uint8_t *cell_links, uint8_t *cell_inact, const Rb2Seg *segs_u, const Rb2ShSeg *segs_s, const Rb2Status *st) {
+    __shared__ uint64_t s_key[RB2_STATIC_SMALL_PAIRS]; __shared__ uint32_t s_np;
+    const uint32_t tid = threadIdx.x, nu = st->nseg_u, ns = st->nseg_s;
+    if (tid == 0) s_np = 0u;
+    if (nu) {
+        for (uint32_t v = 0; v < 2u; v++) {                                  // v = 0: mark, then the first loop; v = 1: unmark
+            for (uint32_t s = tid; s < nsh; s += 1024u) {
+                if (!S.nk[s] || S.nact[s] != 0u) continue;
+                for (uint32_t k = 0; k < 8; k++) { const int32_t c = S.cells[(size_t)s * 8 + k]; if (c >= 0) cell_inact[c] = (uint8_t)(v ^ 1u); }
+            }
+            __syncthreads();
+            if (v == 0u) {
+                for (uint32_t s = tid; s < nu; s += 1024u) {
+                    const Rb2Seg G = segs_u[s];
+                    if (!G.exists1 || G.slot < 0 || !(G.changed || G.created)) continue;
+                    const uint32_t sl = (uint32_t)G.slot;
+                    const bool stat = C.cell_nl[sl] == 0u && (cell_links[sl] == 0u || cell_inact[sl] != 0u);
+                    C.cell_flags[sl] = (uint8_t)((C.cell_flags[sl] & ~CF_STATIC_SECTION) | (stat ? CF_STATIC_SECTION : 0));
+                }
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (!ns) return;
+    // (slot, shared segment) pairs: slot in the high word, so equal slots are neighbours after the sort (a segment links a slot at most once; which of a slot's pairs comes first does not matter to the fold below)
+    for (uint32_t s = tid; s < ns; s += 1024u) {
+        const Rb2ShSeg &G = segs_s[s];
+        if (!G.exists1 || G.idx < 0) continue;
+        const uint32_t at = atomicAdd(&s_np, (uint32_t)G.nk);
+        for (uint32_t k = 0; k < G.nk && at + k < RB2_STATIC_SMALL_PAIRS; k++) s_key[at + k] = ((uint64_t)(uint32_t)S.cells[(size_t)G.idx * 8 + k] << 32) | s;
+    }
+    __syncthreads();
+    const uint32_t np = min(s_np, RB2_STATIC_SMALL_PAIRS);                   // (the host chose this kernel for 8 * nseg_s <= RB2_STATIC_SMALL_PAIRS)
+    uint32_t m = 1; while (m < np) m <<= 1;
+    for (uint32_t i = np + tid; i < m; i += 1024u) s_key[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < m; i += 1024u) {
+                const uint32_t l = i ^ j;
+                if (l > i) { const uint64_t a = s_key[i], b = s_key[l]; if ((a > b) == ((i & k) == 0)) { s_key[i] = b; s_key[l] = a; } }
+            }
+            __syncthreads();
+        }
+    for (uint32_t t = tid; t < np; t += 1024u) {
+        const uint32_t sl = (uint32_t)(s_key[t] >> 32);
+        if (t > 0 && (uint32_t)(s_key[t - 1] >> 32) == sl) continue;
+        if (sl >= 0x80000000u) continue;                                     // (a link that could not be resolved: reported by the apply kernel)
+        bool any_active = false; uint32_t last = (uint32_t)s_key[t];
+        for (uint32_t q = t; q < np && (uint32_t)(s_key[q] >> 32) == sl; q++) {
+            const uint32_t g = (uint32_t)s_key[q];
+            const Rb2ShSeg &G = segs_s[g];
+            if (G.na1 != 0u) any_active = true;
+            const Rb2ShSeg &L = segs_s[last];
+            if (sh_id_less(L.keys, L.nk, G.keys, G.nk)) last = g;
+        }
+        uint8_t f = C.cell_flags[sl];
+        if (C.cell_nl[sl] != 0u) { if (any_active) f &= (uint8_t)~CF_STATIC_SECTION; }
+        else f = (uint8_t)((f & ~CF_STATIC_SECTION) | (segs_s[last].na1 == 0u ? CF_STATIC_SECTION : 0));
+        C.cell_flags[sl] = f;
+    }
+}
 
 __global__ __launch_bounds__(256) void k_rb2_gather_u32(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[perm[i]];
+}
+// the status block for the host: copied into mapped pinned memory and announced by a sequence word the host polls (publish_to_host) -- a stream-ordered copy plus a stream
+// synchronise cost ~15 us per read-back, three times a batch
+// ... and, for the last read-back of a small batch, the segment lists with it (words_a / words_b 32-bit words) and the block reset for the next batch (everything but pool_used, which the
+// device keeps current)
+__global__ __launch_bounds__(256) void k_rb2_publish_status(Rb2Status *__restrict__ st, Rb2Status *__restrict__ h_st, uint32_t *h_seq, uint32_t seq,
+                                                            const uint32_t *__restrict__ src_a, uint32_t *__restrict__ dst_a, uint32_t words_a,
+                                                            const uint32_t *__restrict__ src_b, uint32_t *__restrict__ dst_b, uint32_t words_b, uint32_t reset) {
+    static_assert(sizeof(Rb2Status) % 4u == 0 && sizeof(Rb2Status) / 4u <= 256u, "one word per thread");
+    uint32_t *src = reinterpret_cast<uint32_t *>(st); uint32_t *dst = reinterpret_cast<uint32_t *>(h_st);
+    if (threadIdx.x < sizeof(Rb2Status) / 4u) {
+        dst[threadIdx.x] = __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (reset && threadIdx.x != offsetof(Rb2Status, pool_used) / 4u) src[threadIdx.x] = 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < words_a; i += 256u) dst_a[i] = src_a[i];
+    for (uint32_t i = threadIdx.x; i < words_b; i += 256u) dst_b[i] = src_b[i];
+    wait_own_stores();
+    __syncthreads();                                                          // every wave's host stores have left before thread 0 publishes
+    if (threadIdx.x == 0) publish_to_host(h_seq, seq);
 }
 __global__ __launch_bounds__(256) void k_rb2_clear_deleted(uint32_t n, const uint32_t *__restrict__ movers, uint32_t *__restrict__ row_cell) {      // the deleted rows are in no section any more
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -900,14 +900,16 @@ def hopping_world(R, dims=(14, 14, 14), first=121, atomic=64, every=2):
     return R.synthetic.hopping_lattice(dims, first, atomic, every)
 
 
-@pytest.mark.parametrize("straddlers", [False, True])
-def test_rebucket_on_the_device(R, straddlers):
+@pytest.mark.parametrize("straddlers,general", [(False, False), (True, False), (True, True)])
+def test_rebucket_on_the_device(R, straddlers, general, monkeypatch):
     """batches of movers between world sections: the bookkeeping runs on the device (re_rebucket.hip: k_rb2_*), the host only notes which sections
     changed.  Sections are emptied (-> padding slots), created (free slots of the level run), outgrow their segment (relocated); the host mirrors are
     fetched on demand (a change-request batch, the debug getters) and the device path resumes afterwards.
     straddlers: some movers are wider than a world section (shared sections, higher levels): shared sections are created, emptied and re-created,
     the unique sections they link gain and lose links (and with the last one their existence), in the order of the reference's single pass -- on the
-    device too: no part of a tick's batch is left to the host"""
+    device too: no part of a tick's batch is left to the host.
+    general: the shortcuts of small batches are off (k_rb2_static_small, phase 3 chained behind phase 2 without a read-back): the kernels of large batches see these"""
+    if general: monkeypatch.setenv("RE_EXP_RB2_GENERAL", "1")
     ents = hopping_world(R)
     if straddlers:
         mv = np.nonzero((ents["flags"] & R.F_HAS_VEL) != 0)[0][::23]
@@ -977,10 +979,10 @@ def test_delete_and_move_batches_on_the_device(R):
     p.close(); w.close()
 
 
-@pytest.mark.parametrize("k", [1, 255, 256, 257, 1023, 1024, 1025])
+@pytest.mark.parametrize("k", [1, 113, 114, 255, 256, 257, 1023, 1024, 1025])
 def test_change_batch_size_boundaries(R, k):
     """k Position changes that each carry a dynamic entity into another section: around the limits of the one-launch path of small batches (256 writes / moved
-    entities: k_apply_small vs the general path) and of the one-workgroup sort of the device re-bucket (2,048 ops = 1,024 movers: k_rb2_sort_small vs the radix sorts)"""
+    entities: k_apply_small vs the general path) and of the one-workgroup sort of the device re-bucket (2,048 ops = 1,024 movers: k_rb2_sort_small vs the radix sorts; 113 movers: the largest batch whose phase 3 is chained behind phase 2 without a read-back)"""
     ents = hopping_world(R, dims=(16, 16, 16), first=120, every=2)
     p, w = build_pair(R, ents)
     C = R._capi
