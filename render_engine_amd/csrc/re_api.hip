@@ -1939,10 +1939,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     auto mapped = [&](const void *h) { return reinterpret_cast<uint32_t *>(B.d_pin + (reinterpret_cast<const uint8_t *>(h) - B.pin)); };
     const RbTables T = rb_tables(c); const RbCells C = rb_cells(c); const ShTable S = sh_table(c);
     // the status block as the kernels so far left it: published into the mapped block by one small kernel and polled (a copy plus a stream synchronise costs ~15 us more, three times a batch)
-    auto read_status = [&](const void *src_a = nullptr, void *h_a = nullptr, uint32_t words_a = 0, const void *src_b = nullptr, void *h_b = nullptr, uint32_t words_b = 0, bool reset = false) -> int {
-        const uint32_t seq = ++B.seq;
-        hipLaunchKernelGGL(k_rb2_publish_status, dim3(1), dim3(256), 0, st, B.status.p, B.d_h_status, B.d_h_seq, seq, static_cast<const uint32_t *>(src_a), words_a ? mapped(h_a) : nullptr, words_a,
-                           static_cast<const uint32_t *>(src_b), words_b ? mapped(h_b) : nullptr, words_b, reset ? 1u : 0u);
+    auto wait_status = [&](uint32_t seq) -> int {
         HIPCHK(c, hipGetLastError());
         const volatile uint32_t *flag = B.h_seq; bool done = false;
         const auto t0 = std::chrono::steady_clock::now();
@@ -1951,6 +1948,12 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         if (!done) { HIPCHK(c, sync_stream(st)); if (*flag != seq) return c->fail(RE_E_STATE, "device re-bucket: the status block was not published"); }
         std::atomic_thread_fence(std::memory_order_acquire);
         return RE_OK;
+    };
+    auto read_status = [&](const void *src_a = nullptr, void *h_a = nullptr, uint32_t words_a = 0, const void *src_b = nullptr, void *h_b = nullptr, uint32_t words_b = 0, bool reset = false) -> int {
+        const uint32_t seq = ++B.seq;
+        hipLaunchKernelGGL(k_rb2_publish_status, dim3(1), dim3(256), 0, st, B.status.p, B.d_h_status, B.d_h_seq, seq, static_cast<const uint32_t *>(src_a), words_a ? mapped(h_a) : nullptr, words_a,
+                           static_cast<const uint32_t *>(src_b), words_b ? mapped(h_b) : nullptr, words_b, reset ? 1u : 0u);
+        return wait_status(seq);
     };
     auto sort_ops = [&](uint32_t n, const uint64_t *key_src, uint64_t *ksorted, uint32_t *perm, const uint32_t *n_extra = nullptr) -> int {      // by (placement key, reference order): two stable radix sorts
         if (n <= RB2_SORT_SMALL) { hipLaunchKernelGGL(k_rb2_sort_small, dim3(1), dim3(1024), 0, st, n, key_src, (const uint64_t *)B.ord.p, ksorted, perm, n_extra); return RE_OK; }      // (one launch of one workgroup)
@@ -1961,34 +1964,35 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         HIPCHK(c, re::sort_pairs_u64_u32(B.tmp.p, &tb, B.kgath.p, ksorted, B.perm_a.p, perm, n, 0, 64, st));
         return RE_OK;
     };
-    // ---- phase 1 + 2: ops, the shared placements
-    hipLaunchKernelGGL(k_rb2_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), C, S, c->cfg.outline_length, c->cfg.atomic_length,
-                       B.key.p, B.key2.p, B.ord.p, B.row.p, B.idx.p, B.mk.p, B.mnk.p, B.host_list.p, B.status.p);
-    { int rc = sort_ops(n1, B.key.p, B.ksorted1.p, B.perm1.p); if (rc != RE_OK) return rc; }
-    hipLaunchKernelGGL(k_rb2_shared_segments, dim3((n1 + 255) / 256), dim3(256), 0, st, n1, M, (const uint32_t *)B.perm1.p, (const uint64_t *)B.ksorted1.p, (const uint32_t *)B.row.p, B.ord.p,
-                       (const uint64_t *)B.mk.p, (const uint8_t *)B.mnk.p, S, C, B.key2.p, B.row.p, B.idx.p, link_cap, B.segs_s.p, B.status.p);
-    // ---- phase 3: the unique placements with the link ops merged in.  A batch whose ops AND every link op they can emit (8 per op) fit the one-workgroup sort does not
-    // wait for the count of link ops: the kernels read it from the status block, and a fallback raised by phase 2 is seen with phase 3's (nothing is touched before phase 4)
+    // ---- phases 1-3: the ops, the shared placements (link ops for the sections they link), the unique placements with the link ops merged in
     const bool general = getenv("RE_EXP_RB2_GENERAL") != nullptr;            // (tests: small batches through the kernels of large ones; read per batch)
-    const bool chained = 9u * n1 <= RB2_SORT_SMALL && !general;
-    if (chained) {
-        const uint32_t *n_link = &B.status.p->n_link;
-        { int rc = sort_ops(n1, B.key2.p, B.ksorted2.p, B.perm2.p, n_link); if (rc != RE_OK) return rc; }
-        hipLaunchKernelGGL(k_rb2_unique_segments, dim3((9u * n1 + 255) / 256), dim3(256), 0, st, n1, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p, n_link);
+    const bool plan_small = M <= RB2_PLAN_SMALL && !general;
+    static_assert(RB2_PLAN_SMALL * 18u <= RB2_SORT_SMALL, "2 member ops per mover + 8 link ops per op");
+    if (plan_small) {                                                         // one launch of one workgroup, the status block published behind it
+        const uint32_t seq = ++B.seq;
+        hipLaunchKernelGGL(k_rb2_plan_small, dim3(1), dim3(1024), 0, st, M, (const uint32_t *)c->d_movers.p, row_arrays(c), C, S, T, c->cfg.outline_length, c->cfg.atomic_length,
+                           B.key.p, B.key2.p, B.ord.p, B.row.p, B.idx.p, B.mk.p, B.mnk.p, B.host_list.p, B.ksorted1.p, B.perm1.p, B.ksorted2.p, B.perm2.p, link_cap, (const uint8_t *)c->d_cell_links.p,
+                           B.segs_s.p, B.segs_u.p, B.status.p, B.d_h_status, B.d_h_seq, seq, mapped(B.h_segs_u));
+        { int rc = wait_status(seq); if (rc != RE_OK) return rc; }
     } else {
+        hipLaunchKernelGGL(k_rb2_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), C, S, c->cfg.outline_length, c->cfg.atomic_length,
+                           B.key.p, B.key2.p, B.ord.p, B.row.p, B.idx.p, B.mk.p, B.mnk.p, B.host_list.p, B.status.p);
+        { int rc = sort_ops(n1, B.key.p, B.ksorted1.p, B.perm1.p); if (rc != RE_OK) return rc; }
+        hipLaunchKernelGGL(k_rb2_shared_segments, dim3((n1 + 255) / 256), dim3(256), 0, st, n1, M, (const uint32_t *)B.perm1.p, (const uint64_t *)B.ksorted1.p, (const uint32_t *)B.row.p, B.ord.p,
+                           (const uint64_t *)B.mk.p, (const uint8_t *)B.mnk.p, S, C, B.key2.p, B.row.p, B.idx.p, link_cap, B.segs_s.p, B.status.p);
         { int rc = read_status(); if (rc != RE_OK) return rc; }
         lap("shared");
         if (hs.fallback || hs.n_link > link_cap) return 1;
         const uint32_t n2 = n1 + hs.n_link;
         { int rc = sort_ops(n2, B.key2.p, B.ksorted2.p, B.perm2.p); if (rc != RE_OK) return rc; }
-        hipLaunchKernelGGL(k_rb2_unique_segments, dim3((n2 + 255) / 256), dim3(256), 0, st, n2, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_rb2_unique_segments, dim3((n2 + 255) / 256), dim3(256), 0, st, n2, (const uint32_t *)B.perm2.p, (const uint64_t *)B.ksorted2.p, (const uint32_t *)B.row.p, T, C, c->d_cell_links.p, B.segs_u.p, B.status.p);
+        { int rc = read_status(); if (rc != RE_OK) return rc; }
     }
-    { int rc = read_status(); if (rc != RE_OK) return rc; }
     lap("unique");
     if (hs.fallback || hs.n_link > link_cap) return 1;
     if (!c->ghost_map.empty() || !c->dormant_cached.empty()) {               // sections this batch would create or retire: none may be one the ghost books of the frozen cache know
         const uint32_t nq = hs.nseg_u;
-        if (nq) { HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nq * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st)); HIPCHK(c, sync_stream(st)); }
+        if (nq && !plan_small) { HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nq * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st)); HIPCHK(c, sync_stream(st)); }      // (k_rb2_plan_small publishes the list with the status)
         for (uint32_t i2 = 0; i2 < nq; i2++) {
             const Rb2Seg &G = B.h_segs_u[i2];
             if (G.exists0 != G.exists1 && (c->ghost_map.count(G.key) || c->dormant_cached.count(G.key))) return 1;

@@ -68,10 +68,8 @@ __global__ __launch_bounds__(256) void k_rb2_hash_insert(uint32_t n, ShTable S) 
 
 // ---- small batches: (placement key, reference order) sorted by ONE workgroup (a bitonic network in LDS) instead of two radix sorts and a gather -- a batch of a
 // handful of movers (a change request that carries the user entity across a section border) is bound by the number of launches, not by the sorting
-__global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint64_t *__restrict__ key, const uint64_t *__restrict__ ord, uint64_t *__restrict__ key_sorted, uint32_t *__restrict__ perm, const uint32_t *n_extra) {
-    __shared__ uint64_t s_key[RB2_SORT_SMALL], s_ord[RB2_SORT_SMALL]; __shared__ uint32_t s_idx[RB2_SORT_SMALL];
+__device__ __forceinline__ void rb2_sort_block(uint32_t n, const uint64_t *key, const uint64_t *ord, uint64_t *key_sorted, uint32_t *perm, uint64_t *s_key, uint64_t *s_ord, uint32_t *s_idx) {      // a workgroup of 1,024
     const uint32_t tid = threadIdx.x;
-    if (n_extra) n = min(n + *n_extra, RB2_SORT_SMALL);                    // (a count an earlier kernel of the batch left on the device: the host has not read it)
     uint32_t m = 1; while (m < n) m <<= 1;                                  // (n <= RB2_SORT_SMALL: the host chose this kernel)
     for (uint32_t i = tid; i < m; i += 1024u) { const bool on = i < n; s_key[i] = on ? key[i] : ~0ull; s_ord[i] = on ? (ord ? ord[i] : 0ull) : ~0ull; s_idx[i] = on ? i : 0xFFFFFFFFu; }
     __syncthreads();
@@ -90,14 +88,19 @@ __global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint6
         }
     for (uint32_t i = tid; i < n; i += 1024u) { key_sorted[i] = s_key[i]; perm[i] = s_idx[i]; }
 }
+__global__ __launch_bounds__(1024) void k_rb2_sort_small(uint32_t n, const uint64_t *__restrict__ key, const uint64_t *__restrict__ ord, uint64_t *__restrict__ key_sorted, uint32_t *__restrict__ perm, const uint32_t *n_extra) {
+    __shared__ uint64_t s_key[RB2_SORT_SMALL], s_ord[RB2_SORT_SMALL]; __shared__ uint32_t s_idx[RB2_SORT_SMALL];
+    if (n_extra) n = min(n + *n_extra, RB2_SORT_SMALL);                    // (a count an earlier kernel of the batch left on the device: the host has not read it)
+    rb2_sort_block(n, key, ord, key_sorted, perm, s_key, s_ord, s_idx);
+}
 
 // ---- phase 1: two ops per mover --------------------------------------------------------------------------------------------------------------
 // The list may end with the rows a change batch DELETES (RB2_MOVER_DELETED; DeleteRequest -> remove_entity, entity_change_helpers.rs:109-136): they only have a remove op, ordered in
 // front of every mover in the order of the batch (apply_change removes them inline, before the kinematic re-adds).
-__global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic,
-                                                 uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_key2, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
-                                                 uint32_t *__restrict__ op_idx, uint64_t *__restrict__ mk, uint8_t *__restrict__ mnk, uint32_t *__restrict__ host_list, Rb2Status *st) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// (the bodies of phases 1-3 are functions of one op / one segment head: a kernel of their own for batches of any size, steps of k_rb2_plan_small for small ones.  No __restrict__
+// here: in the fused kernel one step reads what the step before wrote)
+__device__ __forceinline__ void rb2_ops_one(uint32_t i, uint32_t m, const uint32_t *movers, const RowArrays &R, const RbCells &C, const ShTable &S, uint32_t outline, uint32_t atomic,
+                                            uint64_t *op_key, uint64_t *op_key2, uint64_t *op_ord, uint32_t *op_row, uint32_t *op_idx, uint64_t *mk, uint8_t *mnk, uint32_t *host_list, Rb2Status *st) {
     if (i >= m) return;
     if (movers[i] & RB2_MOVER_DELETED) {
         const uint32_t r = movers[i] & 0x1FFFFFFFu, rc = C.row_cell[r];
@@ -152,14 +155,16 @@ __global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__r
     op_key2[2 * i] = (pold & RB2_SHARED_BIT) ? ~0ull : pold;
     op_key2[2 * i + 1] = (pnew & RB2_SHARED_BIT) ? ~0ull : pnew;
 }
+__global__ __launch_bounds__(256) void k_rb2_ops(uint32_t m, const uint32_t *__restrict__ movers, RowArrays R, RbCells C, ShTable S, uint32_t outline, uint32_t atomic,
+                                                 uint64_t *__restrict__ op_key, uint64_t *__restrict__ op_key2, uint64_t *__restrict__ op_ord, uint32_t *__restrict__ op_row,
+                                                 uint32_t *__restrict__ op_idx, uint64_t *__restrict__ mk, uint8_t *__restrict__ mnk, uint32_t *__restrict__ host_list, Rb2Status *st) {
+    rb2_ops_one(blockIdx.x * blockDim.x + threadIdx.x, m, movers, R, C, S, outline, atomic, op_key, op_key2, op_ord, op_row, op_idx, mk, mnk, host_list, st);
+}
 
 // ---- phase 2: the shared placements.  One thread per placement (segment head of the first sort) replays remove_entity / add_entity on the shared section's
 // counts (re_api.hip: rebucket, `replay`); every creation / emptying on the way becomes link ops for the sections it links ------------------------------------
-__global__ __launch_bounds__(256) void k_rb2_shared_segments(uint32_t n, uint32_t m, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
-                                                             uint64_t *__restrict__ op_ord, const uint64_t *__restrict__ mk, const uint8_t *__restrict__ mnk, ShTable S, RbCells C,
-                                                             uint64_t *__restrict__ op_key2, uint32_t *__restrict__ op_row_w, uint32_t *__restrict__ op_idx, uint32_t link_cap,
-                                                             Rb2ShSeg *__restrict__ segs, Rb2Status *st) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void rb2_shared_segment_one(uint32_t t, uint32_t n, uint32_t m, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, uint64_t *op_ord, const uint64_t *mk,
+                                                       const uint8_t *mnk, const ShTable &S, const RbCells &C, uint64_t *op_key2, uint32_t *op_row_w, uint32_t *op_idx, uint32_t link_cap, Rb2ShSeg *segs, Rb2Status *st) {
     if (t >= n) return;
     const uint64_t pkey = key_sorted[t];
     if (!(pkey & RB2_SHARED_BIT) || pkey == ~0ull) return;                 // unique placements: phase 3; ~0: the movers left to the host path
@@ -209,12 +214,16 @@ __global__ __launch_bounds__(256) void k_rb2_shared_segments(uint32_t n, uint32_
         if (idx0 < 0 || size > S.rowcap[idx0]) { const uint32_t cap = size * 2u > 4u ? size * 2u : 4u; atomicAdd(&st->need_pool, cap); }
     }
 }
+__global__ __launch_bounds__(256) void k_rb2_shared_segments(uint32_t n, uint32_t m, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
+                                                             uint64_t *__restrict__ op_ord, const uint64_t *__restrict__ mk, const uint8_t *__restrict__ mnk, ShTable S, RbCells C,
+                                                             uint64_t *__restrict__ op_key2, uint32_t *__restrict__ op_row_w, uint32_t *__restrict__ op_idx, uint32_t link_cap,
+                                                             Rb2ShSeg *__restrict__ segs, Rb2Status *st) {
+    rb2_shared_segment_one(blockIdx.x * blockDim.x + threadIdx.x, n, m, perm, key_sorted, op_row, op_ord, mk, mnk, S, C, op_key2, op_row_w, op_idx, link_cap, segs, st);
+}
 
 // ---- phase 3: the unique placements, member ops and link ops merged by the reference's order -----------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rb2_unique_segments(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
-                                                             RbTables T, RbCells C, uint8_t *__restrict__ cell_links, Rb2Seg *__restrict__ segs, Rb2Status *st, const uint32_t *n_extra) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_extra) n += *n_extra;                                              // (as in k_rb2_sort_small; the grid covers the bound)
+__device__ __forceinline__ void rb2_unique_segment_one(uint32_t t, uint32_t n, const uint32_t *perm, const uint64_t *key_sorted, const uint32_t *op_row, const RbTables &T, const RbCells &C,
+                                                       const uint8_t *cell_links, Rb2Seg *segs, Rb2Status *st) {
     if (t >= n) return;
     const uint64_t key = key_sorted[t];
     if (key == ~0ull) return;
@@ -249,6 +258,10 @@ __global__ __launch_bounds__(256) void k_rb2_unique_segments(uint32_t n, const u
         if (slot < 0) atomicAdd(&st->need_slots[key_level(key) & (MAX_LEVELS - 1)], 1u);
         if (changed && (slot < 0 || size > C.cell_cap[slot])) { const uint32_t cap = size * 2u > 4u ? size * 2u : 4u; atomicAdd(&st->need_pool, cap); }
     }
+}
+__global__ __launch_bounds__(256) void k_rb2_unique_segments(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ key_sorted, const uint32_t *__restrict__ op_row,
+                                                             RbTables T, RbCells C, uint8_t *__restrict__ cell_links, Rb2Seg *__restrict__ segs, Rb2Status *st) {
+    rb2_unique_segment_one(blockIdx.x * blockDim.x + threadIdx.x, n, perm, key_sorted, op_row, T, C, cell_links, segs, st);
 }
 
 // members of one placement rewritten in place: the active rows that stay (compacted), the arrivals merged in ascending EntityId from the back, the static
@@ -562,20 +575,50 @@ __global__ __launch_bounds__(256) void k_rb2_gather_u32(uint32_t n, const uint32
 // synchronise cost ~15 us per read-back, three times a batch
 // ... and, for the last read-back of a small batch, the segment lists with it (words_a / words_b 32-bit words) and the block reset for the next batch (everything but pool_used, which the
 // device keeps current)
-__global__ __launch_bounds__(256) void k_rb2_publish_status(Rb2Status *__restrict__ st, Rb2Status *__restrict__ h_st, uint32_t *h_seq, uint32_t seq,
-                                                            const uint32_t *__restrict__ src_a, uint32_t *__restrict__ dst_a, uint32_t words_a,
-                                                            const uint32_t *__restrict__ src_b, uint32_t *__restrict__ dst_b, uint32_t words_b, uint32_t reset) {
+__device__ __forceinline__ void rb2_publish_block(Rb2Status *st, Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, const uint32_t *src_a, uint32_t *dst_a, uint32_t words_a,
+                                                  const uint32_t *src_b, uint32_t *dst_b, uint32_t words_b, uint32_t reset) {      // the whole workgroup
     static_assert(sizeof(Rb2Status) % 4u == 0 && sizeof(Rb2Status) / 4u <= 256u, "one word per thread");
     uint32_t *src = reinterpret_cast<uint32_t *>(st); uint32_t *dst = reinterpret_cast<uint32_t *>(h_st);
     if (threadIdx.x < sizeof(Rb2Status) / 4u) {
         dst[threadIdx.x] = __hip_atomic_load(src + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (reset && threadIdx.x != offsetof(Rb2Status, pool_used) / 4u) src[threadIdx.x] = 0u;
     }
-    for (uint32_t i = threadIdx.x; i < words_a; i += 256u) dst_a[i] = src_a[i];
-    for (uint32_t i = threadIdx.x; i < words_b; i += 256u) dst_b[i] = src_b[i];
+    for (uint32_t i = threadIdx.x; i < words_a; i += blockDim.x) dst_a[i] = __hip_atomic_load(src_a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = threadIdx.x; i < words_b; i += blockDim.x) dst_b[i] = __hip_atomic_load(src_b + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wait_own_stores();
     __syncthreads();                                                          // every wave's host stores have left before thread 0 publishes
     if (threadIdx.x == 0) publish_to_host(h_seq, seq);
+}
+__global__ __launch_bounds__(256) void k_rb2_publish_status(Rb2Status *st, Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, const uint32_t *src_a, uint32_t *dst_a, uint32_t words_a,
+                                                            const uint32_t *src_b, uint32_t *dst_b, uint32_t words_b, uint32_t reset) {
+    rb2_publish_block(st, h_st, h_seq, seq, src_a, dst_a, words_a, src_b, dst_b, words_b, reset);
+}
+
+// ---- small batches (<= RB2_PLAN_SMALL movers: their ops and every link op they can emit fit the one-workgroup sort): phases 1-3 and the status read-back as ONE launch of
+// ONE workgroup.  A batch that carries the user entity across a section border took five launches and a read-back to get here; each dependent launch costs 5-7 us, whatever it does.
+// Between the steps: a workgroup barrier with its workgroup-scope fence -- the waves of a workgroup share one L1, which is write-through, and atomics are performed in the L2 behind it,
+// so nothing more is needed for one step to see what the step before wrote.  (An AGENT-scope fence here writes back and invalidates the XCD's L2: measured, it made this kernel slower
+// than the five launches it replaces.)
+__device__ __forceinline__ void rb2_phase_barrier() { __syncthreads(); }
+__global__ __launch_bounds__(1024) void k_rb2_plan_small(uint32_t m, const uint32_t *movers, RowArrays R, RbCells C, ShTable S, RbTables T, uint32_t outline, uint32_t atomic,
+                                                         uint64_t *op_key, uint64_t *op_key2, uint64_t *op_ord, uint32_t *op_row, uint32_t *op_idx, uint64_t *mk, uint8_t *mnk, uint32_t *host_list,
+                                                         uint64_t *ksorted1, uint32_t *perm1, uint64_t *ksorted2, uint32_t *perm2, uint32_t link_cap, const uint8_t *cell_links,
+                                                         Rb2ShSeg *segs_s, Rb2Seg *segs_u, Rb2Status *st, Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, uint32_t *h_segs_u) {
+    __shared__ uint64_t s_key[RB2_SORT_SMALL], s_ord[RB2_SORT_SMALL]; __shared__ uint32_t s_idx[RB2_SORT_SMALL];
+    const uint32_t tid = threadIdx.x, n1 = 2u * m;
+    for (uint32_t i = tid; i < m; i += 1024u) rb2_ops_one(i, m, movers, R, C, S, outline, atomic, op_key, op_key2, op_ord, op_row, op_idx, mk, mnk, host_list, st);
+    rb2_phase_barrier();
+    rb2_sort_block(n1, op_key, op_ord, ksorted1, perm1, s_key, s_ord, s_idx);
+    rb2_phase_barrier();
+    for (uint32_t t = tid; t < n1; t += 1024u) rb2_shared_segment_one(t, n1, m, perm1, ksorted1, op_row, op_ord, mk, mnk, S, C, op_key2, op_row, op_idx, link_cap, segs_s, st);
+    rb2_phase_barrier();
+    const uint32_t n2 = min(n1 + __hip_atomic_load(&st->n_link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), RB2_SORT_SMALL);      // (n1 * 9 <= RB2_SORT_SMALL: the host chose this kernel)
+    rb2_sort_block(n2, op_key2, op_ord, ksorted2, perm2, s_key, s_ord, s_idx);
+    rb2_phase_barrier();
+    for (uint32_t t = tid; t < n2; t += 1024u) rb2_unique_segment_one(t, n2, perm2, ksorted2, op_row, T, C, cell_links, segs_u, st);
+    rb2_phase_barrier();
+    const uint32_t nu = __hip_atomic_load(&st->nseg_u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the planned unique segments with the status: the host checks the sections they create or retire against its ghost books)
+    rb2_publish_block(st, h_st, h_seq, seq, reinterpret_cast<const uint32_t *>(segs_u), h_segs_u, nu * (uint32_t)(sizeof(Rb2Seg) / 4u), nullptr, nullptr, 0u, 0u);
 }
 __global__ __launch_bounds__(256) void k_rb2_clear_deleted(uint32_t n, const uint32_t *__restrict__ movers, uint32_t *__restrict__ row_cell) {      // the deleted rows are in no section any more
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
