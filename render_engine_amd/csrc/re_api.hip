@@ -2020,6 +2020,20 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     const uint32_t *a_free_u = inline_free ? mapped(B.h_free_u) : B.free_u.p, *a_free_s = inline_free ? mapped(B.h_free_s) : B.free_s.p, *a_free_off = inline_free ? mapped(B.h_free_off) : B.free_off.p;
     const uint32_t nu = hs.nseg_u, ns = hs.nseg_s;
     uint32_t nsh_after = c->nsh; for (uint32_t x : fs) nsh_after = std::max(nsh_after, x + 1u);
+    const Rb2Status planned = hs;                                            // (the plan of the phases above; the block is read back once more below)
+    Rb2Status &h2 = *B.h_status;
+    const bool apply_small = !general && inline_free && 8u * ns <= RB2_STATIC_SMALL_PAIRS && nsh_after <= RB2_STATIC_SMALL_SHARED && nu + ns <= 2048u;      // (k_rb2_static_small's limits; segment lists the workgroup can publish)
+    if (apply_small) {                                                        // the whole of phase 4 and its read-back: one launch of one workgroup (behind the per-segment kernels when there are more than a few)
+        const bool wide = nu + ns > 32u;                                       // more segments than two rounds of the workgroup's 16 waves: a workgroup per segment first
+        if (wide && nu) hipLaunchKernelGGL(k_rb2_apply_unique, dim3(nu), dim3(64), 0, st, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), c->d_cell_links.p, B.segs_u.p, B.status.p,
+                                           a_free_u, a_free_off, B.tmp_u.p, B.refold.p);
+        if (wide && ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3(ns), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p, a_free_s, B.tmp_s.p);
+        const uint32_t seq = ++B.seq;
+        hipLaunchKernelGGL(k_rb2_apply_small, dim3(1), dim3(1024), 0, st, M, (const uint32_t *)c->d_movers.p, n_deleted ? 1u : 0u, (const uint32_t *)B.perm1.p, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p,
+                           T, C, row_arrays(c), S, c->d_cell_links.p, c->d_cell_inact.p, c->d_cell_tight.p, B.segs_u.p, B.segs_s.p, B.status.p, a_free_u, a_free_off, a_free_s, B.tmp_u.p, B.tmp_s.p, B.refold.p,
+                           nsh_after, c->cfg.atomic_length, hs.total > 500u ? 1u : 0u, wide ? 1u : 0u, B.d_h_status, B.d_h_seq, seq, mapped(B.h_segs_u), mapped(B.h_segs_s));
+        { int rc = wait_status(seq); if (rc != RE_OK) return rc; }
+    } else {
     if (nu) hipLaunchKernelGGL(k_rb2_apply_unique, dim3(nu), dim3(64), 0, st, (const uint32_t *)B.perm2.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), c->d_cell_links.p, B.segs_u.p, B.status.p,
                                a_free_u, a_free_off, B.tmp_u.p, B.refold.p);
     if (ns) hipLaunchKernelGGL(k_rb2_apply_shared, dim3(ns), dim3(64), 0, st, (const uint32_t *)B.perm1.p, (const uint32_t *)B.row.p, T, C, row_arrays(c), S, B.segs_s.p, B.status.p,
@@ -2053,8 +2067,6 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
                                c->d_aabb.p, c->d_cell_tight.p, c->cfg.atomic_length, hs.total > 500u ? 1 : 0);
     if (n_deleted) hipLaunchKernelGGL(k_rb2_clear_deleted, dim3((M + 255) / 256), dim3(256), 0, st, M, (const uint32_t *)c->d_movers.p, c->d_row_cell.p);
     HIPCHK(c, hipGetLastError());
-    const Rb2Status planned = hs;                                            // (the plan of the phases above; the block is read back once more below)
-    Rb2Status &h2 = *B.h_status;
     static_assert(sizeof(Rb2Seg) % 4u == 0 && sizeof(Rb2ShSeg) % 4u == 0, "segment lists are copied by words");
     const uint32_t wu = nu * (uint32_t)(sizeof(Rb2Seg) / 4u), ws = ns * (uint32_t)(sizeof(Rb2ShSeg) / 4u);
     if ((uint64_t)wu + ws <= RB2_INLINE_WORDS) {
@@ -2063,6 +2075,7 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
         if (nu) HIPCHK(c, hipMemcpyAsync(B.h_segs_u, B.segs_u.p, (size_t)nu * sizeof(Rb2Seg), hipMemcpyDeviceToHost, st));
         if (ns) HIPCHK(c, hipMemcpyAsync(B.h_segs_s, B.segs_s.p, (size_t)ns * sizeof(Rb2ShSeg), hipMemcpyDeviceToHost, st));
         int rc = read_status(nullptr, nullptr, 0, nullptr, nullptr, 0, true); if (rc != RE_OK) return rc;      // (stream order: the segment copies above have landed when the sequence word arrives)
+    }
     }
     B.status_clean = h2.err == 0; B.status_pool = h2.pool_used;
     const Rb2Seg *su = B.h_segs_u; const Rb2ShSeg *ss = B.h_segs_s;

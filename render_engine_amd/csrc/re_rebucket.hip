@@ -372,11 +372,9 @@ __device__ __forceinline__ Rb2Rewrite rb2_rewrite_members_wave(const uint32_t *_
 }
 
 // ---- phase 4a: the unique sections (one WAVE per section) -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rb2_apply_unique(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, uint8_t *__restrict__ cell_links,
-                                                         Rb2Seg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_slots, const uint32_t *__restrict__ free_off,
-                                                         uint32_t *__restrict__ tmp_row, uint32_t *__restrict__ refold) {
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
-    if (s >= st->nseg_u) return;
+// (as with phases 1-3: the body is a function of one segment and one wave -- a kernel with a workgroup per segment for batches of any size, a step of k_rb2_apply_small for small ones)
+__device__ __forceinline__ void rb2_apply_unique_one(uint32_t s, uint32_t lane, const uint32_t *perm, const uint32_t *op_row, const RbTables &T, const RbCells &C, const RowArrays &R, uint8_t *cell_links,
+                                                     Rb2Seg *segs, Rb2Status *st, const uint32_t *free_slots, const uint32_t *free_off, uint32_t *tmp_row, uint32_t *refold) {
     Rb2Seg S = segs[s];
     const uint32_t lv = key_level(S.key) & (MAX_LEVELS - 1);
     if (!S.exists1) {
@@ -411,12 +409,16 @@ __global__ __launch_bounds__(64) void k_rb2_apply_unique(const uint32_t *__restr
     }
     if (lane == 0) { segs[s] = S; refold[s] = (S.changed || S.created) ? sl : 0xFFFFFFFFu; }      // end_of_changes / update_static_world_sections touch the changed (and the new) sections
 }
+__global__ __launch_bounds__(64) void k_rb2_apply_unique(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, uint8_t *__restrict__ cell_links,
+                                                         Rb2Seg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_slots, const uint32_t *__restrict__ free_off,
+                                                         uint32_t *__restrict__ tmp_row, uint32_t *__restrict__ refold) {
+    if (blockIdx.x >= st->nseg_u) return;
+    rb2_apply_unique_one(blockIdx.x, threadIdx.x, perm, op_row, T, C, R, cell_links, segs, st, free_slots, free_off, tmp_row, refold);
+}
 
 // ---- phase 4b: the shared sections (stable indices: a retired entry is a hole, a new one takes a free index the host handed over); one WAVE per section ---------
-__global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, ShTable S,
-                                                         Rb2ShSeg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_sh, uint32_t *__restrict__ tmp_row) {
-    const uint32_t s = blockIdx.x, lane = threadIdx.x;
-    if (s >= st->nseg_s) return;
+__device__ __forceinline__ void rb2_apply_shared_one(uint32_t s, uint32_t lane, const uint32_t *perm, const uint32_t *op_row, const RbTables &T, const RbCells &C, const RowArrays &R, const ShTable &S,
+                                                     Rb2ShSeg *segs, Rb2Status *st, const uint32_t *free_sh, uint32_t *tmp_row) {
     Rb2ShSeg G = segs[s];
     if (!G.exists1) {
         if (G.idx >= 0 && lane == 0) {
@@ -451,6 +453,11 @@ __global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restr
         S.aabb[idx] = u;
         G.na1 = r.na1; segs[s] = G;
     }
+}
+__global__ __launch_bounds__(64) void k_rb2_apply_shared(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ op_row, RbTables T, RbCells C, RowArrays R, ShTable S,
+                                                         Rb2ShSeg *__restrict__ segs, Rb2Status *st, const uint32_t *__restrict__ free_sh, uint32_t *__restrict__ tmp_row) {
+    if (blockIdx.x >= st->nseg_s) return;
+    rb2_apply_shared_one(blockIdx.x, threadIdx.x, perm, op_row, T, C, R, S, segs, st, free_sh, tmp_row);
 }
 
 // ---- phase 4c: update_static_world_sections (bounding_box_tree_v2.rs:1133-1213) --------------------------------------------------------------------------
@@ -503,9 +510,9 @@ __global__ __launch_bounds__(256) void k_rb2_static_second(uint32_t n, const uin
 }
 // small batches: both loops in ONE workgroup (mark, first loop, unmark, the pairs, their sort in LDS, second loop) -- eight launches and a read-back of the pair count less.
 // The arrays are read and written through plain pointers (no __restrict__): later steps read what earlier steps of this kernel wrote, ordered by the workgroup barriers.
-__global__ __launch_bounds__(1024) void k_rb2_static_small(uint32_t nsh, ShTable S, RbCells C, const uint8_t *cell_links, uint8_t *cell_inact, const Rb2Seg *segs_u, const Rb2ShSeg *segs_s, const Rb2Status *st) {
-    __shared__ uint64_t s_key[RB2_STATIC_SMALL_PAIRS]; __shared__ uint32_t s_np;
-    const uint32_t tid = threadIdx.x, nu = st->nseg_u, ns = st->nseg_s;
+__device__ __forceinline__ void rb2_static_block(uint32_t nsh, const ShTable &S, const RbCells &C, const uint8_t *cell_links, uint8_t *cell_inact, const Rb2Seg *segs_u, const Rb2ShSeg *segs_s, uint32_t nu, uint32_t ns,
+                                                 uint64_t *s_key, uint32_t &s_np) {      // a workgroup of 1,024; s_key: RB2_STATIC_SMALL_PAIRS words of LDS
+    const uint32_t tid = threadIdx.x;
     if (tid == 0) s_np = 0u;
     if (nu) {
         for (uint32_t v = 0; v < 2u; v++) {                                  // v = 0: mark, then the first loop; v = 1: unmark
@@ -566,6 +573,10 @@ __global__ __launch_bounds__(1024) void k_rb2_static_small(uint32_t nsh, ShTable
         C.cell_flags[sl] = f;
     }
 }
+__global__ __launch_bounds__(1024) void k_rb2_static_small(uint32_t nsh, ShTable S, RbCells C, const uint8_t *cell_links, uint8_t *cell_inact, const Rb2Seg *segs_u, const Rb2ShSeg *segs_s, const Rb2Status *st) {
+    __shared__ uint64_t s_key[RB2_STATIC_SMALL_PAIRS]; __shared__ uint32_t s_np;
+    rb2_static_block(nsh, S, C, cell_links, cell_inact, segs_u, segs_s, st->nseg_u, st->nseg_s, s_key, s_np);
+}
 
 __global__ __launch_bounds__(256) void k_rb2_gather_u32(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -619,6 +630,39 @@ __global__ __launch_bounds__(1024) void k_rb2_plan_small(uint32_t m, const uint3
     rb2_phase_barrier();
     const uint32_t nu = __hip_atomic_load(&st->nseg_u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the planned unique segments with the status: the host checks the sections they create or retire against its ghost books)
     rb2_publish_block(st, h_st, h_seq, seq, reinterpret_cast<const uint32_t *>(segs_u), h_segs_u, nu * (uint32_t)(sizeof(Rb2Seg) / 4u), nullptr, nullptr, 0u, 0u);
+}
+// ... and phase 4 of such a batch: the unique sections (a wave each, 16 at a time), the shared sections, update_static_world_sections, the tight AABBs of end_of_changes, the rows the
+// batch deleted, then the status block and both segment lists for the host's bookkeeping, and the status block reset for the next batch -- six to eleven launches as one
+__global__ __launch_bounds__(1024) void k_rb2_apply_small(uint32_t m, const uint32_t *movers, uint32_t has_deleted, const uint32_t *perm1, const uint32_t *perm2, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R,
+                                                          ShTable S, uint8_t *cell_links, uint8_t *cell_inact, Aabb *cell_tight, Rb2Seg *segs_u, Rb2ShSeg *segs_s, Rb2Status *st, const uint32_t *free_u,
+                                                          const uint32_t *free_off, const uint32_t *free_s, uint32_t *tmp_u, uint32_t *tmp_s, uint32_t *refold, uint32_t nsh, uint32_t atomic, uint32_t too_many, uint32_t segments_done,
+                                                          Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, uint32_t *h_segs_u, uint32_t *h_segs_s) {
+    __shared__ uint64_t s_key[RB2_STATIC_SMALL_PAIRS]; __shared__ uint32_t s_np;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t nu = st->nseg_u, ns = st->nseg_s;                          // (the plan of k_rb2_plan_small: not written here)
+    if (!segments_done) {                                                     // (more than a few segments: k_rb2_apply_unique / k_rb2_apply_shared ran in front of this kernel, a workgroup per segment -- 16 waves at a time are 9 rounds of dependent loads for 143 segments)
+        for (uint32_t s = wave; s < nu; s += 16u) rb2_apply_unique_one(s, lane, perm2, op_row, T, C, R, cell_links, segs_u, st, free_u, free_off, tmp_u, refold);
+        rb2_phase_barrier();
+        for (uint32_t s = wave; s < ns; s += 16u) rb2_apply_shared_one(s, lane, perm1, op_row, T, C, R, S, segs_s, st, free_s, tmp_s);
+        rb2_phase_barrier();
+    }
+    rb2_static_block(nsh, S, C, cell_links, cell_inact, segs_u, segs_s, nu, ns, s_key, s_np);
+    rb2_phase_barrier();
+    for (uint32_t i = tid; i < nu; i += 1024u) {                              // end_of_changes (k_fold_tight_list)
+        const uint32_t c = refold[i];
+        if (c == 0xFFFFFFFFu) continue;
+        const uint64_t key = C.cell_key[c];
+        const uint32_t n = C.cell_nl[c] + C.cell_ns[c];
+        uint32_t adj = 20u + key_level(key) * 5u; if (adj > 50u) adj = 50u;
+        Aabb u = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        if (too_many && n > adj) u = key_to_aabb(key, atomic);
+        else { const uint32_t b = C.cell_begin[c]; for (uint32_t k = 0; k < n; k++) { const Aabb e = R.aabb[C.rows[b + k]]; u = (k == 0) ? e : combine_aabb(u, e); } }
+        cell_tight[c] = u;
+    }
+    if (has_deleted) for (uint32_t i = tid; i < m; i += 1024u) if (movers[i] & RB2_MOVER_DELETED) C.row_cell[movers[i] & 0x1FFFFFFFu] = ROW_CELL_NONE;
+    rb2_phase_barrier();
+    rb2_publish_block(st, h_st, h_seq, seq, reinterpret_cast<const uint32_t *>(segs_u), h_segs_u, nu * (uint32_t)(sizeof(Rb2Seg) / 4u),
+                      reinterpret_cast<const uint32_t *>(segs_s), h_segs_s, ns * (uint32_t)(sizeof(Rb2ShSeg) / 4u), 1u);
 }
 __global__ __launch_bounds__(256) void k_rb2_clear_deleted(uint32_t n, const uint32_t *__restrict__ movers, uint32_t *__restrict__ row_cell) {      // the deleted rows are in no section any more
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
