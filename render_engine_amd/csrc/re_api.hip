@@ -1966,15 +1966,21 @@ static int rebucket_on_device2(re_ctx *c, uint32_t M, std::vector<uint32_t> *hos
     };
     // ---- phases 1-3: the ops, the shared placements (link ops for the sections they link), the unique placements with the link ops merged in
     const bool general = getenv("RE_EXP_RB2_GENERAL") != nullptr;            // (tests: small batches through the kernels of large ones; read per batch)
-    const bool plan_small = M <= RB2_PLAN_SMALL && !general;
-    static_assert(RB2_PLAN_SMALL * 18u <= RB2_SORT_SMALL, "2 member ops per mover + 8 link ops per op");
+    bool plan_small = M <= RB2_PLAN_SMALL && !general;
+    static_assert(RB2_PLAN_SMALL * 2u <= RB2_SORT_SMALL, "2 member ops per mover");
     if (plan_small) {                                                         // one launch of one workgroup, the status block published behind it
         const uint32_t seq = ++B.seq;
         hipLaunchKernelGGL(k_rb2_plan_small, dim3(1), dim3(1024), 0, st, M, (const uint32_t *)c->d_movers.p, row_arrays(c), C, S, T, c->cfg.outline_length, c->cfg.atomic_length,
                            B.key.p, B.key2.p, B.ord.p, B.row.p, B.idx.p, B.mk.p, B.mnk.p, B.host_list.p, B.ksorted1.p, B.perm1.p, B.ksorted2.p, B.perm2.p, link_cap, (const uint8_t *)c->d_cell_links.p,
                            B.segs_s.p, B.segs_u.p, B.status.p, B.d_h_status, B.d_h_seq, seq, mapped(B.h_segs_u));
         { int rc = wait_status(seq); if (rc != RE_OK) return rc; }
-    } else {
+        if (n1 + hs.n_link > RB2_SORT_SMALL) {                                // the link ops did not fit the one-workgroup sort (many shared sections created / emptied): the plan is void, again below
+            plan_small = false;
+            hs = Rb2Status{}; hs.pool_used = c->pool_used;
+            HIPCHK(c, hipMemcpyAsync(B.status.p, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+        }
+    }
+    if (!plan_small) {
         hipLaunchKernelGGL(k_rb2_ops, dim3((M + 255) / 256), dim3(256), 0, st, M, c->d_movers.p, row_arrays(c), C, S, c->cfg.outline_length, c->cfg.atomic_length,
                            B.key.p, B.key2.p, B.ord.p, B.row.p, B.idx.p, B.mk.p, B.mnk.p, B.host_list.p, B.status.p);
         { int rc = sort_ops(n1, B.key.p, B.ksorted1.p, B.perm1.p); if (rc != RE_OK) return rc; }

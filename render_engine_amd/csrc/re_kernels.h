@@ -312,7 +312,7 @@ __global__ void k_rb2_unique_segments(uint32_t n, const uint32_t *perm, const ui
 __global__ void k_rb2_apply_small(uint32_t m, const uint32_t *movers, uint32_t has_deleted, const uint32_t *perm1, const uint32_t *perm2, const uint32_t *op_row, RbTables T, RbCells C, RowArrays R, ShTable S,
                                   uint8_t *cell_links, uint8_t *cell_inact, Aabb *cell_tight, Rb2Seg *segs_u, Rb2ShSeg *segs_s, Rb2Status *st, const uint32_t *free_u, const uint32_t *free_off, const uint32_t *free_s,
                                   uint32_t *tmp_u, uint32_t *tmp_s, uint32_t *refold, uint32_t nsh, uint32_t atomic, uint32_t too_many, uint32_t segments_done, Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, uint32_t *h_segs_u, uint32_t *h_segs_s);
-constexpr uint32_t RB2_PLAN_SMALL = RB2_SORT_SMALL / 18u;   // movers of a batch whose ops (2 each) and every link op they can emit (8 per op) fit the one-workgroup sort: phases 1-3 in one launch (k_rb2_plan_small)
+constexpr uint32_t RB2_PLAN_SMALL = RB2_SORT_SMALL / 2u;   // movers of a batch whose ops (2 each) fit the one-workgroup sort: phases 1-3 in one launch (k_rb2_plan_small) -- if the link ops they emit (up to 8 per op) fit too; the host sees from the status block when they did not and plans the batch again with the kernels of large batches
 __global__ void k_rb2_plan_small(uint32_t m, const uint32_t *movers, RowArrays R, RbCells C, ShTable S, RbTables T, uint32_t outline, uint32_t atomic, uint64_t *op_key, uint64_t *op_key2, uint64_t *op_ord,
                                  uint32_t *op_row, uint32_t *op_idx, uint64_t *mk, uint8_t *mnk, uint32_t *host_list, uint64_t *ksorted1, uint32_t *perm1, uint64_t *ksorted2, uint32_t *perm2, uint32_t link_cap,
                                  const uint8_t *cell_links, Rb2ShSeg *segs_s, Rb2Seg *segs_u, Rb2Status *st, Rb2Status *h_st, uint32_t *h_seq, uint32_t seq, uint32_t *h_segs_u);

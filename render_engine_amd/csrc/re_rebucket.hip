@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void k_rb2_publish_status(Rb2Status *st, Rb2St
     rb2_publish_block(st, h_st, h_seq, seq, src_a, dst_a, words_a, src_b, dst_b, words_b, reset);
 }
 
-// ---- small batches (<= RB2_PLAN_SMALL movers: their ops and every link op they can emit fit the one-workgroup sort): phases 1-3 and the status read-back as ONE launch of
+// ---- small batches (<= RB2_PLAN_SMALL movers: their ops fit the one-workgroup sort, and so do, nearly always, the link ops they emit): phases 1-3 and the status read-back as ONE launch of
 // ONE workgroup.  A batch that carries the user entity across a section border took five launches and a read-back to get here; each dependent launch costs 5-7 us, whatever it does.
 // Between the steps: a workgroup barrier with its workgroup-scope fence -- the waves of a workgroup share one L1, which is write-through, and atomics are performed in the L2 behind it,
 // so nothing more is needed for one step to see what the step before wrote.  (An AGENT-scope fence here writes back and invalidates the XCD's L2: measured, it made this kernel slower
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(1024) void k_rb2_plan_small(uint32_t m, const uint3
     rb2_phase_barrier();
     for (uint32_t t = tid; t < n1; t += 1024u) rb2_shared_segment_one(t, n1, m, perm1, ksorted1, op_row, op_ord, mk, mnk, S, C, op_key2, op_row, op_idx, link_cap, segs_s, st);
     rb2_phase_barrier();
-    const uint32_t n2 = min(n1 + __hip_atomic_load(&st->n_link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), RB2_SORT_SMALL);      // (n1 * 9 <= RB2_SORT_SMALL: the host chose this kernel)
+    const uint32_t n2 = min(n1 + __hip_atomic_load(&st->n_link, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), RB2_SORT_SMALL);      // (more link ops than fit: phase 3 below plans on a truncated list, nothing is touched, and the host -- n1 + n_link > RB2_SORT_SMALL in the status block -- plans again)
     rb2_sort_block(n2, op_key2, op_ord, ksorted2, perm2, s_key, s_ord, s_idx);
     rb2_phase_barrier();
     for (uint32_t t = tid; t < n2; t += 1024u) rb2_unique_segment_one(t, n2, perm2, ksorted2, op_row, T, C, cell_links, segs_u, st);
