@@ -1,15 +1,16 @@
 // re_lighting.hip -- BASELINE.json configs[4]: the deferred-lighting second pass of render_engine
 // (render_engine_assets/shaders/second_pass_frag.glsl:20-139) as a HIP compute kernel for gfx950, plus its C ABI.
 //
-// Tiled deferred shading.  One 256-thread workgroup owns a 32x32-pixel tile (4 pixels per lane):
+// Tiled deferred shading.  One 256-thread workgroup owns a 32x16-pixel tile (2 pixels per lane; each wave a compact 16x8 block of it):
 //   1. tile AABB of the G-buffer positions (wave shuffles + LDS),
 //   2. exact-conservative culling of the radius ("spot") lights against the tile AABB, 256 lights per round, compacted
 //      into an LDS list (ballot + prefix: the per-pixel summation order is deterministic).  Only the lights that can reach the
 //      tile along one axis are tested: re_lighting_set_lights orders the records by LIGHT_BUCKETS slabs along the axis of the
 //      lights' largest extent (ascending light index inside a slab), and a tile takes the slabs its AABB, grown by the largest
 //      radius, overlaps -- 192 of the 4096 lights of configs[4] instead of all of them,
-//   3. every lane shades its 4 pixels over the list; the light record (64 B) is fetched with scalar loads
-//      (wave-uniform index), so the inner loop is pure f32 VALU -- the kernel is VALU-bound, not HBM-bound,
+//   3. every lane shades its pixels over the list, a pair at a time as 2-vectors; the listed lights' records (64 B) are staged in LDS by the
+//      whole workgroup and read as broadcasts, so the inner loop is pure f32 VALU -- the kernel is VALU-bound, not HBM-bound; a light that
+//      reaches no pixel of the wave's block costs the wave its distance test only,
 //   4. cone ("point") lights cannot be culled (no radius in the shader) and are evaluated for every pixel,
 //   5. epilogue exactly as main(): (spot + point) + spot -- the spot term is added twice in the shader --, the
 //      default-diffuse floor, clamp.
@@ -27,6 +28,7 @@
 namespace {
 
 constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 512;
+constexpr int NPX = 2, NPAIR = NPX / 2, TILE_H = 8 * NPX;   // pixels per lane (pairs of them shaded as 2-vectors); a workgroup's tile is TILE x TILE_H pixels, a wave's share of it 16 x 4 NPX
 constexpr uint32_t CULL_CHUNK = 2;      // rounds of 256 lights whose positions are in flight together (a tile of configs[4] tests 192 lights; more rounds in flight cost registers: 8 -> 152 VGPRs, 2 -> 128)
 constexpr uint32_t LIGHT_BUCKETS = 4096; // slabs along the sort axis of the radius lights
 
@@ -127,12 +129,15 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
     __shared__ float4 s_rec[LIST_CAP * 4];                                    // the listed lights' records (A, B, C, D)
     __shared__ uint32_t s_wcnt[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
-    const uint32_t tx = blockIdx.x * TILE + (tid & 31u), ty0 = blockIdx.y * TILE + (tid >> 5);
-    float3 frag[4], nrm[4], od[4], camdir[4], acc[4]; bool live[4];
+    // A wave owns a 16x16 QUADRANT of the tile (lane -> column lane & 15, rows (lane >> 4) + 4k): a listed light that misses the quadrant costs the wave its distance test only (shade_pair
+    // returns with no lane inside).  With the rows of a wave spread over the whole tile (round 2: row (tid >> 5) + 8k) every wave went through the full evaluation of nearly every listed light.
+    static_assert(TILE == 32 && LT_THREADS == 256 && NPX % 2 == 0, "four waves, one quadrant each; pixels in pairs");
+    const uint32_t tx = blockIdx.x * TILE + 16u * (wid & 1u) + (lane & 15u), ty0 = blockIdx.y * TILE_H + (uint32_t)(4 * NPX) * (wid >> 1) + (lane >> 4);
+    float3 frag[NPX], nrm[NPX], od[NPX], camdir[NPX], acc[NPX]; bool live[NPX];
     float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t y = ty0 + 8u * k;
+    for (int k = 0; k < NPX; k++) {
+        uint32_t y = ty0 + 4u * k;
         live[k] = tx < P.width && y < P.height;
         frag[k] = nrm[k] = od[k] = camdir[k] = f3(0.f, 0.f, 0.f); acc[k] = f3(0.f, 0.f, 0.f);
         if (live[k]) {
@@ -161,9 +166,9 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         // together before their tests, and the 64-byte records of the listed lights are fetched into LDS by the whole workgroup in one go, so the
         // per-pixel loop reads them as LDS broadcasts (round 1 loaded each light's record with scalar loads inside that loop: one exposed L2
         // latency per listed light and tile).
-        PixelPair X[2]; f2 sax[2], say[2], saz[2];                              // pixels (0, 1) and (2, 3) of the lane
+        PixelPair X[NPAIR]; f2 sax[NPAIR], say[NPAIR], saz[NPAIR];                // pixels (0, 1), (2, 3) .. of the lane
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
+        for (int q = 0; q < NPAIR; q++) {
             const int k0 = 2 * q, k1 = 2 * q + 1;
             X[q].fx.x = frag[k0].x; X[q].fx.y = frag[k1].x; X[q].fy.x = frag[k0].y; X[q].fy.y = frag[k1].y; X[q].fz.x = frag[k0].z; X[q].fz.y = frag[k1].z;
             X[q].nx.x = nrm[k0].x; X[q].nx.y = nrm[k1].x; X[q].ny.x = nrm[k0].y; X[q].ny.y = nrm[k1].y; X[q].nz.x = nrm[k0].z; X[q].nz.y = nrm[k1].z;
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
             for (uint32_t j = 0; j < n; j++) {
                 const float4 A = s_rec[j * 4u], B = s_rec[j * 4u + 1u], C = s_rec[j * 4u + 2u], D = s_rec[j * 4u + 3u];
 #pragma unroll
-                for (int q = 0; q < 2; q++) shade_pair(X[q], live[2 * q], live[2 * q + 1], A, B, C, D, sax[q], say[q], saz[q]);
+                for (int q = 0; q < NPAIR; q++) shade_pair(X[q], live[2 * q], live[2 * q + 1], A, B, C, D, sax[q], say[q], saz[q]);
             }
             __syncthreads();                                                   // (s_rec / s_list are refilled afterwards)
             n = 0;
@@ -216,22 +221,22 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         }
         if (n) shade_list();
         // ---- cone lights (calculatePointLights :72-91): no radius, every pixel evaluates every light ----
-        float3 point_acc[4]; for (int k = 0; k < 4; k++) point_acc[k] = f3(0.f, 0.f, 0.f);
+        float3 point_acc[NPX]; for (int k = 0; k < NPX; k++) point_acc[k] = f3(0.f, 0.f, 0.f);
         for (uint32_t l = 0; l < P.n_point; l++) {
             float4 A = point[(size_t)l * 6], B = point[(size_t)l * 6 + 1], C = point[(size_t)l * 6 + 2], D = point[(size_t)l * 6 + 3], E = point[(size_t)l * 6 + 4], F = point[(size_t)l * 6 + 5];
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (live[k]) {
+            for (int k = 0; k < NPX; k++) if (live[k]) {
                 float3 fn = norm3v(frag[k]);
                 float angle = dot3(sub3(fn, f3(A.x, A.y, A.z)), f3(E.x, E.y, E.z));
                 float intensity = fminf(fmaxf((angle - F.y) / (F.x - F.y), 0.0f), 1.0f);
                 shade(frag[k], nrm[k], od[k], camdir[k], A, B, C, D, false, intensity, point_acc[k]);
             }
         }
-        float3 spot_acc[4];
+        float3 spot_acc[NPX];
 #pragma unroll
-        for (int q = 0; q < 2; q++) { spot_acc[2 * q] = f3(sax[q].x, say[q].x, saz[q].x); spot_acc[2 * q + 1] = f3(sax[q].y, say[q].y, saz[q].y); }
+        for (int q = 0; q < NPAIR; q++) { spot_acc[2 * q] = f3(sax[q].x, say[q].x, saz[q].x); spot_acc[2 * q + 1] = f3(sax[q].y, say[q].y, saz[q].y); }
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NPX; k++) {
             // main() :42-44: lightColour = spot; lightColour += point; lightColour += spot
             acc[k].x = (spot_acc[k].x + point_acc[k].x) + spot_acc[k].x; acc[k].y = (spot_acc[k].y + point_acc[k].y) + spot_acc[k].y; acc[k].z = (spot_acc[k].z + point_acc[k].z) + spot_acc[k].z;
             acc[k].x += (acc[k].x < P.cutoff ? 1.0f : 0.0f) * od[k].x * P.default_diffuse;
@@ -241,10 +246,10 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) acc[k] = f3(od[k].x * 1.0f * P.default_diffuse, od[k].y * 1.0f * P.default_diffuse, od[k].z * 1.0f * P.default_diffuse);   // :30-34
+        for (int k = 0; k < NPX; k++) acc[k] = f3(od[k].x * 1.0f * P.default_diffuse, od[k].y * 1.0f * P.default_diffuse, od[k].z * 1.0f * P.default_diffuse);   // :30-34
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (live[k]) out[(size_t)(ty0 + 8u * k) * P.width + tx] = make_float4(acc[k].x, acc[k].y, acc[k].z, 1.0f);
+    for (int k = 0; k < NPX; k++) if (live[k]) out[(size_t)(ty0 + 4u * k) * P.width + tx] = make_float4(acc[k].x, acc[k].y, acc[k].z, 1.0f);
 }
 
 __global__ void k_gather_pixels(const float4 *img, const uint32_t *idx, uint32_t n, float4 *out) {
@@ -354,7 +359,7 @@ extern "C" int re_lighting_run(re_lighting *l, float *kernel_us) try {
     LCHK(l, hipSetDevice(l->cfg.device));
     hipEvent_t a = nullptr, b = nullptr;
     if (kernel_us) { LCHK(l, hipEventCreate(&a)); LCHK(l, hipEventCreate(&b)); }
-    dim3 grid((l->cfg.width + TILE - 1) / TILE, (l->cfg.height + TILE - 1) / TILE);
+    dim3 grid((l->cfg.width + TILE - 1) / TILE, (l->cfg.height + TILE_H - 1) / TILE_H);
     hipExtLaunchKernelGGL(k_deferred_lighting, grid, dim3(LT_THREADS), 0, l->stream, a, b, 0, l->P, l->d_pos, l->d_nrm, l->d_alb, l->d_spot, l->d_slab, l->d_point, l->d_out);
     LCHK(l, hipGetLastError());
     LCHK(l, hipStreamSynchronize(l->stream));
