@@ -27,9 +27,9 @@
 
 namespace {
 
-constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 512;
+constexpr int TILE = 32, LT_THREADS = 256, LIST_CAP = 384;
 constexpr int NPX = 2, NPAIR = NPX / 2, TILE_H = 8 * NPX;   // pixels per lane (pairs of them shaded as 2-vectors); a workgroup's tile is TILE x TILE_H pixels, a wave's share of it 16 x 4 NPX
-constexpr uint32_t CULL_CHUNK = 2;      // rounds of 256 lights whose positions are in flight together (a tile of configs[4] tests 192 lights; more rounds in flight cost registers: 8 -> 152 VGPRs, 2 -> 128)
+constexpr uint32_t CULL_CHUNK = 1;      // rounds of 256 lights whose positions are in flight together (a tile of configs[4] tests 192 lights; more rounds in flight cost registers: 8 -> 152 VGPRs, 2 -> 128)
 constexpr uint32_t LIGHT_BUCKETS = 4096; // slabs along the sort axis of the radius lights
 
 struct LightParams {
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
                                                                    const float4 *__restrict__ point,    // 5 float4 per light: A(pos), B, C, D, E(dir.xyz normalised, -) + F(cutoff, outer, -, -) packed as 6
                                                                    float4 *__restrict__ out) {
     __shared__ float s_red[4][6];
-    __shared__ uint32_t s_list[LIST_CAP];
     __shared__ float4 s_rec[LIST_CAP * 4];                                    // the listed lights' records (A, B, C, D)
     __shared__ uint32_t s_wcnt[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -177,15 +176,13 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
             sax[q] = say[q] = saz[q] = (f2)(0.0f);
         }
         uint32_t n = 0;                                                        // listed lights (uniform)
-        auto shade_list = [&]() {
-            for (uint32_t idx = tid; idx < n * 4u; idx += LT_THREADS) s_rec[idx] = spot[(size_t)s_list[idx >> 2] * 4 + (idx & 3u)];
-            __syncthreads();
+        auto shade_list = [&]() {                                              // (the records are in s_rec: the lane that listed a light put its record there, behind the barrier of the round)
             for (uint32_t j = 0; j < n; j++) {
                 const float4 A = s_rec[j * 4u], B = s_rec[j * 4u + 1u], C = s_rec[j * 4u + 2u], D = s_rec[j * 4u + 3u];
 #pragma unroll
                 for (int q = 0; q < NPAIR; q++) shade_pair(X[q], live[2 * q], live[2 * q + 1], A, B, C, D, sax[q], say[q], saz[q]);
             }
-            __syncthreads();                                                   // (s_rec / s_list are refilled afterwards)
+            __syncthreads();                                                   // (s_rec is refilled afterwards)
             n = 0;
         };
         // the records a light of this tile can be among: the slabs [lo - rmax, hi + rmax] along the sort axis (a light farther away along that axis alone misses the tile)
@@ -194,9 +191,15 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         uint32_t l_begin = 0, l_end = 0;
         if (P.n_spot && ahi >= alo) { l_begin = slab_start[light_bucket(alo - reach, P.kmin, P.inv_w)]; l_end = slab_start[light_bucket(ahi + reach, P.kmin, P.inv_w) + 1u]; }
         for (uint32_t c0 = l_begin; c0 < l_end; c0 += LT_THREADS * CULL_CHUNK) {
-            float4 Ac[CULL_CHUNK];
+            // the WHOLE record of every light tested (64 B, L2-resident: 4,096 lights are 256 KB), not its position alone: a lane that lists its light stores the record into LDS at once,
+            // and the tile does not wait for a second round trip (list -> records) before it can shade
+            float4 Ac[CULL_CHUNK], Bc[CULL_CHUNK], Cc[CULL_CHUNK], Dc[CULL_CHUNK];
 #pragma unroll
-            for (uint32_t r = 0; r < CULL_CHUNK; r++) { const uint32_t li = c0 + r * LT_THREADS + tid; Ac[r] = li < l_end ? spot[(size_t)li * 4] : make_float4(0.f, 0.f, 0.f, -1.f); }
+            for (uint32_t r = 0; r < CULL_CHUNK; r++) {
+                const uint32_t li = c0 + r * LT_THREADS + tid;
+                Ac[r] = make_float4(0.f, 0.f, 0.f, -1.f); Bc[r] = Cc[r] = Dc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (li < l_end) { Ac[r] = spot[(size_t)li * 4]; Bc[r] = spot[(size_t)li * 4 + 1]; Cc[r] = spot[(size_t)li * 4 + 2]; Dc[r] = spot[(size_t)li * 4 + 3]; }
+            }
 #pragma unroll
             for (uint32_t r = 0; r < CULL_CHUNK; r++) {
                 const uint32_t i0 = c0 + r * LT_THREADS;
@@ -213,7 +216,10 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
                 __syncthreads();
                 uint32_t base = n, tot = 0;
                 for (uint32_t w = 0; w < 4; w++) { if (w < wid) base += s_wcnt[w]; tot += s_wcnt[w]; }
-                if (hit) s_list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = li;
+                if (hit) {
+                    const uint32_t at = (base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) * 4u;
+                    s_rec[at] = Ac[r]; s_rec[at + 1u] = Bc[r]; s_rec[at + 2u] = Cc[r]; s_rec[at + 3u] = Dc[r];
+                }
                 __syncthreads();
                 n += tot;
                 if (n + LT_THREADS > LIST_CAP) shade_list();                    // uniform decision: the next round could overflow the list
