@@ -141,7 +141,12 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         frag[k] = nrm[k] = od[k] = camdir[k] = f3(0.f, 0.f, 0.f); acc[k] = f3(0.f, 0.f, 0.f);
         if (live[k]) {
             size_t p = (size_t)y * P.width + tx;
-            float4 gp = gpos[p], gn = gnormal[p]; uchar4 ga = galbedo[p];
+            // (streamed once: non-temporal, so the G-buffer does not push the light records and slab bounds out of the L2)
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f gpv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gpos) + p), gnv = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(gnormal) + p);
+            const uint32_t gaw = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(galbedo) + p);
+            const float4 gp = make_float4(gpv.x, gpv.y, gpv.z, gpv.w), gn = make_float4(gnv.x, gnv.y, gnv.z, gnv.w);
+            uchar4 ga; ga.x = (unsigned char)(gaw & 0xFFu); ga.y = (unsigned char)((gaw >> 8) & 0xFFu); ga.z = (unsigned char)((gaw >> 16) & 0xFFu); ga.w = (unsigned char)(gaw >> 24);
             frag[k] = f3(gp.x, gp.y, gp.z); nrm[k] = f3(gn.x, gn.y, gn.z);
             // (per-pixel setup with the hardware's 1-ulp operations, like the shading itself: the IEEE divisions and square root here were ~300 of a tile's ~1,900 instructions per wave)
             constexpr float k255 = 1.0f / 255.0f;
@@ -255,7 +260,11 @@ __global__ __launch_bounds__(LT_THREADS) void k_deferred_lighting(LightParams P,
         for (int k = 0; k < NPX; k++) acc[k] = f3(od[k].x * 1.0f * P.default_diffuse, od[k].y * 1.0f * P.default_diffuse, od[k].z * 1.0f * P.default_diffuse);   // :30-34
     }
 #pragma unroll
-    for (int k = 0; k < NPX; k++) if (live[k]) out[(size_t)(ty0 + 4u * k) * P.width + tx] = make_float4(acc[k].x, acc[k].y, acc[k].z, 1.0f);
+    for (int k = 0; k < NPX; k++) if (live[k]) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f o; o.x = acc[k].x; o.y = acc[k].y; o.z = acc[k].z; o.w = 1.0f;
+        __builtin_nontemporal_store(o, reinterpret_cast<v4f *>(out) + ((size_t)(ty0 + 4u * k) * P.width + tx));
+    }
 }
 
 __global__ void k_gather_pixels(const float4 *img, const uint32_t *idx, uint32_t n, float4 *out) {
